@@ -1,0 +1,163 @@
+/*
+ * svh.h -- C-ABI of libsvhip.so, the MI355X (gfx950) implementation of the
+ * dense/sparse stereo hot path of willSapgreen/stereo-vision.
+ *
+ * Every entry point is plain C: opaque handles, raw pointers, sizes.  No C++
+ * or torch types cross this boundary.  Each function names the reference
+ * interface it replaces (paths relative to the reference checkout).
+ *
+ * The C++ drop-in classes in include/elas.h and include/matcher.h are thin
+ * wrappers over these calls; INTEGRATION.md shows the reference-side binding.
+ */
+#ifndef SVH_H
+#define SVH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* return codes                                                              */
+/* ------------------------------------------------------------------------ */
+#define SVH_OK                 0
+#define SVH_ERR_FEW_SUPPORT    1  /* <3 support points: outputs untouched, message on
+                                     stdout (libelas/src/elas.cpp:69-75)              */
+#define SVH_ERR_BAD_ARG       -1
+#define SVH_ERR_HIP           -2  /* HIP runtime failure; svh_last_error() has text   */
+#define SVH_ERR_UNSUPPORTED   -3  /* parameter combination not implemented on device  */
+#define SVH_ERR_NO_DEVICE     -4
+
+/* ------------------------------------------------------------------------ */
+/* ELAS parameters: field-for-field Elas::parameters (libelas/src/elas.h:59-148),
+ * bools widened to int32 for a stable ABI.                                   */
+/* ------------------------------------------------------------------------ */
+typedef struct svh_elas_params {
+    int32_t disp_min;
+    int32_t disp_max;
+    float   support_threshold;
+    int32_t support_texture;
+    int32_t candidate_stepsize;
+    int32_t incon_window_size;
+    int32_t incon_threshold;
+    int32_t incon_min_support;
+    int32_t add_corners;
+    int32_t grid_size;
+    float   beta;
+    float   gamma;
+    float   sigma;
+    float   sradius;
+    int32_t match_texture;
+    int32_t lr_threshold;
+    float   speckle_sim_threshold;
+    int32_t speckle_size;
+    int32_t ipol_gap_width;
+    int32_t filter_median;
+    int32_t filter_adaptive_mean;
+    int32_t postprocess_only_left;
+    int32_t subsampling;
+} svh_elas_params;
+
+#define SVH_ELAS_ROBOTICS   0
+#define SVH_ELAS_MIDDLEBURY 1
+
+/* Elas::parameters::parameters(setting) -- libelas/src/elas.h:86-147 */
+void svh_elas_params_default(svh_elas_params* p, int32_t setting);
+
+/* ------------------------------------------------------------------------ */
+/* library / device                                                          */
+/* ------------------------------------------------------------------------ */
+const char* svh_version(void);
+/* thread-local text of the last failure on the calling thread */
+const char* svh_last_error(void);
+int32_t     svh_device_count(void);
+/* bind the calling thread's subsequent svh_* objects to a HIP device */
+int32_t     svh_set_device(int32_t device);
+
+/* ------------------------------------------------------------------------ */
+/* Elas                                                                      */
+/* ------------------------------------------------------------------------ */
+typedef struct svh_elas svh_elas;
+
+/* Elas::Elas(parameters) -- libelas/src/elas.h:151.  Cheap: callers build one
+ * per frame (stereomapper/stereothread.cpp:113); device buffers live in a
+ * process-wide pool keyed by (device, width, height).                        */
+svh_elas* svh_elas_create(const svh_elas_params* p);
+/* Elas::~Elas() -- libelas/src/elas.h:154 */
+void      svh_elas_destroy(svh_elas* e);
+
+/* Elas::process(I1,I2,D1,D2,dims) -- libelas/src/elas.h:165, elas.cpp:32-170.
+ * Host pointers; dims = {width, height, bytes_per_line}; D1/D2 tightly packed
+ * width x height float (width/2 x height/2 when subsampling).  Synchronous:
+ * inputs are consumed and outputs complete on return.                        */
+int32_t svh_elas_process(svh_elas* e, const uint8_t* I1, const uint8_t* I2,
+                         float* D1, float* D2, const int32_t* dims);
+
+/* n independent pairs of identical dims, pipelined over the engine's lanes
+ * (one HIP stream + one host worker each).  status[i] receives the per-pair
+ * return code (may be NULL).  Returns the first non-OK status or SVH_OK.     */
+int32_t svh_elas_process_batch(svh_elas* e, int32_t n,
+                               const uint8_t* const* I1, const uint8_t* const* I2,
+                               float* const* D1, float* const* D2,
+                               const int32_t* dims, int32_t* status);
+
+/* Same, with images and disparity maps resident in device memory (HBM):
+ * dI1/dI2 point at n images of dims[2]*dims[1] bytes spaced in_stride bytes
+ * apart, dD1/dD2 at n maps spaced out_stride bytes apart.                   */
+int32_t svh_elas_process_batch_device(svh_elas* e, int32_t n,
+                                      const uint8_t* dI1, const uint8_t* dI2, size_t in_stride,
+                                      float* dD1, float* dD2, size_t out_stride,
+                                      const int32_t* dims, int32_t* status);
+
+/* number of pipeline lanes (streams + host workers) the engine uses per device */
+int32_t svh_elas_set_lanes(int32_t lanes);
+
+/* Stage taps for parity tests: after a successful svh_elas_process() the
+ * intermediate of the given stage (of the last pair processed through handle
+ * e) is copied to buf.  *size receives the byte size; returns SVH_ERR_BAD_ARG
+ * when cap is too small.  Taps are recorded only after svh_elas_set_taps(e,1). */
+enum svh_elas_stage {
+    SVH_ELAS_DESC1 = 0,      /* u8  [H][W][16]        descriptor.cpp:88-119          */
+    SVH_ELAS_DESC2,
+    SVH_ELAS_DCAN_RAW,       /* i16 [Hc][Wc]          elas.cpp:471-493               */
+    SVH_ELAS_SUPPORT,        /* i32 [n][3] (u,v,d)    elas.cpp:495-523               */
+    SVH_ELAS_TRI1,           /* i32 [n][3]            elas.cpp:534-600 (left)        */
+    SVH_ELAS_TRI2,           /* i32 [n][3]            (right)                        */
+    SVH_ELAS_PLANES1,        /* f32 [n][6] t1a..t2c   elas.cpp:605-680               */
+    SVH_ELAS_PLANES2,
+    SVH_ELAS_GRID1,          /* i32 [gh][gw][disp_max+2] elas.cpp:684-780            */
+    SVH_ELAS_GRID2,
+    SVH_ELAS_D1_RAW,         /* f32 [H][W]            elas.cpp:960-1118              */
+    SVH_ELAS_D2_RAW,
+    SVH_ELAS_D1_LR,          /* after leftRightConsistencyCheck elas.cpp:1122        */
+    SVH_ELAS_D2_LR,
+    SVH_ELAS_D1_SEG,         /* after removeSmallSegments elas.cpp:1208              */
+    SVH_ELAS_D2_SEG,
+    SVH_ELAS_D1_GAP,         /* after gapInterpolation elas.cpp:1330                 */
+    SVH_ELAS_D2_GAP,
+    SVH_ELAS_STAGE_COUNT
+};
+int32_t svh_elas_set_taps(svh_elas* e, int32_t enable);
+int32_t svh_elas_get_stage(svh_elas* e, int32_t stage, void* buf, size_t cap, size_t* size);
+
+/* per-stage GPU/host milliseconds of the last single svh_elas_process() call;
+ * names mirror the -DPROFILE labels of elas.cpp:58-163.  Returns the number
+ * of entries written (<= cap).                                               */
+int32_t svh_elas_last_timing(svh_elas* e, const char** names, float* ms, int32_t cap);
+
+/* ------------------------------------------------------------------------ */
+/* host-side geometry helpers that stay on the CPU; exported
+ * so they can be parity-tested directly.                                     */
+/* ------------------------------------------------------------------------ */
+/* Delaunay triangulation reproducing Triangle 1.6 "zQB" output order
+ * (libelas/src/triangle.cpp:8499; elas.cpp:534-600).  pts = n (x,y) floats.
+ * tri receives up to cap triangles (3 input-order vertex indices each).
+ * Returns the triangle count or a negative error.                            */
+int32_t svh_delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVH_H */

@@ -1,0 +1,103 @@
+"""Pin the CPU restatement (oracle/elas_oracle.cpp) to the reference.
+
+ * against the committed golden vectors (generated from the reference itself by
+   tests/golden/make_goldens.py) -- always runs;
+ * against the real reference compiled into oracle/_ref -- when that library is
+   present (build container and GPU box), on seeded synthetic pairs.
+Bit-exact on every stage, integer and float alike.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+CASES = ["urban1_robotics", "urban2_stereomapper", "urban3_demo", "cones_middlebury"]
+
+
+def load_case(case):
+    z = np.load(os.path.join(H.GOLDEN, case + ".npz"))
+    prm = H.ElasParams.from_buffer_copy(z["params"].tobytes())
+    l, r = H.golden_pair(str(z["crop"]))
+    return z, prm, l, r
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_golden(case, oracle_lib):
+    z, prm, l, r = load_case(case)
+    tri_fn = H.fixture_triangulator([z["tri1"], z["tri2"]])   # Triangle is not restated
+    run = H.oracle_elas_run(prm, l, r, tri_fn)
+    assert run.status == 0
+    hgt, wid = l.shape
+    for s in (H.DESC1, H.DESC2):
+        assert hashlib.sha256(run[s].tobytes()).hexdigest() == str(z[H.STAGE_NAMES[s] + "_sha256"])
+    assert np.array_equal(run[H.DESC1].reshape(hgt, wid, 16)[::16], z["desc1_rows16"])
+    for s in (H.SUPPORT, H.PLANES1, H.PLANES2):
+        assert np.array_equal(run[s], z[H.STAGE_NAMES[s]]), H.STAGE_NAMES[s]
+    for s in (H.GRID1, H.GRID2):
+        assert hashlib.sha256(run[s].tobytes()).hexdigest() == str(z[H.STAGE_NAMES[s] + "_sha256"])
+    for s in (H.D1_RAW, H.D2_RAW, H.D1_LR, H.D2_LR, H.D1_SEG, H.D2_SEG):
+        assert np.array_equal(run[s], z[H.STAGE_NAMES[s] + "_i16"].astype(np.float32)), H.STAGE_NAMES[s]
+    assert np.array_equal(run[H.D1_GAP], z["d1_gap"])
+    assert np.array_equal(run[H.D2_GAP], z["d2_gap"])
+    assert np.array_equal(run[H.D1_FINAL], z["d1"])
+    assert np.array_equal(run[H.D2_FINAL], z["d2"])
+
+
+def test_known_answers(oracle_lib):
+    """SURVEY 8c known-answer facts: prior table, plane radius, mean-filter mask."""
+    import ctypes as C
+    # adaptive-mean weights are the step function {4 if |x|<2, 2 if 2<=|x|<8, 0 otherwise}
+    prm = H.robotics()
+    for delta, wexp in [(0.0, 4), (1.5, 4), (2.0, 2), (7.9, 2), (8.0, 0), (100.0, 0)]:
+        D = np.full((16, 16), 50.0, np.float32)
+        D[8, 9] = 50.0 + delta
+        out = D.copy()
+        oracle_lib.orc_adaptive_mean(C.byref(prm), H._p(out), 16, 16)
+        # horizontal pass at (8,8): 7 taps of 50 (w=4) and one tap of 50+delta (w=wexp)
+        hval = np.float32((np.float32(7 * 4 * 50.0) + np.float32(wexp) * np.float32(50 + delta))
+                          / np.float32(28 + wexp))
+        assert out[8, 8] > 0 and abs(out[8, 8] - hval) < 0.5
+
+
+@pytest.mark.skipif(not H.have_ref_elas(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed,w,h,kw", [
+    (1, 320, 200, {}),
+    (2, 333, 117, {"postprocess_only_left": 0}),      # width not a multiple of 16
+    (3, 256, 160, {"support_texture": 30, "ipol_gap_width": 7}),
+    (4, 400, 240, {"disp_max": 63, "grid_size": 16, "candidate_stepsize": 4}),
+])
+def test_oracle_matches_reference_live(seed, w, h, kw, oracle_lib):
+    l, r = H.synth_pair(w, h, seed, dmax=48)
+    prm = H.robotics(**kw)
+    a = H.ref_elas_run(prm, l, r)
+    b = H.oracle_elas_run(prm, l, r)
+    assert a.status == b.status == 0
+    bad = [(n, c) for n, c in H.compare_runs(a, b) if c != 0]
+    assert not bad, bad
+
+
+@pytest.mark.skipif(not H.have_ref_elas(), reason="oracle/_ref not built")
+def test_oracle_middlebury_live(oracle_lib):
+    l, r = H.synth_pair(300, 220, 7, dmax=40)
+    prm = H.middlebury()
+    a = H.ref_elas_run(prm, l, r)
+    b = H.oracle_elas_run(prm, l, r)
+    bad = [(n, c) for n, c in H.compare_runs(a, b) if c != 0]
+    assert not bad, bad
+
+
+def test_too_few_support_points(oracle_lib, capsys):
+    """flat images: <3 support points, outputs untouched (elas.cpp:69-75)."""
+    import ctypes as C
+    I = np.full((64, 96), 77, np.uint8)
+    D1 = np.full((64, 96), -7.0, np.float32)
+    D2 = D1.copy()
+    prm = H.robotics()
+    cb = H.fixture_triangulator([])
+    st = oracle_lib.orc_elas_process(C.byref(prm), H._p(I), H._p(I), H._p(D1), H._p(D2),
+                                     H.dims_of(I), C.cast(cb, C.c_void_p))
+    assert st == 1
+    assert np.all(D1 == -7.0) and np.all(D2 == -7.0)
