@@ -1,0 +1,520 @@
+// Host-side Delaunay triangulation for the ELAS disparity prior and the
+// libviso2 outlier filter.
+//
+// The reference calls Shewchuk's Triangle in library mode with switches "zQB"
+// (libelas/src/elas.cpp:581-582, libviso2/src/matcher.cpp:1432-1433).  Support
+// points sit on a 5-px lattice, so several percent of the interior edges are
+// exactly co-circular and the result depends on Triangle's tie-breaking; the
+// triangle ORDER decides which plane the few multiply-covered pixels get, and
+// libviso2 match indices depend on which duplicate vertex survives.  This file
+// is an independent implementation of the same published algorithm --
+// Guibas & Stolfi divide-and-conquer on a triangle-based structure with Dwyer's
+// alternating cuts -- arranged so that it reproduces Triangle's observable
+// output exactly:
+//
+//   * vertex order: randomised quicksort / quickselect driven by the LCG
+//     seed = (seed*1366 + 150889) % 714025, seed 1 per call
+//     (triangle.cpp:4045-4049, 5446-5568), duplicates dropped keeping the first
+//     in sorted order (triangle.cpp:6179-6196), alternating-axis reorder
+//     (triangle.cpp:5582-5604);
+//   * recursion: split at n/2, left first, base cases of 2 and 3 vertices that
+//     create 2 resp. 4 triangle records (triangle.cpp:5953-6103);
+//   * merge: strict ">0" orientation / in-circle tests, "<=0" finish tests, the
+//     left candidate kept on co-circular ties, edge removal by in-place flips,
+//     exactly two new records per merge (triangle.cpp:5638-5934);
+//   * output: surviving records in creation order, corners (org,dest,apex) of
+//     orientation 0 (triangle.cpp:7800-7860).
+//
+// Differences by design: records live in flat index arrays (no pointers, no
+// pools), predicates are exact integer determinants (__int128) instead of
+// adaptive floating-point expansions -- same sign, coordinates are integers or
+// dyadic fractions -- and all state is per call, so the routine is re-entrant
+// (the reference keeps its LCG seed and predicate constants in globals,
+// triangle.cpp:541-550).
+#include <stdint.h>
+#include <string.h>
+
+#include <cmath>
+#include <vector>
+
+#include "../../include/svh.h"
+
+namespace svh {
+
+namespace {
+
+typedef __int128 i128;
+
+struct Handle {
+    int32_t t;  // record index (0 = "outer space")
+    int32_t o;  // orientation 0..2
+};
+
+class DivConq {
+public:
+    DivConq(const float* pts, int32_t n) : pts_(pts), n_(n), seed_(1) {}
+
+    // returns triangle count, or <0 on failure
+    int32_t run(int32_t* out, int32_t cap);
+
+private:
+    const float* pts_;
+    int32_t n_;
+    uint64_t seed_;
+    std::vector<int64_t> ix_, iy_;   // exact scaled integer coordinates
+    std::vector<int32_t> nb_;        // 3 neighbour handles per record, encoded t*4+o
+    std::vector<int32_t> vx_;        // 3 vertex ids per record, -1 = the ghost apex
+    std::vector<uint8_t> dead_;
+
+    float X(int32_t v) const { return pts_[2 * v]; }
+    float Y(int32_t v) const { return pts_[2 * v + 1]; }
+    float C(int32_t v, int axis) const { return pts_[2 * v + axis]; }
+
+    // ---- handle algebra -------------------------------------------------
+    static Handle next(Handle h) { h.o = (h.o + 1) % 3; return h; }
+    static Handle prev(Handle h) { h.o = (h.o + 2) % 3; return h; }
+    Handle sym(Handle h) const {
+        int32_t e = nb_[3 * h.t + h.o];
+        Handle r = {e >> 2, e & 3};
+        return r;
+    }
+    int32_t org(Handle h) const { return vx_[3 * h.t + (h.o + 1) % 3]; }
+    int32_t dest(Handle h) const { return vx_[3 * h.t + (h.o + 2) % 3]; }
+    int32_t apex(Handle h) const { return vx_[3 * h.t + h.o]; }
+    void set_org(Handle h, int32_t v) { vx_[3 * h.t + (h.o + 1) % 3] = v; }
+    void set_dest(Handle h, int32_t v) { vx_[3 * h.t + (h.o + 2) % 3] = v; }
+    void set_apex(Handle h, int32_t v) { vx_[3 * h.t + h.o] = v; }
+    void bond(Handle a, Handle b) {
+        nb_[3 * a.t + a.o] = b.t * 4 + b.o;
+        nb_[3 * b.t + b.o] = a.t * 4 + a.o;
+    }
+    Handle make() {
+        Handle h = {(int32_t)(vx_.size() / 3), 0};
+        for (int k = 0; k < 3; k++) {
+            nb_.push_back(0);  // outer space, orientation 0
+            vx_.push_back(-1);
+        }
+        dead_.push_back(0);
+        return h;
+    }
+
+    // ---- exact predicates -------------------------------------------------
+    int ccw(int32_t a, int32_t b, int32_t c) const {
+        i128 l = (i128)(ix_[a] - ix_[c]) * (iy_[b] - iy_[c]);
+        i128 r = (i128)(iy_[a] - iy_[c]) * (ix_[b] - ix_[c]);
+        return l > r ? 1 : (l < r ? -1 : 0);
+    }
+    int incircle(int32_t a, int32_t b, int32_t c, int32_t d) const {
+        i128 adx = ix_[a] - ix_[d], ady = iy_[a] - iy_[d];
+        i128 bdx = ix_[b] - ix_[d], bdy = iy_[b] - iy_[d];
+        i128 cdx = ix_[c] - ix_[d], cdy = iy_[c] - iy_[d];
+        i128 al = adx * adx + ady * ady, bl = bdx * bdx + bdy * bdy, cl = cdx * cdx + cdy * cdy;
+        i128 det = al * (bdx * cdy - cdx * bdy) + bl * (cdx * ady - adx * cdy) +
+                   cl * (adx * bdy - bdx * ady);
+        return det > 0 ? 1 : (det < 0 ? -1 : 0);
+    }
+
+    // ---- ordering ---------------------------------------------------------
+    uint32_t pick(uint32_t choices) {
+        seed_ = (seed_ * 1366u + 150889u) % 714025u;
+        return (uint32_t)(seed_ / (714025u / choices + 1));
+    }
+    bool less2(int32_t a, float p1, float p2, int axis) const {
+        float c1 = C(a, axis);
+        return c1 < p1 || (c1 == p1 && C(a, 1 - axis) < p2);
+    }
+    bool greater2(int32_t a, float p1, float p2, int axis) const {
+        float c1 = C(a, axis);
+        return c1 > p1 || (c1 == p1 && C(a, 1 - axis) > p2);
+    }
+    // Hoare partition around a pseudo-random pivot; returns the two scan ends
+    void partition(int32_t* a, int32_t n, int axis, int32_t* lo, int32_t* hi) {
+        int32_t pv = a[pick((uint32_t)n)];
+        float p1 = C(pv, axis), p2 = C(pv, 1 - axis);
+        int32_t l = -1, r = n;
+        while (l < r) {
+            do { l++; } while (l <= r && less2(a[l], p1, p2, axis));
+            do { r--; } while (l <= r && greater2(a[r], p1, p2, axis));
+            if (l < r) { int32_t t = a[l]; a[l] = a[r]; a[r] = t; }
+        }
+        *lo = l;
+        *hi = r;
+    }
+    void order_pair(int32_t* a, int axis) {
+        if (greater2(a[0], C(a[1], axis), C(a[1], 1 - axis), axis)) {
+            int32_t t = a[0]; a[0] = a[1]; a[1] = t;
+        }
+    }
+    void sort_xy(int32_t* a, int32_t n) {
+        if (n == 2) { order_pair(a, 0); return; }
+        int32_t l, r;
+        partition(a, n, 0, &l, &r);
+        if (l > 1) sort_xy(a, l);
+        if (r < n - 2) sort_xy(a + r + 1, n - r - 1);
+    }
+    void select(int32_t* a, int32_t n, int32_t median, int axis) {
+        if (n == 2) { order_pair(a, axis); return; }
+        int32_t l, r;
+        partition(a, n, axis, &l, &r);
+        if (l > median) select(a, l, median, axis);
+        if (r < median - 1) select(a + r + 1, n - r - 1, median - r - 1, axis);
+    }
+    void alternate(int32_t* a, int32_t n, int axis) {
+        int32_t half = n >> 1;
+        if (n <= 3) axis = 0;
+        select(a, n, half, axis);
+        if (n - half >= 2) {
+            if (half >= 2) alternate(a, half, 1 - axis);
+            alternate(a + half, n - half, 1 - axis);
+        }
+    }
+
+    void recurse(const int32_t* a, int32_t n, int axis, Handle* farleft, Handle* farright);
+    void merge(Handle* farleft, Handle* innerleft, Handle* innerright, Handle* farright, int axis);
+    bool scale_coordinates();
+};
+
+// Coordinates are float; every float is a dyadic rational, so scaling all of
+// them by one power of two makes the predicates exact in integers.  The
+// in-circle determinant needs 4*bits+3 <= 127.
+bool DivConq::scale_coordinates() {
+    int min_exp = 0;  // most negative exponent of a set low bit
+    float maxabs = 0.f;
+    for (int32_t i = 0; i < 2 * n_; i++) {
+        float f = pts_[i];
+        if (!(f == f) || std::fabs(f) > 1e9f) return false;
+        maxabs = std::fabs(f) > maxabs ? std::fabs(f) : maxabs;
+        if (f != 0.f && f != std::floor(f)) {
+            int e;
+            float m = std::frexp(f, &e);  // f = m * 2^e, 0.5 <= |m| < 1
+            int32_t mi = (int32_t)std::ldexp(m, 24);
+            int tz = 0;
+            while ((mi & 1) == 0) { mi >>= 1; tz++; }
+            int low = e - 24 + tz;  // exponent of the lowest set bit
+            if (low < min_exp) min_exp = low;
+        }
+    }
+    int int_bits = 1;
+    while (std::ldexp(1.0f, int_bits) <= maxabs) int_bits++;
+    if (int_bits - min_exp + 1 > 30) return false;
+    ix_.resize(n_);
+    iy_.resize(n_);
+    for (int32_t i = 0; i < n_; i++) {
+        ix_[i] = (int64_t)std::ldexp((double)pts_[2 * i], -min_exp);
+        iy_[i] = (int64_t)std::ldexp((double)pts_[2 * i + 1], -min_exp);
+    }
+    return true;
+}
+
+void DivConq::recurse(const int32_t* a, int32_t n, int axis, Handle* farleft, Handle* farright) {
+    if (n == 2) {
+        // an edge: two ghost records glued along all three sides
+        Handle L = make();
+        set_org(L, a[0]);
+        set_dest(L, a[1]);
+        Handle R = make();
+        set_org(R, a[1]);
+        set_dest(R, a[0]);
+        bond(L, R);
+        L = prev(L); R = next(R);
+        bond(L, R);
+        L = prev(L); R = next(R);
+        bond(L, R);
+        *farright = R;
+        *farleft = prev(R);
+        return;
+    }
+    if (n == 3) {
+        Handle mid = make(), t1 = make(), t2 = make(), t3 = make();
+        int area = ccw(a[0], a[1], a[2]);
+        if (area == 0) {
+            // collinear: two edges, four ghosts
+            set_org(mid, a[0]); set_dest(mid, a[1]);
+            set_org(t1, a[1]);  set_dest(t1, a[0]);
+            set_org(t2, a[2]);  set_dest(t2, a[1]);
+            set_org(t3, a[1]);  set_dest(t3, a[2]);
+            bond(mid, t1);
+            bond(t2, t3);
+            mid = next(mid); t1 = prev(t1); t2 = next(t2); t3 = prev(t3);
+            bond(mid, t3);
+            bond(t1, t2);
+            mid = next(mid); t1 = prev(t1); t2 = next(t2); t3 = prev(t3);
+            bond(mid, t1);
+            bond(t2, t3);
+            *farleft = t1;
+            *farright = t2;
+        } else {
+            // one real triangle (mid) fenced by three ghosts
+            int32_t p = area > 0 ? a[1] : a[2];
+            int32_t q = area > 0 ? a[2] : a[1];
+            set_org(mid, a[0]); set_dest(t1, a[0]); set_org(t3, a[0]);
+            set_dest(mid, p);   set_org(t1, p);     set_dest(t2, p);
+            set_apex(mid, q);   set_org(t2, q);     set_dest(t3, q);
+            bond(mid, t1);
+            mid = next(mid);
+            bond(mid, t2);
+            mid = next(mid);
+            bond(mid, t3);
+            t1 = prev(t1); t2 = next(t2);
+            bond(t1, t2);
+            t1 = prev(t1); t3 = prev(t3);
+            bond(t1, t3);
+            t2 = next(t2); t3 = prev(t3);
+            bond(t2, t3);
+            *farleft = t1;
+            *farright = area > 0 ? t2 : next(t1);
+        }
+        return;
+    }
+    int32_t half = n >> 1;
+    Handle innerleft, innerright;
+    recurse(a, half, 1 - axis, farleft, &innerleft);
+    recurse(a + half, n - half, 1 - axis, &innerright, farright);
+    merge(farleft, &innerleft, &innerright, farright, axis);
+}
+
+void DivConq::merge(Handle* farleft, Handle* innerleft, Handle* innerright, Handle* farright,
+                    int axis) {
+    int32_t il_dest = dest(*innerleft), il_apex = apex(*innerleft);
+    int32_t ir_org = org(*innerright), ir_apex = apex(*innerright);
+
+    if (axis == 1) {
+        // horizontal cut: walk the four extreme handles from leftmost/rightmost
+        // to bottommost/topmost (undone at the end)
+        int32_t fl_pt = org(*farleft), fl_apex = apex(*farleft);
+        int32_t fr_pt = dest(*farright);
+        while (Y(fl_apex) < Y(fl_pt)) {
+            *farleft = sym(next(*farleft));
+            fl_pt = fl_apex;
+            fl_apex = apex(*farleft);
+        }
+        Handle chk = sym(*innerleft);
+        int32_t cv = apex(chk);
+        while (Y(cv) > Y(il_dest)) {
+            *innerleft = next(chk);
+            il_apex = il_dest;
+            il_dest = cv;
+            chk = sym(*innerleft);
+            cv = apex(chk);
+        }
+        while (Y(ir_apex) < Y(ir_org)) {
+            *innerright = sym(next(*innerright));
+            ir_org = ir_apex;
+            ir_apex = apex(*innerright);
+        }
+        chk = sym(*farright);
+        cv = apex(chk);
+        while (Y(cv) > Y(fr_pt)) {
+            *farright = next(chk);
+            fr_pt = cv;
+            chk = sym(*farright);
+            cv = apex(chk);
+        }
+    }
+    // lower common tangent
+    bool moved;
+    do {
+        moved = false;
+        if (ccw(il_dest, il_apex, ir_org) > 0) {
+            *innerleft = sym(prev(*innerleft));
+            il_dest = il_apex;
+            il_apex = apex(*innerleft);
+            moved = true;
+        }
+        if (ccw(ir_apex, ir_org, il_dest) > 0) {
+            *innerright = sym(next(*innerright));
+            ir_org = ir_apex;
+            ir_apex = apex(*innerright);
+            moved = true;
+        }
+    } while (moved);
+
+    Handle lcand = sym(*innerleft), rcand = sym(*innerright);
+    // bottom ghost of the seam
+    Handle base = make();
+    bond(base, *innerleft);
+    base = next(base);
+    bond(base, *innerright);
+    base = next(base);
+    set_org(base, ir_org);
+    set_dest(base, il_dest);
+    if (il_dest == org(*farleft)) *farleft = next(base);
+    if (ir_org == dest(*farright)) *farright = prev(base);
+
+    int32_t lowerleft = il_dest, lowerright = ir_org;
+    int32_t upperleft = apex(lcand), upperright = apex(rcand);
+    for (;;) {
+        bool leftdone = ccw(upperleft, lowerleft, lowerright) <= 0;
+        bool rightdone = ccw(upperright, lowerleft, lowerright) <= 0;
+        if (leftdone && rightdone) {
+            // top ghost of the seam
+            Handle top = make();
+            set_org(top, lowerleft);
+            set_dest(top, lowerright);
+            bond(top, base);
+            top = next(top);
+            bond(top, rcand);
+            top = next(top);
+            bond(top, lcand);
+            if (axis == 1) {
+                // restore leftmost / rightmost anchors
+                int32_t fl_pt = org(*farleft);
+                int32_t fr_pt = dest(*farright), fr_apex = apex(*farright);
+                Handle chk = sym(*farleft);
+                int32_t cv = apex(chk);
+                while (X(cv) < X(fl_pt)) {
+                    *farleft = prev(chk);
+                    fl_pt = cv;
+                    chk = sym(*farleft);
+                    cv = apex(chk);
+                }
+                while (X(fr_apex) > X(fr_pt)) {
+                    *farright = sym(prev(*farright));
+                    fr_pt = fr_apex;
+                    fr_apex = apex(*farright);
+                }
+            }
+            return;
+        }
+        if (!leftdone) {
+            // strip left-side edges that fail the in-circle test (flip in place)
+            Handle nx = sym(prev(lcand));
+            int32_t nap = apex(nx);
+            if (nap >= 0) {
+                bool bad = incircle(lowerleft, lowerright, upperleft, nap) > 0;
+                while (bad) {
+                    nx = next(nx);
+                    Handle topc = sym(nx);
+                    nx = next(nx);
+                    Handle sidec = sym(nx);
+                    bond(nx, topc);
+                    bond(lcand, sidec);
+                    lcand = next(lcand);
+                    Handle outerc = sym(lcand);
+                    nx = prev(nx);
+                    bond(nx, outerc);
+                    set_org(lcand, lowerleft);
+                    set_dest(lcand, -1);
+                    set_apex(lcand, nap);
+                    set_org(nx, -1);
+                    set_dest(nx, upperleft);
+                    set_apex(nx, nap);
+                    upperleft = nap;
+                    nx = sidec;
+                    nap = apex(nx);
+                    bad = nap >= 0 && incircle(lowerleft, lowerright, upperleft, nap) > 0;
+                }
+            }
+        }
+        if (!rightdone) {
+            Handle nx = sym(next(rcand));
+            int32_t nap = apex(nx);
+            if (nap >= 0) {
+                bool bad = incircle(lowerleft, lowerright, upperright, nap) > 0;
+                while (bad) {
+                    nx = prev(nx);
+                    Handle topc = sym(nx);
+                    nx = prev(nx);
+                    Handle sidec = sym(nx);
+                    bond(nx, topc);
+                    bond(rcand, sidec);
+                    rcand = prev(rcand);
+                    Handle outerc = sym(rcand);
+                    nx = next(nx);
+                    bond(nx, outerc);
+                    set_org(rcand, -1);
+                    set_dest(rcand, lowerright);
+                    set_apex(rcand, nap);
+                    set_org(nx, upperright);
+                    set_dest(nx, -1);
+                    set_apex(nx, nap);
+                    upperright = nap;
+                    nx = sidec;
+                    nap = apex(nx);
+                    bad = nap >= 0 && incircle(lowerleft, lowerright, upperright, nap) > 0;
+                }
+            }
+        }
+        if (leftdone ||
+            (!rightdone && incircle(upperleft, lowerleft, lowerright, upperright) > 0)) {
+            // new edge lowerleft -> upperright
+            bond(base, rcand);
+            base = prev(rcand);
+            set_dest(base, lowerleft);
+            lowerright = upperright;
+            rcand = sym(base);
+            upperright = apex(rcand);
+        } else {
+            // new edge upperleft -> lowerright (also taken on a co-circular tie)
+            bond(base, lcand);
+            base = next(lcand);
+            set_org(base, lowerright);
+            lowerleft = upperleft;
+            lcand = sym(base);
+            upperleft = apex(lcand);
+        }
+    }
+}
+
+int32_t DivConq::run(int32_t* out, int32_t cap) {
+    if (n_ < 2) return 0;
+    if (!scale_coordinates()) return SVH_ERR_UNSUPPORTED;
+    std::vector<int32_t> order(n_);
+    for (int32_t i = 0; i < n_; i++) order[i] = i;
+    sort_xy(order.data(), n_);
+    // drop coincident vertices: the first in sorted order survives
+    int32_t m = 0;
+    for (int32_t j = 1; j < n_; j++) {
+        if (X(order[m]) == X(order[j]) && Y(order[m]) == Y(order[j])) continue;
+        order[++m] = order[j];
+    }
+    m++;
+    if (m < 2) return 0;
+    int32_t half = m >> 1;
+    if (m - half >= 2) {
+        if (half >= 2) alternate(order.data(), half, 1);
+        alternate(order.data() + half, m - half, 1);
+    }
+    nb_.reserve(3 * (2 * (size_t)m + 8));
+    vx_.reserve(3 * (2 * (size_t)m + 8));
+    make();  // record 0 = outer space
+    Handle hullleft, hullright;
+    recurse(order.data(), m, 0, &hullleft, &hullright);
+
+    // peel the ghost fan off the hull
+    Handle g = hullleft;
+    do {
+        Handle dying = next(g);
+        g = sym(prev(g));
+        nb_[3 * g.t + g.o] = 0;  // hull triangle now faces outer space
+        g = sym(dying);
+        dead_[dying.t] = 1;
+    } while (!(g.t == hullleft.t && g.o == hullleft.o));
+
+    int32_t count = 0;
+    const int32_t nrec = (int32_t)(vx_.size() / 3);
+    for (int32_t t = 1; t < nrec; t++) {
+        if (dead_[t]) continue;
+        if (count < cap) {
+            out[3 * count + 0] = vx_[3 * t + 1];
+            out[3 * count + 1] = vx_[3 * t + 2];
+            out[3 * count + 2] = vx_[3 * t + 0];
+        }
+        count++;
+    }
+    return count;
+}
+
+}  // namespace
+
+int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap) {
+    DivConq dc(pts, n);
+    return dc.run(tri, cap);
+}
+
+}  // namespace svh
+
+extern "C" int32_t svh_delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap) {
+    if (!pts || !tri || n < 0) return SVH_ERR_BAD_ARG;
+    return svh::delaunay(pts, n, tri, cap);
+}

@@ -1,0 +1,202 @@
+"""ctypes binding of libsvhip.so (C-ABI: include/svh.h).
+
+Python is plumbing here: the product is the shared library (HIP kernels for
+gfx950 + C++ host engine).  This module mirrors the reference's class surface
+(`Elas(parameters).process(I1, I2, D1, D2, dims)`, libelas/src/elas.h:151-165) so
+parity tests read like reference call sites.  There is NO CPU fallback: a
+missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libsvhip.so")
+
+OK, ERR_FEW_SUPPORT, ERR_BAD_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = 0, 1, -1, -2, -3, -4
+ROBOTICS, MIDDLEBURY = 0, 1
+
+
+class ElasParams(C.Structure):
+    """svh_elas_params == Elas::parameters (libelas/src/elas.h:59-148)."""
+    _fields_ = [
+        ("disp_min", C.c_int32), ("disp_max", C.c_int32),
+        ("support_threshold", C.c_float), ("support_texture", C.c_int32),
+        ("candidate_stepsize", C.c_int32), ("incon_window_size", C.c_int32),
+        ("incon_threshold", C.c_int32), ("incon_min_support", C.c_int32),
+        ("add_corners", C.c_int32), ("grid_size", C.c_int32),
+        ("beta", C.c_float), ("gamma", C.c_float), ("sigma", C.c_float), ("sradius", C.c_float),
+        ("match_texture", C.c_int32), ("lr_threshold", C.c_int32),
+        ("speckle_sim_threshold", C.c_float), ("speckle_size", C.c_int32),
+        ("ipol_gap_width", C.c_int32), ("filter_median", C.c_int32),
+        ("filter_adaptive_mean", C.c_int32), ("postprocess_only_left", C.c_int32),
+        ("subsampling", C.c_int32),
+    ]
+
+
+class SvhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libsvhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libsvhip.so; fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libsvhip.so not built (run __graft_entry__.build()): " + LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.svh_version.restype = C.c_char_p
+        L.svh_last_error.restype = C.c_char_p
+        L.svh_elas_create.restype = C.c_void_p
+        L.svh_elas_create.argtypes = [C.POINTER(ElasParams)]
+        L.svh_elas_destroy.argtypes = [C.c_void_p]
+        L.svh_elas_params_default.argtypes = [C.POINTER(ElasParams), C.c_int32]
+        L.svh_elas_process.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.svh_elas_process_batch.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 6
+        L.svh_elas_process_batch_device.argtypes = [
+            C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+            C.c_size_t, C.c_void_p, C.c_void_p]
+        L.svh_elas_set_taps.argtypes = [C.c_void_p, C.c_int32]
+        L.svh_elas_get_stage.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
+                                         C.POINTER(C.c_size_t)]
+        L.svh_elas_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.svh_delaunay.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().svh_last_error().decode()
+
+
+def default_params(setting=ROBOTICS, **kw):
+    p = ElasParams()
+    lib().svh_elas_params_default(C.byref(p), setting)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def delaunay(pts):
+    """svh_delaunay: Triangle-1.6-"zQB"-compatible triangulation (host side)."""
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    cap = 2 * len(pts) + 16
+    tri = np.empty((cap, 3), np.int32)
+    n = lib().svh_delaunay(pts.ctypes.data, len(pts), tri.ctypes.data, cap)
+    if n < 0:
+        raise SvhError(n, "svh_delaunay failed")
+    return tri[:n].copy()
+
+
+def _as_params(params):
+    """accept any ctypes struct with the svh_elas_params layout"""
+    if isinstance(params, ElasParams):
+        return params
+    return ElasParams.from_buffer_copy(bytes(params))
+
+
+class Elas:
+    """Drop-in for the reference class (libelas/src/elas.h:151-165)."""
+
+    def __init__(self, params=None):
+        self._p = _as_params(params) if params is not None else default_params()
+        self._h = lib().svh_elas_create(C.byref(self._p))
+        if not self._h:
+            raise RuntimeError("svh_elas_create failed")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.svh_elas_destroy(h)
+
+    @property
+    def params(self):
+        return self._p
+
+    def _dshape(self, h, w):
+        return (h // 2, w // 2) if self._p.subsampling else (h, w)
+
+    def process(self, I1, I2, D1=None, D2=None):
+        """Elas::process(I1,I2,D1,D2,dims).  Returns (status, D1, D2); on status 1
+        (<3 support points) D1/D2 are left untouched, like the reference."""
+        I1 = np.asarray(I1, np.uint8)
+        I2 = np.asarray(I2, np.uint8)
+        assert I1.shape == I2.shape and I1.ndim == 2
+        if I1.strides[1] != 1 or I2.strides != I1.strides:
+            I1 = np.ascontiguousarray(I1)
+            I2 = np.ascontiguousarray(I2)
+        h, w = I1.shape
+        dims = (C.c_int32 * 3)(w, h, I1.strides[0])
+        if D1 is None:
+            D1 = np.zeros(self._dshape(h, w), np.float32)
+        if D2 is None:
+            D2 = np.zeros(self._dshape(h, w), np.float32)
+        rc = lib().svh_elas_process(self._h, I1.ctypes.data, I2.ctypes.data, D1.ctypes.data,
+                                    D2.ctypes.data, dims)
+        if rc < 0:
+            raise SvhError(rc, last_error())
+        return rc, D1, D2
+
+    def process_batch(self, I1s, I2s):
+        """n independent pairs (host arrays [n,H,W]) pipelined over the engine lanes."""
+        I1s = np.ascontiguousarray(I1s, np.uint8)
+        I2s = np.ascontiguousarray(I2s, np.uint8)
+        n, h, w = I1s.shape
+        dh, dw = self._dshape(h, w)
+        D1 = np.zeros((n, dh, dw), np.float32)
+        D2 = np.zeros((n, dh, dw), np.float32)
+        arr = C.c_void_p * n
+        a1 = arr(*[I1s[i].ctypes.data for i in range(n)])
+        a2 = arr(*[I2s[i].ctypes.data for i in range(n)])
+        d1 = arr(*[D1[i].ctypes.data for i in range(n)])
+        d2 = arr(*[D2[i].ctypes.data for i in range(n)])
+        st = (C.c_int32 * n)()
+        dims = (C.c_int32 * 3)(w, h, w)
+        rc = lib().svh_elas_process_batch(self._h, n, a1, a2, d1, d2, dims, st)
+        if rc < 0:
+            raise SvhError(rc, last_error())
+        return list(st), D1, D2
+
+    def process_batch_device(self, n, dI1, dI2, in_stride, dD1, dD2, out_stride, w, h, pitch):
+        """device-resident batch: raw device pointers (ints), see include/svh.h"""
+        st = (C.c_int32 * n)()
+        dims = (C.c_int32 * 3)(w, h, pitch)
+        rc = lib().svh_elas_process_batch_device(self._h, n, dI1, dI2, in_stride, dD1, dD2,
+                                                 out_stride, dims, st)
+        if rc < 0:
+            raise SvhError(rc, last_error())
+        return list(st)
+
+    # ---- parity taps -----------------------------------------------------
+    def set_taps(self, enable=True):
+        lib().svh_elas_set_taps(self._h, 1 if enable else 0)
+
+    def stage(self, stage, dtype):
+        n = C.c_size_t(0)
+        lib().svh_elas_get_stage(self._h, stage, None, 0, C.byref(n))
+        buf = np.empty(n.value, np.uint8)
+        if n.value:
+            rc = lib().svh_elas_get_stage(self._h, stage, buf.ctypes.data, n.value, C.byref(n))
+            if rc < 0:
+                raise SvhError(rc, last_error())
+        return buf.view(dtype)
+
+    def last_timing(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = lib().svh_elas_last_timing(self._h, names, ms, 16)
+        return [(names[i].decode(), ms[i]) for i in range(n)]
+
+
+def set_lanes(n):
+    return lib().svh_elas_set_lanes(n)
+
+
+def device_count():
+    return lib().svh_device_count()
