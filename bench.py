@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ELAS stereo pairs/s on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W [--batch B] [--lanes L]
+
+Workload (BASELINE.json configs[1]): KITTI-sized 1242x375 pairs, full ELAS
+ROBOTICS parameters, D1+D2 with L/R check, subsampling off.  A "step" is one
+pass of the hot path over one batch of B synthetic pairs that are already
+resident in HBM; disparity maps are written to HBM.  For N>1 the driver starts
+one process per GPU (torch.distributed.run); pairs are independent, so ranks
+shard them with no data-path collective ("weak" scaling: B pairs per rank and
+step) and only a tiny per-rank result record is gathered over RCCL.
+
+Besides the contract fields the JSON line carries
+  roofline      achieved algorithmic GB/s of the dominant kernel, from HIP events
+                recorded on the kernels' own streams (svh_profile_*), vs 8 TB/s
+  cpu_baseline  the reference Elas::process (oracle/_ref) timed on this host,
+                1 thread, on a bounded sample of the same pairs.
+torch is used only for device memory, the barrier and the result gather.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "stereo-vision_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H = 1242, 375
+N_PIX = W * H
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+# algorithmic bytes per pair and kernel launch (SURVEY 8d staged model, N = W*H)
+ALG_BYTES_PER_PIXEL = {
+    "k_descriptor": 34.0,   # 2 x (1 B in + 16 B out)
+    "k_support": 12.8,      # rows v+-2 of a 5-row lattice, both images
+    "k_match": 72.0,        # 2 x (16 own + 16 other + 4 out)
+    "k_lr": 16.0,
+    "k_seg_init": 8.0, "k_seg_merge": 8.0, "k_seg_count": 8.0, "k_seg_mask": 8.0,
+    "k_gap_rows": 8.0, "k_gap_cols": 8.0,
+    "k_mean_h": 8.0, "k_mean_v": 8.0,
+    "k_owner": 8.0,
+}
+
+
+def make_inputs(batch, seed0=1000):
+    import helpers as Hh
+    I1 = np.empty((batch, H, W), np.uint8)
+    I2 = np.empty((batch, H, W), np.uint8)
+    for i in range(batch):
+        I1[i], I2[i] = Hh.synth_pair(W, H, seed0 + i, dmax=96, planes=8)
+    return I1, I2
+
+
+def cpu_baseline(I1, I2, params, budget_s=15.0):
+    """reference (or port) on host cores, 1 thread, bounded sample of the same pairs"""
+    import helpers as Hh
+    n_done, t_used = 0, 0.0
+    D1 = np.zeros((H, W), np.float32)
+    D2 = np.zeros((H, W), np.float32)
+    dims = (C.c_int32 * 3)(W, H, W)
+    if Hh.have_ref_elas():
+        lib = C.CDLL(Hh.ref_elas_path())   # no ref_init(1): plain allocator, fair timing
+        kind = "reference"
+
+        def run(i):
+            lib.ref_elas_process(C.byref(params), I1[i].ctypes.data_as(C.c_void_p),
+                                 I2[i].ctypes.data_as(C.c_void_p), D1.ctypes.data_as(C.c_void_p),
+                                 D2.ctypes.data_as(C.c_void_p), dims)
+    else:
+        import svhip as S
+        lib = Hh.oracle()
+        kind = "port"
+        tri = C.cast(S.lib().svh_delaunay, C.c_void_p)   # timing leg only: Triangle is not restated
+
+        def run(i):
+            lib.orc_elas_process(C.byref(params), I1[i].ctypes.data_as(C.c_void_p),
+                                 I2[i].ctypes.data_as(C.c_void_p), D1.ctypes.data_as(C.c_void_p),
+                                 D2.ctypes.data_as(C.c_void_p), dims, tri)
+    run(0)  # warm
+    i = 0
+    while t_used < budget_s and n_done < 400:
+        t = time.perf_counter()
+        run(i % len(I1))
+        t_used += time.perf_counter() - t
+        n_done += 1
+        i += 1
+    return {"value": n_done / t_used, "unit": "pairs/s", "cores": 1, "kind": kind,
+            "ms_per_pair": 1e3 * t_used / n_done,
+            "sample": "%d x Elas::process on the bench's own 1242x375 synthetic pairs, 1 thread, "
+                      "%s" % (n_done, "oracle/_ref (reference compiled -O3 -msse3)" if kind == "reference"
+                              else "oracle/ scalar port"),
+            "host": _cpu_model(), "host_cores": os.cpu_count()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def read_profile(S):
+    lib = S.lib()
+    lib.svh_profile_get.argtypes = [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int64)]
+    n = lib.svh_profile_get(-1, None, None, None)
+    out = {}
+    for i in range(n):
+        name, ms, cnt = C.c_char_p(), C.c_double(), C.c_int64()
+        lib.svh_profile_get(i, C.byref(name), C.byref(ms), C.byref(cnt))
+        out[name.value.decode()] = (ms.value, cnt.value)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="pairs per step and GPU")
+    ap.add_argument("--lanes", type=int, default=0, help="pipeline lanes per GPU (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import svhip as S
+    import helpers as Hh
+    S.lib().svh_set_device(local_rank)
+    lanes = args.lanes or max(2, min(8, (os.cpu_count() or 8) // max(world, 1)))
+    S.set_lanes(lanes)
+
+    B = args.batch
+    params = Hh.robotics()           # Elas::parameters(ROBOTICS), elas.h:91-116
+    I1, I2 = make_inputs(B, seed0=1000 + 100000 * rank)
+    dI1 = torch.from_numpy(I1).to(dev)
+    dI2 = torch.from_numpy(I2).to(dev)
+    dD1 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    dD2 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    e = S.Elas(params)
+
+    def step():
+        st = e.process_batch_device(B, dI1.data_ptr(), dI2.data_ptr(), W * H, dD1.data_ptr(),
+                                    dD2.data_ptr(), W * H * 4, W, H, W)
+        assert all(s == 0 for s in st), st
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the only collective on the path: a tiny per-rank result record over RCCL
+        rec = torch.tensor([float(B * args.steps), float((dD1[0] >= 0).sum().item())],
+                           dtype=torch.float64, device=dev)
+        allrec = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)
+        total_pairs = int(sum(r[0].item() for r in allrec))
+    else:
+        total_pairs = B * args.steps
+
+    # ---- per-kernel roofline: same steps again with HIP-event timing on each
+    # kernel's own stream (kept out of the timed region above)
+    roofline = None
+    if rank == 0:
+        S.lib().svh_profile_reset()
+        S.lib().svh_profile_enable(1)
+        for _ in range(max(1, min(args.steps, 3))):
+            step()
+        S.lib().svh_profile_enable(0)
+        prof = read_profile(S)
+        if prof:
+            dom = max(prof, key=lambda k: prof[k][0])
+            ms, cnt = prof[dom]
+            avg_s = ms / cnt / 1e3
+            abytes = ALG_BYTES_PER_PIXEL.get(dom, 8.0) * N_PIX
+            achieved = abytes / avg_s / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_us": 1e6 * avg_s, "alg_bytes_per_launch": abytes,
+                        "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in sorted(prof.items())}}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        valid = float((dD1 >= 0).float().mean().item())
+        out = {
+            "metric": "stereo pairs/sec (ELAS 1242x375, ROBOTICS, D1+D2+LR)",
+            "value": total_pairs / elapsed,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_pair": 1e3 * elapsed / (args.steps * B),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: KITTI-size 1242x375 pairs, ELAS ROBOTICS, D1+D2 + "
+                                   "LR-check, subsampling=false, inputs and outputs resident in HBM",
+                       "pairs_per_step_per_gpu": B, "lanes_per_gpu": lanes,
+                       "d1_valid_fraction": round(valid, 4)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(I1, I2, params)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,15 @@ int32_t svh_elas_get_stage(svh_elas* e, int32_t stage, void* buf, size_t cap, si
 int32_t svh_elas_last_timing(svh_elas* e, const char** names, float* ms, int32_t cap);
 
 /* ------------------------------------------------------------------------ */
+/* per-kernel timing: when enabled every kernel launch is bracketed by HIP
+ * events on the stream it is launched on; totals accumulate per kernel name
+ * over all lanes until reset.  svh_profile_get(-1,..) returns the entry count. */
+/* ------------------------------------------------------------------------ */
+int32_t svh_profile_enable(int32_t on);
+void    svh_profile_reset(void);
+int32_t svh_profile_get(int32_t index, const char** name, double* total_ms, int64_t* launches);
+
+/* ------------------------------------------------------------------------ */
 /* host-side geometry helpers that stay on the CPU; exported
  * so they can be parity-tested directly.                                     */
 /* ------------------------------------------------------------------------ */

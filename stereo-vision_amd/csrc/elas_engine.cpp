@@ -60,9 +60,59 @@ static double now_ms() {
 }
 
 // ---------------------------------------------------------------------------
+// per-kernel timing with HIP events recorded on the lane's own stream
+// (svh_profile_*): totals are accumulated per kernel name across lanes.
+// ---------------------------------------------------------------------------
+struct KernelStat {
+    double total_ms = 0;
+    int64_t launches = 0;
+};
+static std::mutex g_prof_mu;
+static std::map<std::string, KernelStat> g_prof;
+static std::atomic<int> g_prof_on{0};
+
+struct EventProfiler : Profiler {
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> ev;          // 2 per launch
+    std::vector<const char*> names;
+    size_t used = 0;
+    void begin(const char* kernel) override {
+        if (ev.size() < 2 * (used + 1)) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            ev.push_back(a);
+            ev.push_back(b);
+            names.push_back(kernel);
+        }
+        names[used] = kernel;
+        (void)hipEventRecord(ev[2 * used], stream);
+    }
+    void end() override {
+        if (ev.size() < 2 * (used + 1)) return;
+        (void)hipEventRecord(ev[2 * used + 1], stream);
+        used++;
+    }
+    // call after the stream has been synchronised
+    void collect() {
+        if (!used) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        for (size_t i = 0; i < used; i++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) {
+                KernelStat& k = g_prof[names[i]];
+                k.total_ms += ms;
+                k.launches++;
+            }
+        }
+        used = 0;
+    }
+};
+
+// ---------------------------------------------------------------------------
 // lane: stream + buffers
 // ---------------------------------------------------------------------------
 struct Lane {
+    EventProfiler prof;
     int device = 0;
     hipStream_t stream = nullptr;
     // geometry the buffers were sized for
@@ -259,6 +309,8 @@ static int run_pair(Lane& L, const svh_elas_params& p, const int32_t* dims, cons
     if (rc) return rc;
     const Dims& d = L.d;
     hipStream_t s = L.stream;
+    L.prof.stream = s;
+    const LaunchCtx cx = {s, g_prof_on.load() ? &L.prof : nullptr};
     const size_t N = (size_t)W * H, DN = (size_t)d.DW * d.DH;
     double t0 = now_ms();
 
@@ -280,12 +332,13 @@ static int run_pair(Lane& L, const svh_elas_params& p, const int32_t* dims, cons
         img.I[0] = L.img[0]; img.I[1] = L.img[1];
         img.pitch[0] = img.pitch[1] = W;
     }
-    launch_descriptor(s, img, W, H, p.subsampling, L.desc[0], L.desc[1]);
-    launch_support(s, p, d, L.desc[0], L.desc[1], L.dcan);
+    launch_descriptor(cx, img, W, H, p.subsampling, L.desc[0], L.desc[1]);
+    launch_support(cx, p, d, L.desc[0], L.desc[1], L.dcan);
     const size_t nc = (size_t)d.Wc * d.Hc;
     HIP_TRY(hipMemcpyAsync(L.h_dcan, L.dcan, nc * sizeof(int16_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
+    L.prof.collect();
     double t1 = now_ms();
     if (taps && taps->enabled) {
         rc = tap_dev(L, taps, SVH_ELAS_DESC1, L.desc[0], N * 16); if (rc) return rc;
@@ -336,7 +389,7 @@ static int run_pair(Lane& L, const svh_elas_params& p, const int32_t* dims, cons
     HIP_TRY(hipMemcpyAsync(L.prior_dev, L.h_prior, off, hipMemcpyHostToDevice, s));
     const TriRaster* r_dev[2] = {(const TriRaster*)(L.prior_dev + o_r[0]),
                                  (const TriRaster*)(L.prior_dev + o_r[1])};
-    launch_owner(s, d, r_dev[0], (int32_t)hp.raster[0].size(), r_dev[1],
+    launch_owner(cx, d, r_dev[0], (int32_t)hp.raster[0].size(), r_dev[1],
                  (int32_t)hp.raster[1].size(), p.subsampling, L.owner[0], L.owner[1]);
     MatchArgs ma;
     for (int k = 0; k < 2; k++) {
@@ -349,7 +402,7 @@ static int run_pair(Lane& L, const svh_elas_params& p, const int32_t* dims, cons
     }
     ma.P = (const int32_t*)(L.prior_dev + o_P);
     ma.plane_radius = hp.plane_radius;
-    launch_match(s, p, d, ma);
+    launch_match(cx, p, d, ma);
     if (taps && taps->enabled) {
         rc = tap_dev(L, taps, SVH_ELAS_D1_RAW, L.Draw[0], DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_RAW, L.Draw[1], DN); if (rc) return rc;
@@ -357,32 +410,33 @@ static int run_pair(Lane& L, const svh_elas_params& p, const int32_t* dims, cons
     // when the caller's maps live on the device the last kernels write them directly
     float* D1 = L.D[0];
     float* D2 = L.D[1];
-    launch_lr(s, p, d, L.Draw[0], L.Draw[1], D1, D2);
+    launch_lr(cx, p, d, L.Draw[0], L.Draw[1], D1, D2);
     if (taps && taps->enabled) {
         rc = tap_dev(L, taps, SVH_ELAS_D1_LR, D1, DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_LR, D2, DN); if (rc) return rc;
     }
     const int nside = p.postprocess_only_left ? 1 : 2;
-    for (int k = 0; k < nside; k++) launch_segments(s, p, d, k ? D2 : D1, L.labels, L.counts);
+    for (int k = 0; k < nside; k++) launch_segments(cx, p, d, k ? D2 : D1, L.labels, L.counts);
     if (taps && taps->enabled) {
         rc = tap_dev(L, taps, SVH_ELAS_D1_SEG, D1, DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_SEG, D2, DN); if (rc) return rc;
     }
-    for (int k = 0; k < nside; k++) launch_gap(s, p, d, k ? D2 : D1, L.tmp);
+    for (int k = 0; k < nside; k++) launch_gap(cx, p, d, k ? D2 : D1, L.tmp);
     if (taps && taps->enabled) {
         rc = tap_dev(L, taps, SVH_ELAS_D1_GAP, D1, DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_GAP, D2, DN); if (rc) return rc;
     }
     if (p.filter_adaptive_mean)
-        for (int k = 0; k < nside; k++) launch_adaptive_mean(s, p, d, k ? D2 : D1, L.tmp);
+        for (int k = 0; k < nside; k++) launch_adaptive_mean(cx, p, d, k ? D2 : D1, L.tmp);
     if (p.filter_median)
-        for (int k = 0; k < nside; k++) launch_median(s, d, k ? D2 : D1, L.tmp);
+        for (int k = 0; k < nside; k++) launch_median(cx, d, k ? D2 : D1, L.tmp);
 
     const hipMemcpyKind kind = io.out_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     HIP_TRY(hipMemcpyAsync(io.D[0], D1, DN * sizeof(float), kind, s));
     HIP_TRY(hipMemcpyAsync(io.D[1], D2, DN * sizeof(float), kind, s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
+    L.prof.collect();
     double t3 = now_ms();
     if (timing) {
         timing->tnames = {"Descriptor+Support Matches (device)", "Filters+Delaunay+Planes+Grid (host)",
@@ -415,6 +469,31 @@ int32_t svh_set_device(int32_t device) {
         return fail(SVH_ERR_NO_DEVICE, "no such HIP device");
     t_device = device;
     return SVH_OK;
+}
+
+int32_t svh_profile_enable(int32_t on) {
+    g_prof_on.store(on ? 1 : 0);
+    return SVH_OK;
+}
+
+void svh_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.clear();
+}
+
+int32_t svh_profile_get(int32_t index, const char** name, double* total_ms, int64_t* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (index < 0) return (int32_t)g_prof.size();
+    int32_t i = 0;
+    for (auto& kv : g_prof) {
+        if (i++ == index) {
+            if (name) *name = kv.first.c_str();
+            if (total_ms) *total_ms = kv.second.total_ms;
+            if (launches) *launches = kv.second.launches;
+            return SVH_OK;
+        }
+    }
+    return SVH_ERR_BAD_ARG;
 }
 
 int32_t svh_elas_set_lanes(int32_t lanes) {

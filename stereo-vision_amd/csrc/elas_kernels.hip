@@ -642,109 +642,121 @@ __global__ __launch_bounds__(256) void k_median(const float* gate, const float* 
 
 inline dim3 grid2d(int w, int h, int z = 1) { return dim3((w + 63) / 64, (h + 3) / 4, z); }
 
+// brackets one kernel launch with the context's timer, if any
+struct Timed {
+    Profiler* p;
+    Timed(const LaunchCtx& cx, const char* name) : p(cx.prof) {
+        if (p) p->begin(name);
+    }
+    ~Timed() {
+        if (p) p->end();
+    }
+};
+
+#define LAUNCH(name, kernel, grid, block, ...)                                                  \
+    do {                                                                                        \
+        Timed timed_(cx, name);                                                                 \
+        hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)cx.stream, __VA_ARGS__);        \
+    } while (0)
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-void launch_descriptor(void* stream, const DevImages& img, int32_t W, int32_t H, int32_t half,
-                       uint8_t* desc1, uint8_t* desc2) {
+void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t W, int32_t H,
+                       int32_t half, uint8_t* desc1, uint8_t* desc2) {
     dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, 2), block(TX, 4);
-    hipLaunchKernelGGL(k_descriptor, grid, block, 0, (hipStream_t)stream, img.I[0], img.I[1],
-                       img.pitch[0], img.pitch[1], W, H, half, desc1, desc2);
+    LAUNCH("k_descriptor", k_descriptor, grid, block, img.I[0], img.I[1], img.pitch[0],
+           img.pitch[1], W, H, half, desc1, desc2);
 }
 
-void launch_support(void* stream, const svh_elas_params& p, const Dims& d, const uint8_t* desc1,
-                    const uint8_t* desc2, int16_t* dcan) {
+void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d,
+                    const uint8_t* desc1, const uint8_t* desc2, int16_t* dcan) {
     SupportParams P;
     P.W = d.W; P.H = d.H; P.Wc = d.Wc; P.Hc = d.Hc; P.step = d.step;
     P.disp_min = p.disp_min; P.disp_max = p.disp_max;
     P.support_texture = p.support_texture; P.lr_threshold = p.lr_threshold;
     P.support_threshold = p.support_threshold;
     const int cands = d.Wc * d.Hc;
-    hipLaunchKernelGGL(k_support, dim3((cands + 3) / 4), dim3(256), 0, (hipStream_t)stream, desc1,
-                       desc2, dcan, P);
+    LAUNCH("k_support", k_support, dim3((cands + 3) / 4), dim3(256), desc1, desc2, dcan, P);
 }
 
-void launch_owner(void* stream, const Dims& d, const TriRaster* r1, int32_t n1, const TriRaster* r2,
-                  int32_t n2, int32_t subsampling, int32_t* owner1, int32_t* owner2) {
-    hipStream_t s = (hipStream_t)stream;
+void launch_owner(const LaunchCtx& cx, const Dims& d, const TriRaster* r1, int32_t n1,
+                  const TriRaster* r2, int32_t n2, int32_t subsampling, int32_t* owner1,
+                  int32_t* owner2) {
+    hipStream_t s = (hipStream_t)cx.stream;
     const size_t bytes = (size_t)d.W * d.H * sizeof(int32_t);
     (void)hipMemsetAsync(owner1, 0xFF, bytes, s);
     (void)hipMemsetAsync(owner2, 0xFF, bytes, s);
     const int nmax = n1 > n2 ? n1 : n2;
     if (nmax == 0) return;
-    hipLaunchKernelGGL(k_owner, dim3((nmax + 3) / 4, 2), dim3(256), 0, s, r1, n1, r2, n2, d.W, d.H,
-                       subsampling, owner1, owner2);
+    LAUNCH("k_owner", k_owner, dim3((nmax + 3) / 4, 2), dim3(256), r1, n1, r2, n2, d.W, d.H,
+           subsampling, owner1, owner2);
 }
 
-void launch_match(void* stream, const svh_elas_params& p, const Dims& d, const MatchArgs& a) {
+void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d,
+                  const MatchArgs& a) {
     MatchParams P;
     P.W = d.W; P.H = d.H; P.DW = d.DW; P.DH = d.DH; P.gw = d.gw; P.grid_size = p.grid_size;
     P.sub = p.subsampling; P.disp_max = p.disp_max; P.match_texture = p.match_texture;
     P.plane_radius = a.plane_radius;
-    hipLaunchKernelGGL(k_match, grid2d(d.DW, d.DH, 2), dim3(64, 4), 0, (hipStream_t)stream, a, P);
+    LAUNCH("k_match", k_match, grid2d(d.DW, d.DH, 2), dim3(64, 4), a, P);
 }
 
-void launch_lr(void* stream, const svh_elas_params& p, const Dims& d, const float* D1raw,
+void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, const float* D1raw,
                const float* D2raw, float* D1, float* D2) {
-    hipLaunchKernelGGL(k_lr, grid2d(d.DW, d.DH), dim3(64, 4), 0, (hipStream_t)stream, D1raw, D2raw,
-                       D1, D2, d.DW, d.DH, p.subsampling, (float)p.lr_threshold);
+    LAUNCH("k_lr", k_lr, grid2d(d.DW, d.DH), dim3(64, 4), D1raw, D2raw, D1, D2, d.DW, d.DH,
+           p.subsampling, (float)p.lr_threshold);
 }
 
-void launch_segments(void* stream, const svh_elas_params& p, const Dims& d, float* D,
+void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D,
                      int32_t* labels, int32_t* counts) {
-    hipStream_t s = (hipStream_t)stream;
     const int n = d.DW * d.DH;
     int min_size = p.speckle_size;
     if (p.subsampling) min_size = (int)(sqrtf((float)p.speckle_size) * 2);  // elas.cpp:1218
-    hipLaunchKernelGGL(k_seg_init, dim3((n + 255) / 256), dim3(256), 0, s, D, labels, counts, n);
-    hipLaunchKernelGGL(k_seg_merge, grid2d(d.DW, d.DH), dim3(64, 4), 0, s, D, labels, d.DW, d.DH,
-                       p.speckle_sim_threshold);
-    hipLaunchKernelGGL(k_seg_count, dim3((n + 255) / 256), dim3(256), 0, s, labels, counts, n);
-    hipLaunchKernelGGL(k_seg_mask, dim3((n + 255) / 256), dim3(256), 0, s, D, labels, counts, n,
-                       min_size);
+    const dim3 lin((n + 255) / 256), b256(256);
+    LAUNCH("k_seg_init", k_seg_init, lin, b256, D, labels, counts, n);
+    LAUNCH("k_seg_merge", k_seg_merge, grid2d(d.DW, d.DH), dim3(64, 4), D, labels, d.DW, d.DH,
+           p.speckle_sim_threshold);
+    LAUNCH("k_seg_count", k_seg_count, lin, b256, labels, counts, n);
+    LAUNCH("k_seg_mask", k_seg_mask, lin, b256, D, labels, counts, n, min_size);
 }
 
-void launch_gap(void* stream, const svh_elas_params& p, const Dims& d, float* D, float* tmp) {
-    hipStream_t s = (hipStream_t)stream;
+void launch_gap(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D,
+                float* tmp) {
     int gap = p.ipol_gap_width;
     if (p.subsampling) gap = p.ipol_gap_width / 2 + 1;  // elas.cpp:1340
     if (gap <= 16 && !p.add_corners) {
-        hipLaunchKernelGGL(k_gap_local<false>, grid2d(d.DW, d.DH), dim3(64, 4), 0, s, D, tmp, d.DW,
-                           d.DH, gap);
-        hipLaunchKernelGGL(k_gap_local<true>, grid2d(d.DW, d.DH), dim3(64, 4), 0, s, tmp, D, d.DW,
-                           d.DH, gap);
+        LAUNCH("k_gap_rows", k_gap_local<false>, grid2d(d.DW, d.DH), dim3(64, 4), D, tmp, d.DW, d.DH,
+               gap);
+        LAUNCH("k_gap_cols", k_gap_local<true>, grid2d(d.DW, d.DH), dim3(64, 4), tmp, D, d.DW, d.DH,
+               gap);
     } else {
-        hipLaunchKernelGGL(k_gap_lines<false>, dim3((d.DH + 63) / 64), dim3(64), 0, s, D, d.DW,
-                           d.DH, gap, p.add_corners);
-        hipLaunchKernelGGL(k_gap_lines<true>, dim3((d.DW + 63) / 64), dim3(64), 0, s, D, d.DW, d.DH,
-                           gap, p.add_corners);
+        LAUNCH("k_gap_rows_seq", k_gap_lines<false>, dim3((d.DH + 63) / 64), dim3(64), D, d.DW, d.DH,
+               gap, p.add_corners);
+        LAUNCH("k_gap_cols_seq", k_gap_lines<true>, dim3((d.DW + 63) / 64), dim3(64), D, d.DW, d.DH,
+               gap, p.add_corners);
     }
 }
 
-void launch_adaptive_mean(void* stream, const svh_elas_params& p, const Dims& d, float* D,
+void launch_adaptive_mean(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D,
                           float* tmp) {
-    hipStream_t s = (hipStream_t)stream;
+    const dim3 g = grid2d(d.DW, d.DH), b(64, 4);
     if (p.subsampling) {
-        hipLaunchKernelGGL((k_adaptive_mean<false, 4>), grid2d(d.DW, d.DH), dim3(64, 4), 0, s, D, D,
-                           tmp, d.DW, d.DH);
-        hipLaunchKernelGGL((k_adaptive_mean<true, 4>), grid2d(d.DW, d.DH), dim3(64, 4), 0, s, tmp, D,
-                           D, d.DW, d.DH);
+        LAUNCH("k_mean_h", (k_adaptive_mean<false, 4>), g, b, D, D, tmp, d.DW, d.DH);
+        LAUNCH("k_mean_v", (k_adaptive_mean<true, 4>), g, b, tmp, D, D, d.DW, d.DH);
     } else {
-        hipLaunchKernelGGL((k_adaptive_mean<false, 8>), grid2d(d.DW, d.DH), dim3(64, 4), 0, s, D, D,
-                           tmp, d.DW, d.DH);
-        hipLaunchKernelGGL((k_adaptive_mean<true, 8>), grid2d(d.DW, d.DH), dim3(64, 4), 0, s, tmp, D,
-                           D, d.DW, d.DH);
+        LAUNCH("k_mean_h", (k_adaptive_mean<false, 8>), g, b, D, D, tmp, d.DW, d.DH);
+        LAUNCH("k_mean_v", (k_adaptive_mean<true, 8>), g, b, tmp, D, D, d.DW, d.DH);
     }
 }
 
-void launch_median(void* stream, const Dims& d, float* D, float* tmp) {
-    hipStream_t s = (hipStream_t)stream;
-    // tmp2 is not available: the vertical pass gates on D and reads tmp, writing D in place
-    hipLaunchKernelGGL(k_median<false>, grid2d(d.DW, d.DH), dim3(64, 4), 0, s, D, D, tmp, d.DW,
-                       d.DH);
-    hipLaunchKernelGGL(k_median<true>, grid2d(d.DW, d.DH), dim3(64, 4), 0, s, D, tmp, D, d.DW, d.DH);
+void launch_median(const LaunchCtx& cx, const Dims& d, float* D, float* tmp) {
+    const dim3 g = grid2d(d.DW, d.DH), b(64, 4);
+    // horizontal pass D -> tmp, vertical pass gates on D, reads tmp, writes D
+    LAUNCH("k_median_h", k_median<false>, g, b, D, D, tmp, d.DW, d.DH);
+    LAUNCH("k_median_v", k_median<true>, g, b, D, tmp, D, d.DW, d.DH);
 }
 
 }  // namespace svh

@@ -59,17 +59,27 @@ void expand_grid(const svh_elas_params& p, const Dims& d, const HostPrior& hp, i
 int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap);
 
 // ---------------------------------------------------------------- device
-// Kernel launchers (elas_kernels.hip).  All take a hipStream_t as void*.
+// Kernel launchers (elas_kernels.hip).  LaunchCtx carries the hipStream_t (as
+// void*) and an optional per-kernel timer (HIP events on that same stream).
+struct Profiler {
+    virtual void begin(const char* kernel) = 0;
+    virtual void end() = 0;
+    virtual ~Profiler() {}
+};
+struct LaunchCtx {
+    void* stream;
+    Profiler* prof;
+};
 struct DevImages {
     const uint8_t* I[2];   // left, right
     int32_t pitch[2];
 };
 
-void launch_descriptor(void* stream, const DevImages& img, int32_t W, int32_t H, int32_t half,
+void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t W, int32_t H, int32_t half,
                        uint8_t* desc1, uint8_t* desc2);
-void launch_support(void* stream, const svh_elas_params& p, const Dims& d, const uint8_t* desc1,
+void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, const uint8_t* desc1,
                     const uint8_t* desc2, int16_t* dcan);
-void launch_owner(void* stream, const Dims& d, const TriRaster* r1, int32_t n1, const TriRaster* r2,
+void launch_owner(const LaunchCtx& cx, const Dims& d, const TriRaster* r1, int32_t n1, const TriRaster* r2,
                   int32_t n2, int32_t subsampling, int32_t* owner1, int32_t* owner2);
 struct MatchArgs {
     const uint8_t* desc[2];
@@ -81,16 +91,16 @@ struct MatchArgs {
     float* D[2];
     int32_t plane_radius;
 };
-void launch_match(void* stream, const svh_elas_params& p, const Dims& d, const MatchArgs& a);
-void launch_lr(void* stream, const svh_elas_params& p, const Dims& d, const float* D1raw,
+void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, const MatchArgs& a);
+void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, const float* D1raw,
                const float* D2raw, float* D1, float* D2);
 // speckle removal: labels/counts are scratch of DW*DH int32 each
-void launch_segments(void* stream, const svh_elas_params& p, const Dims& d, float* D,
+void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D,
                      int32_t* labels, int32_t* counts);
-void launch_gap(void* stream, const svh_elas_params& p, const Dims& d, float* D, float* tmp);
-void launch_adaptive_mean(void* stream, const svh_elas_params& p, const Dims& d, float* D,
+void launch_gap(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D, float* tmp);
+void launch_adaptive_mean(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D,
                           float* tmp);
-void launch_median(void* stream, const Dims& d, float* D, float* tmp);
+void launch_median(const LaunchCtx& cx, const Dims& d, float* D, float* tmp);
 
 }  // namespace svh
 #endif
