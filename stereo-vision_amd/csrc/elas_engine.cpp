@@ -128,6 +128,7 @@ struct Lane {
     float* D[2] = {nullptr, nullptr};
     float* tmp = nullptr;
     int32_t* labels = nullptr;
+    int32_t* runlen = nullptr;
     int32_t* counts = nullptr;
     // pinned host
     int16_t* h_dcan = nullptr;
@@ -141,13 +142,14 @@ struct Lane {
         if (!stream) return;
         (void)hipSetDevice(device);
         for (int k = 0; k < 2; k++) {
-            (void)hipFree(img[k]); (void)hipFree(desc[k]); (void)hipFree(owner[k]);
+            (void)hipFree(img[k]); (void)hipFree(desc[k]);
             (void)hipFree(Draw[k]); (void)hipFree(D[k]);
             img[k] = desc[k] = nullptr; owner[k] = nullptr; Draw[k] = D[k] = nullptr;
         }
+        (void)hipFree(owner[0]);
         (void)hipFree(dcan); (void)hipFree(prior_dev); (void)hipFree(tmp); (void)hipFree(labels);
-        (void)hipFree(counts);
-        dcan = nullptr; prior_dev = nullptr; tmp = nullptr; labels = counts = nullptr;
+        (void)hipFree(counts); (void)hipFree(runlen);
+        dcan = nullptr; prior_dev = nullptr; tmp = nullptr; labels = counts = runlen = nullptr;
         (void)hipHostFree(h_dcan); (void)hipHostFree(h_prior); (void)hipHostFree(h_img);
         h_dcan = nullptr; h_prior = nullptr; h_img = nullptr;
         W = H = 0;
@@ -170,13 +172,15 @@ struct Lane {
         for (int k = 0; k < 2; k++) {
             HIP_TRY(hipMalloc(&img[k], N));
             HIP_TRY(hipMalloc(&desc[k], N * 16));
-            HIP_TRY(hipMalloc(&owner[k], N * sizeof(int32_t)));
             HIP_TRY(hipMalloc(&Draw[k], DN * sizeof(float)));
             HIP_TRY(hipMalloc(&D[k], DN * sizeof(float)));
         }
+        HIP_TRY(hipMalloc(&owner[0], 2 * N * sizeof(int32_t)));   // both sides, one memset
+        owner[1] = owner[0] + N;
         HIP_TRY(hipMalloc(&tmp, DN * sizeof(float)));
         HIP_TRY(hipMalloc(&labels, DN * sizeof(int32_t)));
         HIP_TRY(hipMalloc(&counts, DN * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&runlen, DN * sizeof(int32_t)));
         const size_t nc = (size_t)d.Wc * d.Hc;
         HIP_TRY(hipMalloc(&dcan, nc * sizeof(int16_t)));
         HIP_TRY(hipHostMalloc(&h_dcan, nc * sizeof(int16_t)));
@@ -407,16 +411,17 @@ static int run_pair(Lane& L, const svh_elas_params& p, const int32_t* dims, cons
         rc = tap_dev(L, taps, SVH_ELAS_D1_RAW, L.Draw[0], DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_RAW, L.Draw[1], DN); if (rc) return rc;
     }
-    // when the caller's maps live on the device the last kernels write them directly
-    float* D1 = L.D[0];
-    float* D2 = L.D[1];
+    // when the caller's maps live on the device the post-processing chain runs in
+    // place on them: no final copy
+    float* D1 = io.out_device ? io.D[0] : L.D[0];
+    float* D2 = io.out_device ? io.D[1] : L.D[1];
     launch_lr(cx, p, d, L.Draw[0], L.Draw[1], D1, D2);
     if (taps && taps->enabled) {
         rc = tap_dev(L, taps, SVH_ELAS_D1_LR, D1, DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_LR, D2, DN); if (rc) return rc;
     }
     const int nside = p.postprocess_only_left ? 1 : 2;
-    for (int k = 0; k < nside; k++) launch_segments(cx, p, d, k ? D2 : D1, L.labels, L.counts);
+    for (int k = 0; k < nside; k++) launch_segments(cx, p, d, k ? D2 : D1, L.labels, L.runlen, L.counts);
     if (taps && taps->enabled) {
         rc = tap_dev(L, taps, SVH_ELAS_D1_SEG, D1, DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_SEG, D2, DN); if (rc) return rc;
@@ -431,9 +436,10 @@ static int run_pair(Lane& L, const svh_elas_params& p, const int32_t* dims, cons
     if (p.filter_median)
         for (int k = 0; k < nside; k++) launch_median(cx, d, k ? D2 : D1, L.tmp);
 
-    const hipMemcpyKind kind = io.out_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    HIP_TRY(hipMemcpyAsync(io.D[0], D1, DN * sizeof(float), kind, s));
-    HIP_TRY(hipMemcpyAsync(io.D[1], D2, DN * sizeof(float), kind, s));
+    if (!io.out_device) {
+        HIP_TRY(hipMemcpyAsync(io.D[0], D1, DN * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(io.D[1], D2, DN * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
     L.prof.collect();

@@ -346,6 +346,17 @@ __global__ __launch_bounds__(256) void k_lr(const float* __restrict__ R1,
 // The flood fill joins 4-neighbours that are both valid and differ by at most
 // speckle_sim_threshold: a symmetric relation, so segments are the connected
 // components of that graph and a parallel union-find gives the same sets.
+//
+// Run-based labelling keeps the number of atomic unions near the number of
+// run-to-run contacts instead of two per pixel:
+//   k_seg_runs  : every wave (64 consecutive pixels of one row) cuts its span
+//                 into horizontally connected runs with one ballot; L[p] = index
+//                 of the run's first pixel, RL[first] = run length
+//   k_seg_link  : unions between runs -- across wave borders, and to the row
+//                 above, skipping a vertical contact when the pixel to the left
+//                 already makes the same union
+//   k_seg_count : one atomicAdd of the run length per run; roots compressed
+//   k_seg_mask  : pixels of components below speckle_size become -10
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int uf_find(const int32_t* L, int x) {
     int p = L[x];
@@ -372,52 +383,81 @@ __device__ __forceinline__ void uf_union(int32_t* L, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_seg_init(const float* __restrict__ D,
+__device__ __forceinline__ bool seg_joined(float a, float b, float thr) {
+    return a >= 0 && b >= 0 && fabsf(a - b) <= thr;
+}
+
+__global__ __launch_bounds__(256) void k_seg_runs(const float* __restrict__ D,
                                                   int32_t* __restrict__ L,
-                                                  int32_t* __restrict__ cnt, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    L[i] = D[i] >= 0 ? i : -1;
+                                                  int32_t* __restrict__ RL,
+                                                  int32_t* __restrict__ cnt, int DW, int DH,
+                                                  float thr) {
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;   // wave-uniform
+    if (y >= DH) return;
+    const int lane = threadIdx.x;
+    const int i = y * DW + x;
+    const bool inside = x < DW;
+    const float d = inside ? D[i] : -10.f;
+    const bool valid = d >= 0;
+    float dl = __shfl_up(d, 1, kWave);
+    if (lane == 0) dl = (x > 0 && inside) ? D[i - 1] : -10.f;
+    const bool cl = seg_joined(d, dl, thr);
+    const bool start = valid && (lane == 0 || !cl);
+    const unsigned long long starts = __ballot(start);
+    const unsigned long long invalid = __ballot(!valid);
+    if (!inside) return;
+    int label = -1, len = 0;
+    if (valid) {
+        const unsigned long long upto = starts & (~0ull >> (63 - lane));
+        const int first = 63 - __clzll((long long)upto);  // a start at or before me always exists
+        label = i - lane + first;
+        if (start) {
+            const unsigned long long stops = ((starts | invalid) >> lane) >> 1;
+            len = stops ? __ffsll((long long)stops) : (kWave - lane);
+        }
+    }
+    L[i] = label;
+    RL[i] = len;
     cnt[i] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_seg_merge(const float* __restrict__ D,
-                                                   int32_t* __restrict__ L, int DW, int DH,
-                                                   float thr) {
+__global__ __launch_bounds__(256) void k_seg_link(const float* __restrict__ D,
+                                                  int32_t* __restrict__ L, int DW, int DH,
+                                                  float thr) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= DW || y >= DH) return;
     const int i = y * DW + x;
     const float d = D[i];
     if (!(d >= 0)) return;
-    if (x > 0) {
-        const float q = D[i - 1];
-        if (q >= 0 && fabsf(d - q) <= thr) uf_union(L, i, i - 1);
-    }
+    const float dl = x > 0 ? D[i - 1] : -10.f;
+    const bool cl = seg_joined(d, dl, thr);
+    // a run that continues across the wave border
+    if (threadIdx.x == 0 && cl) uf_union(L, i, L[i - 1]);
     if (y > 0) {
-        const float q = D[i - DW];
-        if (q >= 0 && fabsf(d - q) <= thr) uf_union(L, i, i - DW);
+        const float du = D[i - DW];
+        if (seg_joined(d, du, thr)) {
+            // p-1 ~ p, p-1 ~ q-1 and q-1 ~ q already put p and q in one set
+            bool redundant = false;
+            if (cl) {
+                const float dul = D[i - DW - 1];
+                redundant = seg_joined(dl, dul, thr) && seg_joined(du, dul, thr);
+            }
+            if (!redundant) uf_union(L, L[i], L[i - DW]);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void k_seg_count(int32_t* __restrict__ L,
+                                                   const int32_t* __restrict__ RL,
                                                    int32_t* __restrict__ cnt, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    int root = -1;
-    if (i < n && L[i] >= 0) {
-        root = uf_find(L, i);
+    if (i >= n) return;
+    const int len = RL[i];
+    if (len > 0) {
+        const int root = uf_find(L, i);
         L[i] = root;
-    }
-    // one atomic per run of equal roots inside the wave: a run starts at a valid
-    // lane whose predecessor holds another root and ends before the next run
-    // start or invalid lane
-    const int lane = threadIdx.x & 63;
-    const int prev = __shfl_up(root, 1, kWave);
-    const bool head = root >= 0 && (lane == 0 || prev != root);
-    const unsigned long long stops = __ballot(head) | __ballot(root < 0);
-    if (head) {
-        const unsigned long long later = (stops >> lane) >> 1;
-        const int len = later ? __ffsll((long long)later) : (kWave - lane);
         atomicAdd(&cnt[root], len);
     }
 }
@@ -428,11 +468,11 @@ __global__ __launch_bounds__(256) void k_seg_mask(float* __restrict__ D,
                                                   int min_size) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int root = L[i];
-    // invalid pixels form segments of one pixel and are (re)written as -10
-    if (root < 0) {
+    const int s = L[i];
+    if (s < 0) {
+        // an invalid pixel is a segment of one pixel (elas.cpp:1244-1317)
         if (1 < min_size) D[i] = -10.f;
-    } else if (cnt[root] < min_size) {
+    } else if (cnt[L[s]] < min_size) {
         D[i] = -10.f;
     }
 }
@@ -687,8 +727,12 @@ void launch_owner(const LaunchCtx& cx, const Dims& d, const TriRaster* r1, int32
                   int32_t* owner2) {
     hipStream_t s = (hipStream_t)cx.stream;
     const size_t bytes = (size_t)d.W * d.H * sizeof(int32_t);
-    (void)hipMemsetAsync(owner1, 0xFF, bytes, s);
-    (void)hipMemsetAsync(owner2, 0xFF, bytes, s);
+    if (owner2 == owner1 + (size_t)d.W * d.H) {
+        (void)hipMemsetAsync(owner1, 0xFF, 2 * bytes, s);
+    } else {
+        (void)hipMemsetAsync(owner1, 0xFF, bytes, s);
+        (void)hipMemsetAsync(owner2, 0xFF, bytes, s);
+    }
     const int nmax = n1 > n2 ? n1 : n2;
     if (nmax == 0) return;
     LAUNCH("k_owner", k_owner, dim3((nmax + 3) / 4, 2), dim3(256), r1, n1, r2, n2, d.W, d.H,
@@ -711,15 +755,15 @@ void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, con
 }
 
 void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D,
-                     int32_t* labels, int32_t* counts) {
+                     int32_t* labels, int32_t* runlen, int32_t* counts) {
     const int n = d.DW * d.DH;
     int min_size = p.speckle_size;
     if (p.subsampling) min_size = (int)(sqrtf((float)p.speckle_size) * 2);  // elas.cpp:1218
-    const dim3 lin((n + 255) / 256), b256(256);
-    LAUNCH("k_seg_init", k_seg_init, lin, b256, D, labels, counts, n);
-    LAUNCH("k_seg_merge", k_seg_merge, grid2d(d.DW, d.DH), dim3(64, 4), D, labels, d.DW, d.DH,
+    const dim3 lin((n + 255) / 256), b256(256), g2 = grid2d(d.DW, d.DH), b2(64, 4);
+    LAUNCH("k_seg_runs", k_seg_runs, g2, b2, D, labels, runlen, counts, d.DW, d.DH,
            p.speckle_sim_threshold);
-    LAUNCH("k_seg_count", k_seg_count, lin, b256, labels, counts, n);
+    LAUNCH("k_seg_link", k_seg_link, g2, b2, D, labels, d.DW, d.DH, p.speckle_sim_threshold);
+    LAUNCH("k_seg_count", k_seg_count, lin, b256, labels, runlen, counts, n);
     LAUNCH("k_seg_mask", k_seg_mask, lin, b256, D, labels, counts, n, min_size);
 }
 

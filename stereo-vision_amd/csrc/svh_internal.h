@@ -94,9 +94,9 @@ struct MatchArgs {
 void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, const MatchArgs& a);
 void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, const float* D1raw,
                const float* D2raw, float* D1, float* D2);
-// speckle removal: labels/counts are scratch of DW*DH int32 each
+// speckle removal: labels/runlen/counts are scratch of DW*DH int32 each
 void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D,
-                     int32_t* labels, int32_t* counts);
+                     int32_t* labels, int32_t* runlen, int32_t* counts);
 void launch_gap(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D, float* tmp);
 void launch_adaptive_mean(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D,
                           float* tmp);

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd database (the default output of
+`rocprofv3 --kernel-trace --stats`) as a per-kernel table: calls, total, average,
+min, max (us), share of GPU kernel time, VGPR/SGPR/LDS.  Used to turn the
+gpurun_out/ scratch databases into the small text summaries kept in profiles/."""
+import sqlite3
+import sys
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    rows = db.execute(
+        "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
+        "max(vgpr_count), max(sgpr_count), max(lds_size), max(grid_x*grid_y*grid_z), "
+        "max(workgroup_x*workgroup_y*workgroup_z) from kernels group by name order by sum(duration) desc"
+    ).fetchall()
+    total = sum(r[2] for r in rows) or 1
+    print("%-58s %7s %11s %9s %9s %9s %6s %5s %5s %6s %9s" % (
+        "kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct", "vgpr", "sgpr", "lds", "threads"))
+    for name, n, tot, avg, mn, mx, vg, sg, lds, grid, wg in rows:
+        import re as _re; m = _re.search(r"(k_\w+)(<[^>]*>)?", name); short = (m.group(0) if m else name)[:58]
+        print("%-58s %7d %11.1f %9.2f %9.2f %9.2f %6.2f %5s %5s %6s %9s" % (
+            short, n, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total, vg, sg, lds, grid))
+    span = db.execute("select min(start), max(end) from kernels").fetchone()
+    if span and span[0] is not None:
+        print("\nkernel time %.3f ms over a %.3f ms span (sum/span = %.2f: >1 means kernels from "
+              "different lanes overlap)" % (total / 1e6, (span[1] - span[0]) / 1e6,
+                                            total / max(span[1] - span[0], 1)))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
