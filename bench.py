@@ -41,7 +41,7 @@ ALG_BYTES_PER_PIXEL = {
     "k_support": 12.8,      # rows v+-2 of a 5-row lattice, both images
     "k_match": 72.0,        # 2 x (16 own + 16 other + 4 out)
     "k_lr": 16.0,
-    "k_seg_init": 8.0, "k_seg_merge": 8.0, "k_seg_count": 8.0, "k_seg_mask": 8.0,
+    "k_seg_runs": 8.0, "k_seg_link": 8.0, "k_seg_count": 8.0, "k_seg_mask": 8.0,
     "k_gap_rows": 8.0, "k_gap_cols": 8.0,
     "k_mean_h": 8.0, "k_mean_v": 8.0,
     "k_owner": 8.0,
@@ -126,8 +126,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="pairs per step and GPU")
+    ap.add_argument("--batch", type=int, default=128, help="pairs per step and GPU")
     ap.add_argument("--lanes", type=int, default=0, help="pipeline lanes per GPU (0 = auto)")
+    ap.add_argument("--group", type=int, default=4, help="pairs per kernel launch (1..16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -148,8 +149,9 @@ def main():
     import svhip as S
     import helpers as Hh
     S.lib().svh_set_device(local_rank)
-    lanes = args.lanes or max(2, min(8, (os.cpu_count() or 8) // max(world, 1)))
+    lanes = args.lanes or max(2, min(16, (os.cpu_count() or 8) // max(world, 1)))
     S.set_lanes(lanes)
+    group = S.set_group(args.group)
 
     B = args.batch
     params = Hh.robotics()           # Elas::parameters(ROBOTICS), elas.h:91-116
@@ -207,7 +209,8 @@ def main():
             dom = max(prof, key=lambda k: prof[k][0])
             ms, cnt = prof[dom]
             avg_s = ms / cnt / 1e3
-            abytes = ALG_BYTES_PER_PIXEL.get(dom, 8.0) * N_PIX
+            # one launch covers a whole group of pairs
+            abytes = ALG_BYTES_PER_PIXEL.get(dom, 8.0) * N_PIX * min(group, B)
             achieved = abytes / avg_s / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -235,6 +238,7 @@ def main():
             "config": {"workload": "configs[1]: KITTI-size 1242x375 pairs, ELAS ROBOTICS, D1+D2 + "
                                    "LR-check, subsampling=false, inputs and outputs resident in HBM",
                        "pairs_per_step_per_gpu": B, "lanes_per_gpu": lanes,
+                       "pairs_per_launch": group,
                        "d1_valid_fraction": round(valid, 4)},
             "roofline": roofline,
         }

@@ -113,6 +113,9 @@ int32_t svh_elas_process_batch_device(svh_elas* e, int32_t n,
 
 /* number of pipeline lanes (streams + host workers) the engine uses per device */
 int32_t svh_elas_set_lanes(int32_t lanes);
+/* pairs a lane pushes through each kernel launch (1..16): batches are cut into
+ * groups of this many consecutive pairs */
+int32_t svh_elas_set_group(int32_t pairs);
 
 /* Stage taps for parity tests: after a successful svh_elas_process() the
  * intermediate of the given stage (of the last pair processed through handle

@@ -109,90 +109,97 @@ struct EventProfiler : Profiler {
 };
 
 // ---------------------------------------------------------------------------
-// lane: stream + buffers
+// lane: stream + buffers for a group of up to `gcap` pairs
 // ---------------------------------------------------------------------------
 struct Lane {
     EventProfiler prof;
     int device = 0;
     hipStream_t stream = nullptr;
     // geometry the buffers were sized for
-    int32_t W = 0, H = 0, disp_max = -1, step = 0, grid_size = 0, sub = -1;
+    int32_t W = 0, H = 0, disp_max = -1, step = 0, grid_size = 0, sub = -1, gcap = 0;
     Dims d{};
     // device
-    uint8_t* img[2] = {nullptr, nullptr};
-    uint8_t* desc[2] = {nullptr, nullptr};
-    int16_t* dcan = nullptr;
-    int32_t* owner[2] = {nullptr, nullptr};
-    uint8_t* prior_dev = nullptr;   // packed upload: rasters, cell lists, P
-    float* Draw[2] = {nullptr, nullptr};
-    float* D[2] = {nullptr, nullptr};
-    float* tmp = nullptr;
+    uint8_t* img = nullptr;        // [gcap][2][N]       staged host images
+    uint8_t* desc = nullptr;       // [gcap][2][N*16]
+    int16_t* dcan = nullptr;       // [gcap][nc]
+    int32_t* owner = nullptr;      // [gcap][2][N]
+    uint8_t* prior_dev = nullptr;  // packed upload: header, P, support, triangles
+    TriRaster* raster = nullptr;   // [gcap*2*ntri_max]
+    float* planes = nullptr;       // 6 per triangle
+    uint32_t* seed = nullptr;      // [gcap][2][cells][gwords]
+    uint32_t* mask = nullptr;
+    float* Draw = nullptr;         // [gcap][2][DN]
+    float* D = nullptr;            // [gcap][2][DN]  (host-output mode)
+    float* tmp = nullptr;          // [gcap][2][DN]
     int32_t* labels = nullptr;
     int32_t* runlen = nullptr;
     int32_t* counts = nullptr;
     // pinned host
     int16_t* h_dcan = nullptr;
-    uint8_t* h_img = nullptr;      // packed copy of both input images
+    uint8_t* h_img = nullptr;
     uint8_t* h_prior = nullptr;
     size_t prior_cap = 0;
-    HostPrior hp;
+    size_t ntri_max = 0;
+    std::vector<HostPrior> hp;
     std::vector<int16_t> dcan_work;
+    std::vector<int32_t> P;
 
     void release() {
         if (!stream) return;
         (void)hipSetDevice(device);
-        for (int k = 0; k < 2; k++) {
-            (void)hipFree(img[k]); (void)hipFree(desc[k]);
-            (void)hipFree(Draw[k]); (void)hipFree(D[k]);
-            img[k] = desc[k] = nullptr; owner[k] = nullptr; Draw[k] = D[k] = nullptr;
-        }
-        (void)hipFree(owner[0]);
-        (void)hipFree(dcan); (void)hipFree(prior_dev); (void)hipFree(tmp); (void)hipFree(labels);
-        (void)hipFree(counts); (void)hipFree(runlen);
-        dcan = nullptr; prior_dev = nullptr; tmp = nullptr; labels = counts = runlen = nullptr;
+        (void)hipFree(img); (void)hipFree(desc); (void)hipFree(dcan); (void)hipFree(owner);
+        (void)hipFree(prior_dev); (void)hipFree(raster); (void)hipFree(planes); (void)hipFree(seed);
+        (void)hipFree(mask); (void)hipFree(Draw); (void)hipFree(D); (void)hipFree(tmp);
+        (void)hipFree(labels); (void)hipFree(runlen); (void)hipFree(counts);
+        img = desc = prior_dev = nullptr; dcan = nullptr; owner = nullptr; raster = nullptr;
+        planes = Draw = D = tmp = nullptr; seed = mask = nullptr; labels = runlen = counts = nullptr;
         (void)hipHostFree(h_dcan); (void)hipHostFree(h_prior); (void)hipHostFree(h_img);
         h_dcan = nullptr; h_prior = nullptr; h_img = nullptr;
         W = H = 0;
     }
 
-    int ensure(const svh_elas_params& p, int32_t w, int32_t h) {
+    int ensure(const svh_elas_params& p, int32_t w, int32_t h, int32_t g) {
         if (!stream) {
             HIP_TRY(hipSetDevice(device));
             HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         }
         const int32_t st = p.candidate_stepsize + (p.subsampling ? p.candidate_stepsize % 2 : 0);
         if (w == W && h == H && p.disp_max == disp_max && st == step && p.grid_size == grid_size &&
-            p.subsampling == sub)
+            p.subsampling == sub && g <= gcap)
             return SVH_OK;
         hipStream_t keep = stream;
         release();
         stream = keep;
         d = make_dims(p, w, h);
-        const size_t N = (size_t)w * h, DN = (size_t)d.DW * d.DH;
-        for (int k = 0; k < 2; k++) {
-            HIP_TRY(hipMalloc(&img[k], N));
-            HIP_TRY(hipMalloc(&desc[k], N * 16));
-            HIP_TRY(hipMalloc(&Draw[k], DN * sizeof(float)));
-            HIP_TRY(hipMalloc(&D[k], DN * sizeof(float)));
-        }
-        HIP_TRY(hipMalloc(&owner[0], 2 * N * sizeof(int32_t)));   // both sides, one memset
-        owner[1] = owner[0] + N;
-        HIP_TRY(hipMalloc(&tmp, DN * sizeof(float)));
-        HIP_TRY(hipMalloc(&labels, DN * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&counts, DN * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&runlen, DN * sizeof(int32_t)));
+        const size_t N = (size_t)w * h, DN = (size_t)d.DW * d.DH, G2 = (size_t)2 * g;
+        HIP_TRY(hipMalloc(&img, G2 * N));
+        HIP_TRY(hipMalloc(&desc, G2 * N * 16));
+        HIP_TRY(hipMalloc(&owner, G2 * N * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&Draw, G2 * DN * sizeof(float)));
+        HIP_TRY(hipMalloc(&D, G2 * DN * sizeof(float)));
+        HIP_TRY(hipMalloc(&tmp, G2 * DN * sizeof(float)));
+        HIP_TRY(hipMalloc(&labels, G2 * DN * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&runlen, G2 * DN * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&counts, G2 * DN * sizeof(int32_t)));
         const size_t nc = (size_t)d.Wc * d.Hc;
-        HIP_TRY(hipMalloc(&dcan, nc * sizeof(int16_t)));
-        HIP_TRY(hipHostMalloc(&h_dcan, nc * sizeof(int16_t)));
-        HIP_TRY(hipHostMalloc(&h_img, 2 * N));
-        // worst case prior: 2*(2n+8) triangles, full cell lists
-        const size_t nsup = nc + 6, ntri = 2 * nsup + 8, cells = (size_t)d.gw * d.gh;
-        prior_cap = 2 * (ntri * sizeof(TriRaster) + (cells + 1) * sizeof(int32_t) +
-                         cells * (size_t)(p.disp_max + 1) * sizeof(uint16_t)) +
-                    (size_t)(p.disp_max + 1) * sizeof(int32_t) + 256;
+        HIP_TRY(hipMalloc(&dcan, g * nc * sizeof(int16_t)));
+        HIP_TRY(hipHostMalloc(&h_dcan, g * nc * sizeof(int16_t)));
+        HIP_TRY(hipHostMalloc(&h_img, G2 * N));
+        // worst case per pair: nc+6 support points, 2n+8 triangles per side
+        const size_t nsup = nc + 6;
+        ntri_max = 2 * nsup + 8;
+        prior_cap = sizeof(GroupHdr) + (size_t)(p.disp_max + 1) * sizeof(int32_t) + 512 +
+                    (size_t)g * (nsup * 3 + 2 * ntri_max * 3) * sizeof(int32_t);
         HIP_TRY(hipMalloc(&prior_dev, prior_cap));
         HIP_TRY(hipHostMalloc(&h_prior, prior_cap));
+        HIP_TRY(hipMalloc(&raster, G2 * ntri_max * sizeof(TriRaster)));
+        HIP_TRY(hipMalloc(&planes, G2 * ntri_max * 6 * sizeof(float)));
+        const size_t gw_bytes = G2 * d.gw * d.gh * d.gwords * sizeof(uint32_t);
+        HIP_TRY(hipMalloc(&seed, gw_bytes));
+        HIP_TRY(hipMalloc(&mask, gw_bytes));
+        hp.resize(g);
         W = w; H = h; disp_max = p.disp_max; step = st; grid_size = p.grid_size; sub = p.subsampling;
+        gcap = g;
         return SVH_OK;
     }
 };
@@ -210,7 +217,8 @@ struct Pool {
 
 static std::mutex g_mu;
 static std::map<int, Pool*> g_pools;
-static std::atomic<int> g_lanes{4};
+static std::atomic<int> g_lanes{8};
+static std::atomic<int> g_group{4};
 
 static Pool* pool_for(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -270,12 +278,18 @@ struct svh_elas {
 
 namespace svh {
 
-struct PairIO {
-    const uint8_t* I[2];
-    int32_t pitch;
+// inputs / outputs of one group of g consecutive pairs
+struct GroupIO {
+    int32_t g;
     bool in_device;
-    float* D[2];
+    const uint8_t* dI[2];            // device: image k of pair j at dI[k] + j*in_stride
+    size_t in_stride;
+    const uint8_t* const* hI[2];     // host: per-pair pointers
+    int32_t pitch;
     bool out_device;
+    float* dD[2];                    // device: map k of pair j at dD[k] + j*out_stride (floats)
+    size_t out_stride;
+    float* const* hD[2];             // host: per-pair pointers
 };
 
 static int check_params(const svh_elas_params& p, int32_t W, int32_t H) {
@@ -289,6 +303,7 @@ template <typename T>
 static int tap_dev(Lane& L, Taps* taps, int stage, const T* dev, size_t count) {
     if (!taps || !taps->enabled) return SVH_OK;
     taps->data[stage].resize(count * sizeof(T));
+    if (!count) return SVH_OK;
     HIP_TRY(hipMemcpyAsync(taps->data[stage].data(), dev, count * sizeof(T), hipMemcpyDeviceToHost,
                            L.stream));
     HIP_TRY(hipStreamSynchronize(L.stream));
@@ -302,151 +317,201 @@ static void tap_host(Taps* taps, int stage, const T* src, size_t count) {
     if (count) memcpy(taps->data[stage].data(), src, count * sizeof(T));
 }
 
-// one stereo pair through one lane
-static int run_pair(Lane& L, const svh_elas_params& p, const int32_t* dims, const PairIO& io,
-                    Taps* taps, svh_elas* timing) {
-    const int32_t W = dims[0], H = dims[1];
+// one group of pairs through one lane; status[j] per pair
+static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, const GroupIO& io,
+                     int32_t* status, Taps* taps, svh_elas* timing) {
+    const int32_t W = dims[0], H = dims[1], g = io.g;
     int rc = check_params(p, W, H);
     if (rc) return rc;
+    if (g < 1 || g > kMaxGroup) return fail(SVH_ERR_BAD_ARG, "bad group size");
     HIP_TRY(hipSetDevice(L.device));
-    rc = L.ensure(p, W, H);
+    rc = L.ensure(p, W, H, std::max(g, std::min(g_group.load(), kMaxGroup)));
     if (rc) return rc;
+    if (g > 1) taps = nullptr;
     const Dims& d = L.d;
     hipStream_t s = L.stream;
     L.prof.stream = s;
     const LaunchCtx cx = {s, g_prof_on.load() ? &L.prof : nullptr};
     const size_t N = (size_t)W * H, DN = (size_t)d.DW * d.DH;
+    const size_t nc = (size_t)d.Wc * d.Hc;
     double t0 = now_ms();
 
     // ---- phase A ---------------------------------------------------------
     DevImages img;
     if (io.in_device) {
-        img.I[0] = io.I[0]; img.I[1] = io.I[1];
-        img.pitch[0] = img.pitch[1] = io.pitch;
+        img.I[0] = io.dI[0]; img.I[1] = io.dI[1];
+        img.stride = io.in_stride; img.pitch = io.pitch;
     } else {
-        // the caller's rows (any stride, pageable) are packed into pinned staging
-        // on the host, then each image goes up in one linear DMA
-        for (int k = 0; k < 2; k++) {
-            uint8_t* dst = L.h_img + (size_t)k * N;
-            if (io.pitch == W) memcpy(dst, io.I[k], N);
-            else
-                for (int32_t v = 0; v < H; v++) memcpy(dst + (size_t)v * W, io.I[k] + (size_t)v * io.pitch, W);
-            HIP_TRY(hipMemcpyAsync(L.img[k], dst, N, hipMemcpyHostToDevice, s));
-        }
-        img.I[0] = L.img[0]; img.I[1] = L.img[1];
-        img.pitch[0] = img.pitch[1] = W;
+        // the callers' rows (any stride, pageable) are packed into pinned staging
+        // on the host, then the whole group goes up in one linear DMA
+        for (int32_t j = 0; j < g; j++)
+            for (int k = 0; k < 2; k++) {
+                uint8_t* dst = L.h_img + ((size_t)2 * j + k) * N;
+                const uint8_t* src = io.hI[k][j];
+                if (io.pitch == W) memcpy(dst, src, N);
+                else
+                    for (int32_t v = 0; v < H; v++) memcpy(dst + (size_t)v * W, src + (size_t)v * io.pitch, W);
+            }
+        HIP_TRY(hipMemcpyAsync(L.img, L.h_img, (size_t)2 * g * N, hipMemcpyHostToDevice, s));
+        img.I[0] = L.img; img.I[1] = L.img + N;
+        img.stride = 2 * N; img.pitch = W;
     }
-    launch_descriptor(cx, img, W, H, p.subsampling, L.desc[0], L.desc[1]);
-    launch_support(cx, p, d, L.desc[0], L.desc[1], L.dcan);
-    const size_t nc = (size_t)d.Wc * d.Hc;
-    HIP_TRY(hipMemcpyAsync(L.h_dcan, L.dcan, nc * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    launch_descriptor(cx, img, g, W, H, p.subsampling, L.desc);
+    launch_support(cx, p, d, g, L.desc, L.dcan);
+    HIP_TRY(hipMemcpyAsync(L.h_dcan, L.dcan, g * nc * sizeof(int16_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
     L.prof.collect();
     double t1 = now_ms();
     if (taps && taps->enabled) {
-        rc = tap_dev(L, taps, SVH_ELAS_DESC1, L.desc[0], N * 16); if (rc) return rc;
-        rc = tap_dev(L, taps, SVH_ELAS_DESC2, L.desc[1], N * 16); if (rc) return rc;
+        rc = tap_dev(L, taps, SVH_ELAS_DESC1, L.desc, N * 16); if (rc) return rc;
+        rc = tap_dev(L, taps, SVH_ELAS_DESC2, L.desc + N * 16, N * 16); if (rc) return rc;
         tap_host(taps, SVH_ELAS_DCAN_RAW, L.h_dcan, nc);
     }
 
-    // ---- host ------------------------------------------------------------
-    HostPrior& hp = L.hp;
-    L.dcan_work.assign(L.h_dcan, L.h_dcan + nc);
-    support_from_candidates(p, d, L.dcan_work.data(), hp.support);
-    tap_host(taps, SVH_ELAS_SUPPORT, hp.support.data(), hp.support.size());
-    if (hp.support.size() / 3 < 3) {
-        // elas.cpp:69-75: message on stdout, outputs untouched
-        printf("ERROR: Need at least 3 support points!\n");
-        fflush(stdout);
-        return SVH_ERR_FEW_SUPPORT;
-    }
-    if (!build_prior(p, d, hp)) return fail(SVH_ERR_UNSUPPORTED, "triangulation failed");
-    if (taps && taps->enabled) {
+    // ---- host: lattice filters + Delaunay, then one packed upload ------------
+    GroupHdr* hdr = reinterpret_cast<GroupHdr*>(L.h_prior);
+    memset(hdr, 0, sizeof(GroupHdr));
+    hdr->npairs = g;
+    int32_t total_sup = 0, total_tri = 0, nactive = 0;
+    for (int32_t j = 0; j < g; j++) {
+        HostPrior& hp = L.hp[j];
+        L.dcan_work.assign(L.h_dcan + j * nc, L.h_dcan + (j + 1) * nc);
+        support_from_candidates(p, d, L.dcan_work.data(), hp.support);
+        hdr->sup_off[j] = total_sup;
+        status[j] = SVH_OK;
+        if (hp.support.size() / 3 < 3) {
+            // elas.cpp:69-75: message on stdout, outputs untouched
+            printf("ERROR: Need at least 3 support points!\n");
+            fflush(stdout);
+            status[j] = SVH_ERR_FEW_SUPPORT;
+            hp.support.clear();
+            hp.tri[0].clear();
+            hp.tri[1].clear();
+        } else if (!triangulate_support(hp)) {
+            return fail(SVH_ERR_UNSUPPORTED, "triangulation failed");
+        } else {
+            hdr->active[j] = 1;
+            nactive++;
+        }
+        total_sup += (int32_t)(hp.support.size() / 3);
         for (int k = 0; k < 2; k++) {
-            tap_host(taps, SVH_ELAS_TRI1 + k, hp.tri[k].data(), hp.tri[k].size());
-            tap_host(taps, SVH_ELAS_PLANES1 + k, hp.planes[k].data(), hp.planes[k].size());
-            std::vector<int32_t> g;
-            expand_grid(p, d, hp, k, g);
-            tap_host(taps, SVH_ELAS_GRID1 + k, g.data(), g.size());
+            total_tri += (int32_t)(hp.tri[k].size() / 3);
+            hdr->tri_end[2 * j + k] = total_tri;
         }
     }
-    // pack the prior into one pinned block -> one H2D copy
-    size_t off = 0;
+    hdr->sup_off[g] = total_sup;
+    if (taps && taps->enabled) {
+        tap_host(taps, SVH_ELAS_SUPPORT, L.hp[0].support.data(), L.hp[0].support.size());
+        for (int k = 0; k < 2; k++)
+            tap_host(taps, SVH_ELAS_TRI1 + k, L.hp[0].tri[k].data(), L.hp[0].tri[k].size());
+    }
+    if (nactive == 0) return SVH_OK;   // nothing to match; every status is already set
+    int32_t plane_radius = 2;
+    prior_table(p, L.P, &plane_radius);
+    size_t off = (sizeof(GroupHdr) + 63) & ~(size_t)63;
     auto put = [&](const void* src, size_t bytes) {
         size_t at = off;
         if (bytes) memcpy(L.h_prior + at, src, bytes);
         off = (off + bytes + 63) & ~(size_t)63;
         return at;
     };
-    size_t o_r[2], o_off[2], o_d[2];
-    for (int k = 0; k < 2; k++) {
-        o_r[k] = put(hp.raster[k].data(), hp.raster[k].size() * sizeof(TriRaster));
-        o_off[k] = put(hp.cell_off[k].data(), hp.cell_off[k].size() * sizeof(int32_t));
-        o_d[k] = put(hp.cell_d[k].data(), hp.cell_d[k].size() * sizeof(uint16_t));
+    const size_t o_P = put(L.P.data(), L.P.size() * sizeof(int32_t));
+    const size_t o_sup = off;
+    for (int32_t j = 0; j < g; j++) {
+        const std::vector<int32_t>& v = L.hp[j].support;
+        if (!v.empty()) memcpy(L.h_prior + off, v.data(), v.size() * sizeof(int32_t));
+        off += v.size() * sizeof(int32_t);
     }
-    size_t o_P = put(hp.P.data(), hp.P.size() * sizeof(int32_t));
+    off = (off + 63) & ~(size_t)63;
+    const size_t o_tri = off;
+    for (int32_t j = 0; j < g; j++)
+        for (int k = 0; k < 2; k++) {
+            const std::vector<int32_t>& v = L.hp[j].tri[k];
+            if (!v.empty()) memcpy(L.h_prior + off, v.data(), v.size() * sizeof(int32_t));
+            off += v.size() * sizeof(int32_t);
+        }
     if (off > L.prior_cap) return fail(SVH_ERR_BAD_ARG, "prior exceeds staging capacity");
     double t2 = now_ms();
 
     // ---- phase B ---------------------------------------------------------
     HIP_TRY(hipMemcpyAsync(L.prior_dev, L.h_prior, off, hipMemcpyHostToDevice, s));
-    const TriRaster* r_dev[2] = {(const TriRaster*)(L.prior_dev + o_r[0]),
-                                 (const TriRaster*)(L.prior_dev + o_r[1])};
-    launch_owner(cx, d, r_dev[0], (int32_t)hp.raster[0].size(), r_dev[1],
-                 (int32_t)hp.raster[1].size(), p.subsampling, L.owner[0], L.owner[1]);
-    MatchArgs ma;
-    for (int k = 0; k < 2; k++) {
-        ma.desc[k] = L.desc[k];
-        ma.owner[k] = L.owner[k];
-        ma.raster[k] = r_dev[k];
-        ma.cell_off[k] = (const int32_t*)(L.prior_dev + o_off[k]);
-        ma.cell_d[k] = (const uint16_t*)(L.prior_dev + o_d[k]);
-        ma.D[k] = L.Draw[k];
-    }
-    ma.P = (const int32_t*)(L.prior_dev + o_P);
-    ma.plane_radius = hp.plane_radius;
-    launch_match(cx, p, d, ma);
+    GroupDev G;
+    G.hdr = reinterpret_cast<const GroupHdr*>(L.prior_dev);
+    G.P = reinterpret_cast<const int32_t*>(L.prior_dev + o_P);
+    G.support = reinterpret_cast<const int32_t*>(L.prior_dev + o_sup);
+    G.tri = reinterpret_cast<const int32_t*>(L.prior_dev + o_tri);
+    G.raster = L.raster;
+    G.planes = L.planes;
+    G.seed = L.seed;
+    G.mask = L.mask;
+    G.desc = L.desc;
+    G.owner = L.owner;
+    G.Draw = L.Draw;
+    G.plane_radius = plane_radius;
+    launch_prior(cx, p, d, g, total_sup, total_tri, G);
     if (taps && taps->enabled) {
-        rc = tap_dev(L, taps, SVH_ELAS_D1_RAW, L.Draw[0], DN); if (rc) return rc;
-        rc = tap_dev(L, taps, SVH_ELAS_D2_RAW, L.Draw[1], DN); if (rc) return rc;
+        const int32_t n1 = hdr->tri_end[0], n2 = hdr->tri_end[1] - hdr->tri_end[0];
+        rc = tap_dev(L, taps, SVH_ELAS_PLANES1, L.planes, (size_t)6 * n1); if (rc) return rc;
+        rc = tap_dev(L, taps, SVH_ELAS_PLANES2, L.planes + (size_t)6 * n1, (size_t)6 * n2); if (rc) return rc;
+        const size_t words = (size_t)d.gw * d.gh * d.gwords;
+        std::vector<uint32_t> m(2 * words);
+        HIP_TRY(hipMemcpyAsync(m.data(), L.mask, m.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int k = 0; k < 2; k++) {
+            std::vector<int32_t> gr;
+            expand_grid(p, d, m.data() + k * words, gr);
+            tap_host(taps, SVH_ELAS_GRID1 + k, gr.data(), gr.size());
+        }
     }
-    // when the caller's maps live on the device the post-processing chain runs in
+    launch_owner(cx, p, d, g, total_tri, G);
+    launch_match(cx, p, d, g, G);
+    if (taps && taps->enabled) {
+        rc = tap_dev(L, taps, SVH_ELAS_D1_RAW, L.Draw, DN); if (rc) return rc;
+        rc = tap_dev(L, taps, SVH_ELAS_D2_RAW, L.Draw + DN, DN); if (rc) return rc;
+    }
+    // when the callers' maps live on the device the post-processing chain runs in
     // place on them: no final copy
-    float* D1 = io.out_device ? io.D[0] : L.D[0];
-    float* D2 = io.out_device ? io.D[1] : L.D[1];
-    launch_lr(cx, p, d, L.Draw[0], L.Draw[1], D1, D2);
+    DevMaps out;
+    if (io.out_device) {
+        out.D[0] = io.dD[0]; out.D[1] = io.dD[1]; out.stride = io.out_stride;
+    } else {
+        out.D[0] = L.D; out.D[1] = L.D + DN; out.stride = 2 * DN;
+    }
+    const PostScratch ps = {L.tmp, L.labels, L.runlen, L.counts};
+    launch_lr(cx, p, d, g, G, out);
     if (taps && taps->enabled) {
-        rc = tap_dev(L, taps, SVH_ELAS_D1_LR, D1, DN); if (rc) return rc;
-        rc = tap_dev(L, taps, SVH_ELAS_D2_LR, D2, DN); if (rc) return rc;
+        rc = tap_dev(L, taps, SVH_ELAS_D1_LR, out.D[0], DN); if (rc) return rc;
+        rc = tap_dev(L, taps, SVH_ELAS_D2_LR, out.D[1], DN); if (rc) return rc;
     }
     const int nside = p.postprocess_only_left ? 1 : 2;
-    for (int k = 0; k < nside; k++) launch_segments(cx, p, d, k ? D2 : D1, L.labels, L.runlen, L.counts);
+    launch_segments(cx, p, d, g, nside, G, out, ps);
     if (taps && taps->enabled) {
-        rc = tap_dev(L, taps, SVH_ELAS_D1_SEG, D1, DN); if (rc) return rc;
-        rc = tap_dev(L, taps, SVH_ELAS_D2_SEG, D2, DN); if (rc) return rc;
+        rc = tap_dev(L, taps, SVH_ELAS_D1_SEG, out.D[0], DN); if (rc) return rc;
+        rc = tap_dev(L, taps, SVH_ELAS_D2_SEG, out.D[1], DN); if (rc) return rc;
     }
-    for (int k = 0; k < nside; k++) launch_gap(cx, p, d, k ? D2 : D1, L.tmp);
+    launch_gap(cx, p, d, g, nside, G, out, ps);
     if (taps && taps->enabled) {
-        rc = tap_dev(L, taps, SVH_ELAS_D1_GAP, D1, DN); if (rc) return rc;
-        rc = tap_dev(L, taps, SVH_ELAS_D2_GAP, D2, DN); if (rc) return rc;
+        rc = tap_dev(L, taps, SVH_ELAS_D1_GAP, out.D[0], DN); if (rc) return rc;
+        rc = tap_dev(L, taps, SVH_ELAS_D2_GAP, out.D[1], DN); if (rc) return rc;
     }
-    if (p.filter_adaptive_mean)
-        for (int k = 0; k < nside; k++) launch_adaptive_mean(cx, p, d, k ? D2 : D1, L.tmp);
-    if (p.filter_median)
-        for (int k = 0; k < nside; k++) launch_median(cx, d, k ? D2 : D1, L.tmp);
+    if (p.filter_adaptive_mean) launch_adaptive_mean(cx, p, d, g, nside, G, out, ps);
+    if (p.filter_median) launch_median(cx, d, g, nside, G, out, ps);
 
-    if (!io.out_device) {
-        HIP_TRY(hipMemcpyAsync(io.D[0], D1, DN * sizeof(float), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(io.D[1], D2, DN * sizeof(float), hipMemcpyDeviceToHost, s));
-    }
+    if (!io.out_device)
+        for (int32_t j = 0; j < g; j++) {
+            if (!hdr->active[j]) continue;
+            for (int k = 0; k < 2; k++)
+                HIP_TRY(hipMemcpyAsync(io.hD[k][j], L.D + ((size_t)2 * j + k) * DN, DN * sizeof(float),
+                                       hipMemcpyDeviceToHost, s));
+        }
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
     L.prof.collect();
     double t3 = now_ms();
     if (timing) {
-        timing->tnames = {"Descriptor+Support Matches (device)", "Filters+Delaunay+Planes+Grid (host)",
-                          "Matching+L/R+Segments+Gap+Mean (device)"};
+        timing->tnames = {"Descriptor+Support Matches (device)", "Filters+Delaunay (host)",
+                          "Planes+Grid+Matching+L/R+Segments+Gap+Mean (device)"};
         timing->tms = {(float)(t1 - t0), (float)(t2 - t1), (float)(t3 - t2)};
     }
     return SVH_OK;
@@ -588,30 +653,39 @@ int32_t svh_elas_process(svh_elas* e, const uint8_t* I1, const uint8_t* I2, floa
     int32_t rc = require_device(e->device);
     if (rc) return rc;
     Lane* L = acquire_lane(e->device);
-    PairIO io;
-    io.I[0] = I1; io.I[1] = I2; io.pitch = dims[2]; io.in_device = false;
-    io.D[0] = D1; io.D[1] = D2; io.out_device = false;
-    rc = run_pair(*L, e->p, dims, io, &e->taps, e);
+    GroupIO io{};
+    io.g = 1;
+    io.in_device = false;
+    io.hI[0] = &I1; io.hI[1] = &I2; io.pitch = dims[2];
+    io.out_device = false;
+    io.hD[0] = &D1; io.hD[1] = &D2;
+    int32_t st = SVH_OK;
+    rc = run_group(*L, e->p, dims, io, &st, &e->taps, e);
     release_lane(L);
-    return rc;
+    return rc ? rc : st;
 }
 
+// n pairs -> groups of up to g_group consecutive pairs, spread over the lanes
 static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* status,
-                          const std::function<PairIO(int32_t)>& io_of) {
+                          const std::function<GroupIO(int32_t, int32_t)>& io_of) {
     int32_t rc = require_device(e->device);
     if (rc) return rc;
-    const int lanes = std::min<int>(g_lanes.load(), n);
+    const int32_t G = std::max(1, std::min(g_group.load(), kMaxGroup));
+    const int32_t ngroups = (n + G - 1) / G;
+    const int lanes = std::min<int>(g_lanes.load(), ngroups);
     std::atomic<int32_t> next{0};
     std::vector<int32_t> st(n, SVH_OK);
-    std::vector<std::string> errs(lanes);
+    std::vector<int32_t> grc(ngroups, SVH_OK);
+    std::vector<std::string> errs(std::max(lanes, 1));
     auto worker = [&](int w) {
         Lane* L = acquire_lane(e->device);
         for (;;) {
-            int32_t i = next.fetch_add(1);
-            if (i >= n) break;
-            PairIO io = io_of(i);
-            st[i] = run_pair(*L, e->p, dims, io, nullptr, nullptr);
-            if (st[i] < 0) errs[w] = t_error;
+            int32_t gi = next.fetch_add(1);
+            if (gi >= ngroups) break;
+            const int32_t first = gi * G, cnt = std::min(G, n - first);
+            GroupIO io = io_of(first, cnt);
+            grc[gi] = run_group(*L, e->p, dims, io, &st[first], nullptr, nullptr);
+            if (grc[gi] < 0) errs[w] = t_error;
         }
         release_lane(L);
     };
@@ -622,14 +696,18 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
         for (int w = 0; w < lanes; w++) th.emplace_back(worker, w);
         for (auto& t : th) t.join();
     }
-    int32_t first = SVH_OK;
+    int32_t first_bad = SVH_OK;
+    for (int32_t gi = 0; gi < ngroups; gi++)
+        if (grc[gi] != SVH_OK) {
+            for (int32_t i = gi * G; i < std::min(n, (gi + 1) * G); i++) st[i] = grc[gi];
+        }
     for (int32_t i = 0; i < n; i++) {
         if (status) status[i] = st[i];
-        if (first == SVH_OK && st[i] != SVH_OK) first = st[i];
+        if (first_bad == SVH_OK && st[i] != SVH_OK) first_bad = st[i];
     }
     for (auto& m : errs)
         if (!m.empty()) t_error = m;
-    return first;
+    return first_bad;
 }
 
 int32_t svh_elas_process_batch(svh_elas* e, int32_t n, const uint8_t* const* I1,
@@ -637,10 +715,13 @@ int32_t svh_elas_process_batch(svh_elas* e, int32_t n, const uint8_t* const* I1,
                                const int32_t* dims, int32_t* status) {
     if (!e || n < 0 || !I1 || !I2 || !D1 || !D2 || !dims) return fail(SVH_ERR_BAD_ARG, "null argument");
     if (n == 0) return SVH_OK;
-    return batch_impl(e, n, dims, status, [&](int32_t i) {
-        PairIO io;
-        io.I[0] = I1[i]; io.I[1] = I2[i]; io.pitch = dims[2]; io.in_device = false;
-        io.D[0] = D1[i]; io.D[1] = D2[i]; io.out_device = false;
+    return batch_impl(e, n, dims, status, [&](int32_t first, int32_t cnt) {
+        GroupIO io{};
+        io.g = cnt;
+        io.in_device = false;
+        io.hI[0] = I1 + first; io.hI[1] = I2 + first; io.pitch = dims[2];
+        io.out_device = false;
+        io.hD[0] = D1 + first; io.hD[1] = D2 + first;
         return io;
     });
 }
@@ -649,16 +730,27 @@ int32_t svh_elas_process_batch_device(svh_elas* e, int32_t n, const uint8_t* dI1
                                       size_t in_stride, float* dD1, float* dD2, size_t out_stride,
                                       const int32_t* dims, int32_t* status) {
     if (!e || n < 0 || !dI1 || !dI2 || !dD1 || !dD2 || !dims) return fail(SVH_ERR_BAD_ARG, "null argument");
+    if (out_stride % sizeof(float)) return fail(SVH_ERR_BAD_ARG, "out_stride must be a multiple of 4");
     if (n == 0) return SVH_OK;
-    return batch_impl(e, n, dims, status, [&](int32_t i) {
-        PairIO io;
-        io.I[0] = dI1 + (size_t)i * in_stride; io.I[1] = dI2 + (size_t)i * in_stride;
-        io.pitch = dims[2]; io.in_device = true;
-        io.D[0] = (float*)((uint8_t*)dD1 + (size_t)i * out_stride);
-        io.D[1] = (float*)((uint8_t*)dD2 + (size_t)i * out_stride);
+    return batch_impl(e, n, dims, status, [&](int32_t first, int32_t cnt) {
+        GroupIO io{};
+        io.g = cnt;
+        io.in_device = true;
+        io.dI[0] = dI1 + (size_t)first * in_stride; io.dI[1] = dI2 + (size_t)first * in_stride;
+        io.in_stride = in_stride; io.pitch = dims[2];
         io.out_device = true;
+        io.dD[0] = dD1 + (size_t)first * (out_stride / sizeof(float));
+        io.dD[1] = dD2 + (size_t)first * (out_stride / sizeof(float));
+        io.out_stride = out_stride / sizeof(float);
         return io;
     });
+}
+
+int32_t svh_elas_set_group(int32_t pairs) {
+    if (pairs < 1) pairs = 1;
+    if (pairs > kMaxGroup) pairs = kMaxGroup;
+    g_group.store(pairs);
+    return pairs;
 }
 
 }  // extern "C"

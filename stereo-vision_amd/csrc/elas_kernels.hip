@@ -50,29 +50,40 @@ __device__ __forceinline__ int32_t sat_u8(int32_t x) { return x < 0 ? 0 : (x > 2
 // (uint32_t)f assigned to int32_t with x86 cvttss2si semantics (elas.cpp:1081-1082)
 __device__ __forceinline__ int32_t f2u2i(float f) { return (int32_t)(uint32_t)(long long)f; }
 
+// which (pair, side) slot a packed triangle index belongs to
+__device__ __forceinline__ int tri_slot(const GroupHdr* __restrict__ h, int T, int* first) {
+    const int slots = 2 * h->npairs;
+    int s = 0, lo = 0;
+    while (s < slots - 1 && T >= h->tri_end[s]) {
+        lo = h->tri_end[s];
+        s++;
+    }
+    *first = lo;
+    return s;
+}
+
 // ---------------------------------------------------------------------------
 // E1+E2  3x3 Sobel + 16-byte descriptor, fused
 //   filter::sobel3x3          libelas/src/filter.cpp:408-416 (+372-405, 227-267, 176-222)
 //   Descriptor::createDescriptor   libelas/src/descriptor.cpp:48-121
-// One block = 64x16 pixel tile of one image.  The 8-bit tile (+3 halo) goes to
-// LDS once, du/dv (+2 halo) are built in LDS, then every thread gathers its 16
-// bytes and issues one 16-byte store; a wave writes 1 KiB contiguous.
-// Border descriptors (and odd rows when half) are written as zero.
+// One block = 64x16 pixel tile of one image of one pair (blockIdx.z = 2*pair +
+// image).  The 8-bit tile (+3 halo) goes to LDS once, du/dv (+2 halo) are built
+// in LDS, then every thread gathers its 16 bytes and issues one 16-byte store; a
+// wave writes 1 KiB contiguous.  Border descriptors (and odd rows when half)
+// are written as zero.
 // ---------------------------------------------------------------------------
 constexpr int TX = 64, TY = 16;
 
-__global__ __launch_bounds__(256) void k_descriptor(const uint8_t* __restrict__ I1,
-                                                    const uint8_t* __restrict__ I2, int pitch1,
-                                                    int pitch2, int W, int H, int half,
-                                                    uint8_t* __restrict__ desc1,
-                                                    uint8_t* __restrict__ desc2) {
+__global__ __launch_bounds__(256) void k_descriptor(DevImages img, int W, int H, int half,
+                                                    uint8_t* __restrict__ desc_all) {
     __shared__ uint8_t sI[TY + 6][TX + 8];
     __shared__ uint8_t sU[TY + 4][TX + 4];
     __shared__ uint8_t sV[TY + 4][TX + 4];
 
-    const uint8_t* I = blockIdx.z ? I2 : I1;
-    const int pitch = blockIdx.z ? pitch2 : pitch1;
-    uint8_t* desc = blockIdx.z ? desc2 : desc1;
+    const int pair = blockIdx.z >> 1, im = blockIdx.z & 1;
+    const uint8_t* __restrict__ I = img.I[im] + (size_t)pair * img.stride;
+    const int pitch = img.pitch;
+    uint8_t* __restrict__ desc = desc_all + (size_t)blockIdx.z * W * H * 16;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
     const int tid = threadIdx.y * TX + threadIdx.x;
 
@@ -88,9 +99,8 @@ __global__ __launch_bounds__(256) void k_descriptor(const uint8_t* __restrict__ 
         int r = i / (TX + 4), c = i - r * (TX + 4);
         // (r,c) in sU is image (y0-2+r, x0-2+c) == sI[r+1][c+1]
         int a0 = sI[r][c], a1 = sI[r][c + 1], a2 = sI[r][c + 2];
-        int b0 = sI[r + 1][c], b1 = sI[r + 1][c + 1], b2 = sI[r + 1][c + 2];
+        int b0 = sI[r + 1][c], b2 = sI[r + 1][c + 2];
         int c0 = sI[r + 2][c], c1 = sI[r + 2][c + 1], c2 = sI[r + 2][c + 2];
-        (void)b1;
         int Sl = a0 + 2 * b0 + c0, Sr = a2 + 2 * b2 + c2;          // vertical 1 2 1
         int Tl = a0 - c0, Tm = a1 - c1, Tr = a2 - c2;              // vertical 1 0 -1
         sU[r][c] = (uint8_t)sat_u8(((Sl - Sr) >> 2) + 128);        // horizontal 1 0 -1
@@ -130,10 +140,10 @@ __global__ __launch_bounds__(256) void k_descriptor(const uint8_t* __restrict__ 
 // E3+E4  support candidate matching
 //   Elas::computeMatchingDisparity   libelas/src/elas.cpp:322-445
 //   Elas::computeSupportMatches      libelas/src/elas.cpp:449-493
-// One wave per lattice candidate; lanes = disparities (up to 4 rounds of 64).
-// Energy = SAD over the 4 descriptors at (+-2,+-2) (64 bytes).  The reference
-// keeps best and second best while scanning d upwards with strict "<": that is
-// the smallest and second smallest of the keys (E<<16 | d).
+// One wave per lattice candidate (blockIdx.y = pair); lanes = disparities (up to
+// 4 rounds of 64).  Energy = SAD over the 4 descriptors at (+-2,+-2) (64 bytes).
+// The reference keeps best and second best while scanning d upwards with strict
+// "<": that is the smallest and second smallest of the keys (E<<16 | d).
 // ---------------------------------------------------------------------------
 struct SupportParams {
     int W, H, Wc, Hc, step;
@@ -186,12 +196,15 @@ __device__ __forceinline__ int support_match(const uint8_t* __restrict__ own,
     return -1;
 }
 
-__global__ __launch_bounds__(256) void k_support(const uint8_t* __restrict__ desc1,
-                                                 const uint8_t* __restrict__ desc2,
-                                                 int16_t* __restrict__ dcan, SupportParams P) {
+__global__ __launch_bounds__(256) void k_support(const uint8_t* __restrict__ desc_all,
+                                                 int16_t* __restrict__ dcan_all, SupportParams P) {
     const int cand = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
     const int lane = threadIdx.x & 63;
     if (cand >= P.Wc * P.Hc) return;
+    const int pair = blockIdx.y;
+    const size_t dsz = (size_t)P.W * P.H * 16;
+    const uint8_t* desc1 = desc_all + (size_t)(2 * pair) * dsz;
+    const uint8_t* desc2 = desc1 + dsz;
     const int vc = cand / P.Wc, uc = cand - vc * P.Wc;
     int out = 0;  // row 0 / column 0 stay at calloc's 0 (elas.cpp:464, 471-479)
     if (uc > 0 && vc > 0) {
@@ -204,7 +217,181 @@ __global__ __launch_bounds__(256) void k_support(const uint8_t* __restrict__ des
             if (d2 >= 0 && diff <= P.lr_threshold) out = d;
         }
     }
-    if (lane == 0) dcan[cand] = (int16_t)out;
+    if (lane == 0) dcan_all[(size_t)pair * P.Wc * P.Hc + cand] = (int16_t)out;
+}
+
+// ---------------------------------------------------------------------------
+// E8 + raster records, one thread per triangle of the group
+//   Elas::computeDisparityPlanes   libelas/src/elas.cpp:605-680
+//   Matrix::solve (Gauss-Jordan, full pivoting, eps 1e-20, ">=" pivot search)
+//                                  libelas/src/matrix.cpp:414-501
+//   triangle edges / validity      libelas/src/elas.cpp:1026-1072
+// fp64 with IEEE division and no contraction: the same operation sequence as
+// the reference's double code, so the float planes come out identical.
+// ---------------------------------------------------------------------------
+__device__ bool solve3(double A[3][3], double B[3]) {
+    bool used[3] = {false, false, false};
+    for (int it = 0; it < 3; it++) {
+        double big = 0.0;
+        int pr = 0, pc = 0;
+        for (int j = 0; j < 3; j++) {
+            if (used[j]) continue;
+            for (int k = 0; k < 3; k++)
+                if (!used[k] && fabs(A[j][k]) >= big) {  // ">=": the last maximum wins
+                    big = fabs(A[j][k]);
+                    pr = j;
+                    pc = k;
+                }
+        }
+        used[pc] = true;
+        if (pr != pc) {
+            for (int l = 0; l < 3; l++) {
+                double t = A[pr][l];
+                A[pr][l] = A[pc][l];
+                A[pc][l] = t;
+            }
+            double t = B[pr];
+            B[pr] = B[pc];
+            B[pc] = t;
+        }
+        if (fabs(A[pc][pc]) < 1e-20) return false;
+        const double inv = __ddiv_rn(1.0, A[pc][pc]);
+        A[pc][pc] = 1.0;
+        for (int l = 0; l < 3; l++) A[pc][l] = __dmul_rn(A[pc][l], inv);
+        B[pc] = __dmul_rn(B[pc], inv);
+        for (int r = 0; r < 3; r++) {
+            if (r == pc) continue;
+            const double f = A[r][pc];
+            A[r][pc] = 0.0;
+            for (int l = 0; l < 3; l++) A[r][l] = __dsub_rn(A[r][l], __dmul_rn(A[pc][l], f));
+            B[r] = __dsub_rn(B[r], __dmul_rn(B[pc], f));
+        }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_prior(GroupDev G, int total_tri) {
+    const int T = blockIdx.x * 256 + threadIdx.x;
+    if (T >= total_tri) return;
+    int first;
+    const int slot = tri_slot(G.hdr, T, &first);
+    const int pair = slot >> 1, side = slot & 1;
+    const int32_t* sup = G.support + 3 * (size_t)G.hdr->sup_off[pair];
+    const int32_t* c = G.tri + 3 * (size_t)T;
+    int32_t su[3], sv[3], sd[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int32_t* s = sup + 3 * c[k];
+        su[k] = s[0];
+        sv[k] = s[1];
+        sd[k] = s[2];
+    }
+    float pl[6];
+#pragma unroll
+    for (int rs = 0; rs < 2; rs++) {
+        double A[3][3], B[3];
+        for (int r = 0; r < 3; r++) {
+            A[r][0] = (double)(rs ? su[r] - sd[r] : su[r]);
+            A[r][1] = (double)sv[r];
+            A[r][2] = 1.0;
+            B[r] = (double)sd[r];
+        }
+        if (solve3(A, B)) {
+            pl[3 * rs + 0] = (float)B[0];
+            pl[3 * rs + 1] = (float)B[1];
+            pl[3 * rs + 2] = (float)B[2];
+        } else {
+            pl[3 * rs + 0] = pl[3 * rs + 1] = pl[3 * rs + 2] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) G.planes[6 * (size_t)T + k] = pl[k];
+
+    // corners sorted by u with the reference's exchange loop (not stable on ties)
+    float tu[3], tv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        tu[k] = side ? (float)(su[k] - sd[k]) : (float)su[k];
+        tv[k] = (float)sv[k];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int k = 0; k < j; k++)
+            if (tu[k] > tu[j]) {
+                float a = tu[j]; tu[j] = tu[k]; tu[k] = a;
+                float b = tv[j]; tv[j] = tv[k]; tv[k] = b;
+            }
+    TriRaster r;
+    const float Au = tu[0], Av = tv[0], Bu = tu[1], Bv = tv[1], Cu = tu[2], Cv = tv[2];
+    r.uA = (int32_t)Au;
+    r.uB = (int32_t)Bu;
+    r.uC = (int32_t)Cu;
+    float ABa = 0.f, ACa = 0.f, BCa = 0.f;
+    if (r.uA != r.uB) ABa = __fdiv_rn(__fsub_rn(Av, Bv), __fsub_rn(Au, Bu));
+    if (r.uA != r.uC) ACa = __fdiv_rn(__fsub_rn(Av, Cv), __fsub_rn(Au, Cu));
+    if (r.uB != r.uC) BCa = __fdiv_rn(__fsub_rn(Bv, Cv), __fsub_rn(Bu, Cu));
+    r.ABa = ABa;
+    r.ACa = ACa;
+    r.BCa = BCa;
+    r.ABb = __fsub_rn(Av, __fmul_rn(ABa, Au));
+    r.ACb = __fsub_rn(Av, __fmul_rn(ACa, Au));
+    r.BCb = __fsub_rn(Bv, __fmul_rn(BCa, Bu));
+    const float pa = side ? pl[3] : pl[0];
+    const float pd = side ? pl[0] : pl[3];
+    r.pa = pa;
+    r.pb = side ? pl[4] : pl[1];
+    r.pc = side ? pl[5] : pl[2];
+    r.valid = ((double)fabsf(pa) < 0.7 && (double)fabsf(pd) < 0.7) ? 1 : 0;
+    G.raster[T] = r;
+}
+
+// ---------------------------------------------------------------------------
+// E9  Elas::createGrid   libelas/src/elas.cpp:684-780
+// The grid is kept as one bit set of disparities per 20x20 cell (disp_max+1
+// bits).  k_grid_seed marks d-1..d+1 of every support point (left: cell of u,
+// right: cell of u-d); k_grid_dilate is the reference's flat 3x3 walk over cells
+// gw+1 .. cells-gw-2 (columns wrap, first/last rows stay empty).  Bit order =
+// ascending disparity = the reference's list order.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grid_seed(GroupDev G, int total_sup, int gw, int gh,
+                                                   int gwords, int grid_size, int disp_max) {
+    const int S = blockIdx.x * 256 + threadIdx.x;
+    if (S >= total_sup) return;
+    int pair = 0;
+    while (pair < G.hdr->npairs - 1 && S >= G.hdr->sup_off[pair + 1]) pair++;
+    const int32_t* s = G.support + 3 * (size_t)S;
+    const int xc = s[0], yc = s[1], dc = s[2];
+    const int y = (int)floorf(__fdiv_rn((float)yc, (float)grid_size));
+    const int xl = (int)floorf((float)(xc / grid_size));  // integer division first (elas.cpp:712)
+    const int xr = (int)floorf(__fdiv_rn((float)(xc - dc), (float)grid_size));
+    const int lo = dc - 1 > 0 ? dc - 1 : 0, hi = dc + 1 < disp_max ? dc + 1 : disp_max;
+    const size_t cells = (size_t)gw * gh;
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const int x = side ? xr : xl;
+        if (x < 0 || x >= gw || y < 0 || y >= gh) continue;
+        uint32_t* cell = G.seed + (((size_t)(2 * pair + side) * cells) + (size_t)y * gw + x) * gwords;
+        for (int dd = lo; dd <= hi; dd++) atomicOr(&cell[dd >> 5], 1u << (dd & 31));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_grid_dilate(GroupDev G, int slots, int gw, int gh,
+                                                     int gwords) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int cells = gw * gh;
+    const int per = cells * gwords;
+    if (i >= slots * per) return;
+    const int z = i / per, rem = i - z * per;
+    const int c = rem / gwords, w = rem - c * gwords;
+    uint32_t o = 0;
+    if (c >= gw + 1 && c <= cells - gw - 2) {
+        const uint32_t* base = G.seed + (size_t)z * per + w;
+        const int nb[9] = {-gw - 1, -gw, -gw + 1, -1, 0, 1, gw - 1, gw, gw + 1};
+#pragma unroll
+        for (int k = 0; k < 9; k++) o |= base[(size_t)(c + nb[k]) * gwords];
+    }
+    G.mask[i] = o;
 }
 
 // ---------------------------------------------------------------------------
@@ -213,27 +400,25 @@ __global__ __launch_bounds__(256) void k_support(const uint8_t* __restrict__ des
 // The reference walks triangles in list order and lets a later triangle
 // overwrite an earlier one on the few pixels both cover; findMatch's early-outs
 // depend on the pixel only, so "owner = highest triangle index covering the
-// pixel" is exact.  One wave per triangle, lanes = columns.
+// pixel" is exact.  One wave per triangle: 16 columns x 4 row phases per step.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_owner(const TriRaster* __restrict__ r1, int n1,
-                                               const TriRaster* __restrict__ r2, int n2, int W,
-                                               int H, int sub, int32_t* __restrict__ owner1,
-                                               int32_t* __restrict__ owner2) {
-    const int side = blockIdx.y;
-    const TriRaster* r = side ? r2 : r1;
-    const int n = side ? n2 : n1;
-    int32_t* owner = side ? owner2 : owner1;
-    const int t = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+__global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri, int W, int H, int sub) {
+    const int T = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
     const int lane = threadIdx.x & 63;
-    if (t >= n) return;
-    const TriRaster tr = r[t];
+    if (T >= total_tri) return;
+    int first;
+    const int slot = tri_slot(G.hdr, T, &first);
+    const int t = T - first;
+    int32_t* owner = G.owner + (size_t)slot * W * H;
+    const TriRaster tr = G.raster[T];
+    const int cl = lane & 15, rp = lane >> 4;
 #pragma unroll
     for (int part = 0; part < 2; part++) {
         const int lo = part ? tr.uB : tr.uA, hi = part ? tr.uC : tr.uB;
         if (lo == hi) continue;
         const float ea = part ? tr.BCa : tr.ABa, eb = part ? tr.BCb : tr.ABb;
         const int ulo = lo > 0 ? lo : 0, uhi = hi < W ? hi : W;
-        for (int u = ulo + lane; u < uhi; u += kWave) {
+        for (int u = ulo + cl; u < uhi; u += 16) {
             if (sub && (u & 1)) continue;
             const float fu = (float)u;
             const int v1 = f2u2i(__fadd_rn(__fmul_rn(tr.ACa, fu), tr.ACb));
@@ -241,7 +426,7 @@ __global__ __launch_bounds__(256) void k_owner(const TriRaster* __restrict__ r1,
             int va = v1 < v2 ? v1 : v2, vb = v1 < v2 ? v2 : v1;
             va = va > 0 ? va : 0;
             vb = vb < H ? vb : H;
-            for (int v = va; v < vb; v++) {
+            for (int v = va + rp; v < vb; v += 4) {
                 if (sub && (v & 1)) continue;
                 atomicMax(&owner[(size_t)v * W + u], t);
             }
@@ -251,31 +436,36 @@ __global__ __launch_bounds__(256) void k_owner(const TriRaster* __restrict__ r1,
 
 // ---------------------------------------------------------------------------
 // E11  Elas::findMatch + updatePosteriorMinimum   libelas/src/elas.cpp:784-955
-// One thread per disparity-map pixel; lanes are consecutive u, so for a common
-// candidate disparity the 64 descriptor loads of a wave are one contiguous
-// 1 KiB segment of the other image's descriptor row.
+// One thread per disparity-map pixel (blockIdx.z = 2*pair + side); lanes are
+// consecutive u, so for a common candidate disparity the 64 descriptor loads of
+// a wave are one contiguous 1 KiB segment of the other image's descriptor row.
 // ---------------------------------------------------------------------------
 struct MatchParams {
-    int W, H, DW, DH, gw, grid_size, sub;
+    int W, H, DW, DH, gw, gh, gwords, grid_size, sub;
     int disp_max, match_texture, plane_radius;
 };
 
-__global__ __launch_bounds__(256) void k_match(MatchArgs a, MatchParams P) {
-    const int side = blockIdx.z;
+__global__ __launch_bounds__(256) void k_match(GroupDev G, MatchParams P) {
+    const int z = blockIdx.z, pair = z >> 1, side = z & 1;
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= P.DW || y >= P.DH) return;
+    if (!G.hdr->active[pair]) return;
+    const size_t N = (size_t)P.W * P.H;
     const int u = P.sub ? 2 * x : x, v = P.sub ? 2 * y : y;
     float out = -10.f;
-    const int t = a.owner[side][(size_t)v * P.W + u];
+    const int t = G.owner[(size_t)z * N + (size_t)v * P.W + u];
     if (t >= 0 && u >= 2 && u < P.W - 2) {
         int line = v < P.H - 3 ? v : P.H - 3;
         line = line > 2 ? line : 2;
-        const uint4* own_line = reinterpret_cast<const uint4*>(a.desc[side]) + (size_t)line * P.W;
-        const uint4* oth_line = reinterpret_cast<const uint4*>(a.desc[1 - side]) + (size_t)line * P.W;
+        const uint4* own_line =
+            reinterpret_cast<const uint4*>(G.desc + (size_t)z * N * 16) + (size_t)line * P.W;
+        const uint4* oth_line =
+            reinterpret_cast<const uint4*>(G.desc + (size_t)(z ^ 1) * N * 16) + (size_t)line * P.W;
         const uint4 own = own_line[u];
         if ((int)texture16(own) >= P.match_texture) {
-            const TriRaster* tr = a.raster[side] + t;
+            const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
+            const TriRaster* tr = G.raster + tri0 + t;
             const float pa = tr->pa, pb = tr->pb, pc = tr->pc;
             const int valid = tr->valid;
             const int d_plane = (int)__fadd_rn(
@@ -285,18 +475,22 @@ __global__ __launch_bounds__(256) void k_match(MatchArgs a, MatchParams P) {
             int dhi = d_plane + P.plane_radius;
             dhi = dhi < P.disp_max ? dhi : P.disp_max;
             const int cell = (v / P.grid_size) * P.gw + u / P.grid_size;
-            const int cb = a.cell_off[side][cell], ce = a.cell_off[side][cell + 1];
-            const uint16_t* cd = a.cell_d[side];
+            const uint32_t* bits =
+                G.mask + ((size_t)z * P.gw * P.gh + cell) * P.gwords;
             int min_val = 10000, min_d = -1;
-            for (int i = cb; i < ce; i++) {
-                const int dc = cd[i];
-                if (dc < dlo || dc > dhi) {
-                    const int uw = side ? u + dc : u - dc;
-                    if (uw < 2 || uw >= P.W - 2) continue;
-                    const int val = (int)sad16(own, oth_line[uw]);
-                    if (val < min_val) {
-                        min_val = val;
-                        min_d = dc;
+            for (int w = 0; w < P.gwords; w++) {
+                uint32_t b = bits[w];
+                while (b) {
+                    const int dc = w * 32 + __builtin_ctz(b);
+                    b &= b - 1;
+                    if (dc < dlo || dc > dhi) {
+                        const int uw = side ? u + dc : u - dc;
+                        if (uw < 2 || uw >= P.W - 2) continue;
+                        const int val = (int)sad16(own, oth_line[uw]);
+                        if (val < min_val) {
+                            min_val = val;
+                            min_d = dc;
+                        }
                     }
                 }
             }
@@ -305,7 +499,7 @@ __global__ __launch_bounds__(256) void k_match(MatchArgs a, MatchParams P) {
                 if (uw < 2 || uw >= P.W - 2) continue;
                 int dd = dc - d_plane;
                 dd = dd < 0 ? -dd : dd;
-                const int val = (int)sad16(own, oth_line[uw]) + (valid ? a.P[dd] : 0);
+                const int val = (int)sad16(own, oth_line[uw]) + (valid ? G.P[dd] : 0);
                 if (val < min_val) {
                     min_val = val;
                     min_d = dc;
@@ -314,19 +508,24 @@ __global__ __launch_bounds__(256) void k_match(MatchArgs a, MatchParams P) {
             out = min_d >= 0 ? (float)min_d : -1.f;
         }
     }
-    a.D[side][(size_t)y * P.DW + x] = out;
+    G.Draw[(size_t)z * P.DW * P.DH + (size_t)y * P.DW + x] = out;
 }
 
 // ---------------------------------------------------------------------------
 // E12  Elas::leftRightConsistencyCheck   libelas/src/elas.cpp:1122-1204
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lr(const float* __restrict__ R1,
-                                            const float* __restrict__ R2, float* __restrict__ D1,
-                                            float* __restrict__ D2, int DW, int DH, int sub,
+__global__ __launch_bounds__(256) void k_lr(GroupDev G, DevMaps out, int DW, int DH, int sub,
                                             float lr_threshold) {
+    const int pair = blockIdx.z;
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= DW || y >= DH) return;
+    if (!G.hdr->active[pair]) return;   // outputs of a failed pair stay untouched
+    const size_t DN = (size_t)DW * DH;
+    const float* R1 = G.Draw + (size_t)(2 * pair) * DN;
+    const float* R2 = R1 + DN;
+    float* D1 = out.D[0] + (size_t)pair * out.stride;
+    float* D2 = out.D[1] + (size_t)pair * out.stride;
     const size_t rowo = (size_t)y * DW;
     const float d1 = R1[rowo + x], d2 = R2[rowo + x];
     const float fx = (float)x;
@@ -339,6 +538,13 @@ __global__ __launch_bounds__(256) void k_lr(const float* __restrict__ R1,
         if (!(fabsf(R1[rowo + (int)uw2] - d2) > lr_threshold)) o2 = d2;
     D1[rowo + x] = o1;
     D2[rowo + x] = o2;
+}
+
+// map of post-processing slot z = pair*nside + side
+__device__ __forceinline__ float* post_map(const DevMaps& m, int z, int nside, int* pair) {
+    const int p = z / nside, s = z - p * nside;
+    *pair = p;
+    return m.D[s] + (size_t)p * m.stride;
 }
 
 // ---------------------------------------------------------------------------
@@ -354,8 +560,9 @@ __global__ __launch_bounds__(256) void k_lr(const float* __restrict__ R1,
 //                 of the run's first pixel, RL[first] = run length
 //   k_seg_link  : unions between runs -- across wave borders, and to the row
 //                 above, skipping a vertical contact when the pixel to the left
-//                 already makes the same union
-//   k_seg_count : one atomicAdd of the run length per run; roots compressed
+//                 already makes the same union; finds halve paths as they go
+//   k_seg_count : one atomicAdd of the run length per run, skipped once the
+//                 component is known to be large enough; roots compressed
 //   k_seg_mask  : pixels of components below speckle_size become -10
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int uf_find(const int32_t* L, int x) {
@@ -367,10 +574,23 @@ __device__ __forceinline__ int uf_find(const int32_t* L, int x) {
     return x;
 }
 
+// find with path halving; stale or lost shortcuts are harmless because every
+// value ever stored in L[x] is an ancestor of x
+__device__ __forceinline__ int uf_find_halve(int32_t* L, int x) {
+    int p = L[x];
+    while (p != x) {
+        const int gp = L[p];
+        if (gp != p) L[x] = gp;
+        x = p;
+        p = gp;
+    }
+    return x;
+}
+
 __device__ __forceinline__ void uf_union(int32_t* L, int a, int b) {
     for (;;) {
-        a = uf_find(L, a);
-        b = uf_find(L, b);
+        a = uf_find_halve(L, a);
+        b = uf_find_halve(L, b);
         if (a == b) return;
         if (a > b) {
             int t = a;
@@ -387,14 +607,15 @@ __device__ __forceinline__ bool seg_joined(float a, float b, float thr) {
     return a >= 0 && b >= 0 && fabsf(a - b) <= thr;
 }
 
-__global__ __launch_bounds__(256) void k_seg_runs(const float* __restrict__ D,
-                                                  int32_t* __restrict__ L,
-                                                  int32_t* __restrict__ RL,
-                                                  int32_t* __restrict__ cnt, int DW, int DH,
-                                                  float thr) {
+__global__ __launch_bounds__(256) void k_seg_runs(GroupDev G, DevMaps m, PostScratch S, int nside,
+                                                  int DW, int DH, float thr) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;   // wave-uniform
     if (y >= DH) return;
+    int pair;
+    const float* D = post_map(m, blockIdx.z, nside, &pair);
+    if (!G.hdr->active[pair]) return;
+    const size_t zo = (size_t)blockIdx.z * DW * DH;
     const int lane = threadIdx.x;
     const int i = y * DW + x;
     const bool inside = x < DW;
@@ -417,17 +638,20 @@ __global__ __launch_bounds__(256) void k_seg_runs(const float* __restrict__ D,
             len = stops ? __ffsll((long long)stops) : (kWave - lane);
         }
     }
-    L[i] = label;
-    RL[i] = len;
-    cnt[i] = 0;
+    S.labels[zo + i] = label;
+    S.runlen[zo + i] = len;
+    S.counts[zo + i] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_seg_link(const float* __restrict__ D,
-                                                  int32_t* __restrict__ L, int DW, int DH,
-                                                  float thr) {
+__global__ __launch_bounds__(256) void k_seg_link(GroupDev G, DevMaps m, PostScratch S, int nside,
+                                                  int DW, int DH, float thr) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= DW || y >= DH) return;
+    int pair;
+    const float* D = post_map(m, blockIdx.z, nside, &pair);
+    if (!G.hdr->active[pair]) return;
+    int32_t* L = S.labels + (size_t)blockIdx.z * DW * DH;
     const int i = y * DW + x;
     const float d = D[i];
     if (!(d >= 0)) return;
@@ -449,30 +673,37 @@ __global__ __launch_bounds__(256) void k_seg_link(const float* __restrict__ D,
     }
 }
 
-__global__ __launch_bounds__(256) void k_seg_count(int32_t* __restrict__ L,
-                                                   const int32_t* __restrict__ RL,
-                                                   int32_t* __restrict__ cnt, int n) {
+__global__ __launch_bounds__(256) void k_seg_count(GroupDev G, PostScratch S, int nside, int n,
+                                                   int min_size) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int len = RL[i];
+    if (!G.hdr->active[blockIdx.y / nside]) return;
+    const size_t zo = (size_t)blockIdx.y * n;
+    const int len = S.runlen[zo + i];
     if (len > 0) {
+        int32_t* L = S.labels + zo;
         const int root = uf_find(L, i);
         L[i] = root;
-        atomicAdd(&cnt[root], len);
+        int32_t* c = S.counts + zo + root;
+        // only "below speckle_size or not" is ever asked of a count
+        if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < min_size)
+            atomicAdd(c, len);
     }
 }
 
-__global__ __launch_bounds__(256) void k_seg_mask(float* __restrict__ D,
-                                                  const int32_t* __restrict__ L,
-                                                  const int32_t* __restrict__ cnt, int n,
-                                                  int min_size) {
+__global__ __launch_bounds__(256) void k_seg_mask(GroupDev G, DevMaps m, PostScratch S, int nside,
+                                                  int n, int min_size) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int s = L[i];
+    int pair;
+    float* D = post_map(m, blockIdx.y, nside, &pair);
+    if (!G.hdr->active[pair]) return;
+    const size_t zo = (size_t)blockIdx.y * n;
+    const int s = S.labels[zo + i];
     if (s < 0) {
         // an invalid pixel is a segment of one pixel (elas.cpp:1244-1317)
         if (1 < min_size) D[i] = -10.f;
-    } else if (cnt[L[s]] < min_size) {
+    } else if (S.counts[zo + S.labels[zo + s]] < min_size) {
         D[i] = -10.f;
     }
 }
@@ -491,12 +722,17 @@ __device__ __forceinline__ float gap_value(float d1, float d2) {
 }
 
 template <bool kCols>
-__global__ __launch_bounds__(256) void k_gap_local(const float* __restrict__ in,
-                                                   float* __restrict__ out, int DW, int DH,
-                                                   int gap) {
+__global__ __launch_bounds__(256) void k_gap_local(GroupDev G, DevMaps m, PostScratch S, int nside,
+                                                   int DW, int DH, int gap) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= DW || y >= DH) return;
+    int pair;
+    float* D = post_map(m, blockIdx.z, nside, &pair);
+    if (!G.hdr->active[pair]) return;
+    float* tmp = S.tmp + (size_t)blockIdx.z * DW * DH;
+    const float* in = kCols ? tmp : D;     // rows: D -> tmp, columns: tmp -> D
+    float* out = kCols ? D : tmp;
     const int i = y * DW + x;
     const int stride = kCols ? DW : 1;
     const int pos = kCols ? y : x, len = kCols ? DH : DW;
@@ -522,10 +758,14 @@ __global__ __launch_bounds__(256) void k_gap_local(const float* __restrict__ in,
 
 // general per-line version (any gap width, add_corners extrapolation), in place
 template <bool kCols>
-__global__ void k_gap_lines(float* __restrict__ D, int DW, int DH, int gap, int add_corners) {
+__global__ void k_gap_lines(GroupDev G, DevMaps m, int nside, int DW, int DH, int gap,
+                            int add_corners) {
     const int line = blockIdx.x * blockDim.x + threadIdx.x;
     const int nlines = kCols ? DW : DH;
     if (line >= nlines) return;
+    int pair;
+    float* D = post_map(m, blockIdx.y, nside, &pair);
+    if (!G.hdr->active[pair]) return;
     const int len = kCols ? DH : DW;
     const int stride = kCols ? DW : 1;
     float* base = D + (kCols ? line : (size_t)line * DW);
@@ -570,26 +810,32 @@ __global__ void k_gap_lines(float* __restrict__ D, int DW, int DH, int gap, int 
 // the 8-tap branch first adds slot j and j+4, then sums ((l0+l1)+l2)+l3.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float am_weight(float val, float centre) {
-    const float m = __uint_as_float(__float_as_uint(__fsub_rn(val, centre)) & 0x4F000000u);
-    const float w = __fsub_rn(4.0f, m);
+    const float mm = __uint_as_float(__float_as_uint(__fsub_rn(val, centre)) & 0x4F000000u);
+    const float w = __fsub_rn(4.0f, mm);
     return w > 0.0f ? w : 0.0f;
 }
 
 template <bool kCols, int kTaps>
-__global__ __launch_bounds__(256) void k_adaptive_mean(const float* in, const float* keep,
-                                                       float* out, int DW, int DH) {
-    // in   : filter input (negative values read as -10)
-    // keep : value written where the filter does not fire
+__global__ __launch_bounds__(256) void k_adaptive_mean(GroupDev G, DevMaps m, PostScratch S,
+                                                       int nside, int DW, int DH) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= DW || y >= DH) return;
+    int pair;
+    float* D = post_map(m, blockIdx.z, nside, &pair);
+    if (!G.hdr->active[pair]) return;
+    float* tmp = S.tmp + (size_t)blockIdx.z * DW * DH;
+    // horizontal: in = D (negatives read as -10), out = tmp
+    // vertical  : in = tmp, value kept where the filter does not fire = D, out = D
+    const float* in = kCols ? tmp : D;
+    float* out = kCols ? D : tmp;
     const int i = y * DW + x;
     constexpr int back = kTaps == 8 ? 3 : 1;      // centre = newest - back
     constexpr int lead = kTaps - 1;
     const int stride = kCols ? DW : 1;
     const int pos = kCols ? y : x, len = kCols ? DH : DW;
     const int other = kCols ? x : y, olen = kCols ? DW : DH;
-    float res = keep[i];
+    float res = D[i];
     if (!kCols && res < 0) res = -10.f;  // D_copy/D_tmp initialisation (elas.cpp:1553-1560)
     // lines 3..olen-4; centres lead-back .. len-1-back
     if (other >= 3 && other < olen - 3 && pos >= lead - back && pos <= len - 1 - back) {
@@ -597,20 +843,13 @@ __global__ __launch_bounds__(256) void k_adaptive_mean(const float* in, const fl
         float ring[kTaps];
 #pragma unroll
         for (int k = 0; k < kTaps; k++) {
-            const int p = first + k;
-            float t = in[i + (p - pos) * stride];
+            float t = in[i + (first + k - pos) * stride];
             if (!kCols && t < 0) t = -10.f;
             ring[k] = t;
         }
         float centre = in[i];
         if (!kCols && centre < 0) centre = -10.f;
         // slot s holds the tap whose position % kTaps == s
-        float wl[4], fl[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            wl[j] = 0.f;
-            fl[j] = 0.f;
-        }
         float ws[kTaps], fs[kTaps];
 #pragma unroll
         for (int s = 0; s < kTaps; s++) {
@@ -622,11 +861,12 @@ __global__ __launch_bounds__(256) void k_adaptive_mean(const float* in, const fl
             ws[s] = w;
             fs[s] = __fmul_rn(t, w);
         }
+        float wl[4], fl[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (kTaps == 8) {
-                wl[j] = __fadd_rn(ws[j], ws[j + 4]);
-                fl[j] = __fadd_rn(fs[j], fs[j + 4]);
+                wl[j] = __fadd_rn(ws[j], ws[j + kTaps / 2]);
+                fl[j] = __fadd_rn(fs[j], fs[j + kTaps / 2]);
             } else {
                 wl[j] = ws[j];
                 fl[j] = fs[j];
@@ -644,25 +884,31 @@ __global__ __launch_bounds__(256) void k_adaptive_mean(const float* in, const fl
 
 // ---------------------------------------------------------------------------
 // E16  Elas::median   libelas/src/elas.cpp:1758-1838 (separable 7-tap)
+// horizontal: D -> tmp (tmp is calloc'ed in the reference: 0 outside the
+// interior); vertical: gates on D, reads tmp, writes D.
 // ---------------------------------------------------------------------------
 template <bool kCols>
-__global__ __launch_bounds__(256) void k_median(const float* gate, const float* in, float* out,
+__global__ __launch_bounds__(256) void k_median(GroupDev G, DevMaps m, PostScratch S, int nside,
                                                 int DW, int DH) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= DW || y >= DH) return;
+    int pair;
+    float* D = post_map(m, blockIdx.z, nside, &pair);
+    if (!G.hdr->active[pair]) return;
+    float* tmp = S.tmp + (size_t)blockIdx.z * DW * DH;
+    const float* in = kCols ? tmp : D;
+    float* out = kCols ? D : tmp;
     const int i = y * DW + x;
     const bool interior = x >= 3 && x < DW - 3 && y >= 3 && y < DH - 3;
-    // first pass writes D_temp (calloc'ed: 0 outside the interior); second pass
-    // leaves D untouched outside the interior
-    float res = kCols ? gate[i] : 0.f;
+    const float gate = D[i];
+    float res = kCols ? gate : 0.f;
     if (interior) {
-        if (gate[i] >= 0) {
+        if (gate >= 0) {
             const int stride = kCols ? DW : 1;
             float v[7];
 #pragma unroll
             for (int k = 0; k < 7; k++) v[k] = in[i + (k - 3) * stride];
-            // insertion sort of 7 values
             for (int a = 1; a < 7; a++) {
                 float key = v[a];
                 int b = a - 1;
@@ -674,7 +920,7 @@ __global__ __launch_bounds__(256) void k_median(const float* gate, const float* 
             }
             res = v[3];
         } else {
-            res = gate[i];
+            res = gate;
         }
     }
     out[i] = res;
@@ -704,103 +950,108 @@ struct Timed {
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t W, int32_t H,
-                       int32_t half, uint8_t* desc1, uint8_t* desc2) {
-    dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, 2), block(TX, 4);
-    LAUNCH("k_descriptor", k_descriptor, grid, block, img.I[0], img.I[1], img.pitch[0],
-           img.pitch[1], W, H, half, desc1, desc2);
+void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t g, int32_t W, int32_t H,
+                       int32_t half, uint8_t* desc) {
+    dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, 2 * g), block(TX, 4);
+    LAUNCH("k_descriptor", k_descriptor, grid, block, img, W, H, half, desc);
 }
 
-void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d,
-                    const uint8_t* desc1, const uint8_t* desc2, int16_t* dcan) {
+void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                    const uint8_t* desc, int16_t* dcan) {
     SupportParams P;
     P.W = d.W; P.H = d.H; P.Wc = d.Wc; P.Hc = d.Hc; P.step = d.step;
     P.disp_min = p.disp_min; P.disp_max = p.disp_max;
     P.support_texture = p.support_texture; P.lr_threshold = p.lr_threshold;
     P.support_threshold = p.support_threshold;
     const int cands = d.Wc * d.Hc;
-    LAUNCH("k_support", k_support, dim3((cands + 3) / 4), dim3(256), desc1, desc2, dcan, P);
+    LAUNCH("k_support", k_support, dim3((cands + 3) / 4, g), dim3(256), desc, dcan, P);
 }
 
-void launch_owner(const LaunchCtx& cx, const Dims& d, const TriRaster* r1, int32_t n1,
-                  const TriRaster* r2, int32_t n2, int32_t subsampling, int32_t* owner1,
-                  int32_t* owner2) {
+void launch_prior(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                  int32_t total_sup, int32_t total_tri, const GroupDev& G) {
     hipStream_t s = (hipStream_t)cx.stream;
-    const size_t bytes = (size_t)d.W * d.H * sizeof(int32_t);
-    if (owner2 == owner1 + (size_t)d.W * d.H) {
-        (void)hipMemsetAsync(owner1, 0xFF, 2 * bytes, s);
-    } else {
-        (void)hipMemsetAsync(owner1, 0xFF, bytes, s);
-        (void)hipMemsetAsync(owner2, 0xFF, bytes, s);
-    }
-    const int nmax = n1 > n2 ? n1 : n2;
-    if (nmax == 0) return;
-    LAUNCH("k_owner", k_owner, dim3((nmax + 3) / 4, 2), dim3(256), r1, n1, r2, n2, d.W, d.H,
-           subsampling, owner1, owner2);
+    const int cells = d.gw * d.gh;
+    const size_t words = (size_t)2 * g * cells * d.gwords;
+    (void)hipMemsetAsync(G.seed, 0, words * sizeof(uint32_t), s);
+    if (total_tri > 0) LAUNCH("k_prior", k_prior, dim3((total_tri + 255) / 256), dim3(256), G, total_tri);
+    if (total_sup > 0)
+        LAUNCH("k_grid_seed", k_grid_seed, dim3((total_sup + 255) / 256), dim3(256), G, total_sup,
+               d.gw, d.gh, d.gwords, p.grid_size, p.disp_max);
+    LAUNCH("k_grid_dilate", k_grid_dilate, dim3((unsigned)((words + 255) / 256)), dim3(256), G,
+           2 * g, d.gw, d.gh, d.gwords);
 }
 
-void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d,
-                  const MatchArgs& a) {
+void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                  int32_t total_tri, const GroupDev& G) {
+    hipStream_t s = (hipStream_t)cx.stream;
+    (void)hipMemsetAsync(G.owner, 0xFF, (size_t)2 * g * d.W * d.H * sizeof(int32_t), s);
+    if (total_tri == 0) return;
+    LAUNCH("k_owner", k_owner, dim3((total_tri + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
+           p.subsampling);
+}
+
+void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                  const GroupDev& G) {
     MatchParams P;
-    P.W = d.W; P.H = d.H; P.DW = d.DW; P.DH = d.DH; P.gw = d.gw; P.grid_size = p.grid_size;
-    P.sub = p.subsampling; P.disp_max = p.disp_max; P.match_texture = p.match_texture;
-    P.plane_radius = a.plane_radius;
-    LAUNCH("k_match", k_match, grid2d(d.DW, d.DH, 2), dim3(64, 4), a, P);
+    P.W = d.W; P.H = d.H; P.DW = d.DW; P.DH = d.DH; P.gw = d.gw; P.gh = d.gh; P.gwords = d.gwords;
+    P.grid_size = p.grid_size; P.sub = p.subsampling; P.disp_max = p.disp_max;
+    P.match_texture = p.match_texture; P.plane_radius = G.plane_radius;
+    LAUNCH("k_match", k_match, grid2d(d.DW, d.DH, 2 * g), dim3(64, 4), G, P);
 }
 
-void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, const float* D1raw,
-               const float* D2raw, float* D1, float* D2) {
-    LAUNCH("k_lr", k_lr, grid2d(d.DW, d.DH), dim3(64, 4), D1raw, D2raw, D1, D2, d.DW, d.DH,
-           p.subsampling, (float)p.lr_threshold);
+void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+               const GroupDev& G, const DevMaps& out) {
+    LAUNCH("k_lr", k_lr, grid2d(d.DW, d.DH, g), dim3(64, 4), G, out, d.DW, d.DH, p.subsampling,
+           (float)p.lr_threshold);
 }
 
-void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D,
-                     int32_t* labels, int32_t* runlen, int32_t* counts) {
-    const int n = d.DW * d.DH;
+void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                     int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& S) {
+    const int n = d.DW * d.DH, z = g * nside;
     int min_size = p.speckle_size;
     if (p.subsampling) min_size = (int)(sqrtf((float)p.speckle_size) * 2);  // elas.cpp:1218
-    const dim3 lin((n + 255) / 256), b256(256), g2 = grid2d(d.DW, d.DH), b2(64, 4);
-    LAUNCH("k_seg_runs", k_seg_runs, g2, b2, D, labels, runlen, counts, d.DW, d.DH,
-           p.speckle_sim_threshold);
-    LAUNCH("k_seg_link", k_seg_link, g2, b2, D, labels, d.DW, d.DH, p.speckle_sim_threshold);
-    LAUNCH("k_seg_count", k_seg_count, lin, b256, labels, runlen, counts, n);
-    LAUNCH("k_seg_mask", k_seg_mask, lin, b256, D, labels, counts, n, min_size);
+    const dim3 lin((n + 255) / 256, z), b256(256), g2 = grid2d(d.DW, d.DH, z), b2(64, 4);
+    LAUNCH("k_seg_runs", k_seg_runs, g2, b2, G, out, S, nside, d.DW, d.DH, p.speckle_sim_threshold);
+    LAUNCH("k_seg_link", k_seg_link, g2, b2, G, out, S, nside, d.DW, d.DH, p.speckle_sim_threshold);
+    LAUNCH("k_seg_count", k_seg_count, lin, b256, G, S, nside, n, min_size);
+    LAUNCH("k_seg_mask", k_seg_mask, lin, b256, G, out, S, nside, n, min_size);
 }
 
-void launch_gap(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D,
-                float* tmp) {
+void launch_gap(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& S) {
     int gap = p.ipol_gap_width;
     if (p.subsampling) gap = p.ipol_gap_width / 2 + 1;  // elas.cpp:1340
+    const int z = g * nside;
     if (gap <= 16 && !p.add_corners) {
-        LAUNCH("k_gap_rows", k_gap_local<false>, grid2d(d.DW, d.DH), dim3(64, 4), D, tmp, d.DW, d.DH,
-               gap);
-        LAUNCH("k_gap_cols", k_gap_local<true>, grid2d(d.DW, d.DH), dim3(64, 4), tmp, D, d.DW, d.DH,
-               gap);
+        LAUNCH("k_gap_rows", k_gap_local<false>, grid2d(d.DW, d.DH, z), dim3(64, 4), G, out, S, nside,
+               d.DW, d.DH, gap);
+        LAUNCH("k_gap_cols", k_gap_local<true>, grid2d(d.DW, d.DH, z), dim3(64, 4), G, out, S, nside,
+               d.DW, d.DH, gap);
     } else {
-        LAUNCH("k_gap_rows_seq", k_gap_lines<false>, dim3((d.DH + 63) / 64), dim3(64), D, d.DW, d.DH,
-               gap, p.add_corners);
-        LAUNCH("k_gap_cols_seq", k_gap_lines<true>, dim3((d.DW + 63) / 64), dim3(64), D, d.DW, d.DH,
-               gap, p.add_corners);
+        LAUNCH("k_gap_rows_seq", k_gap_lines<false>, dim3((d.DH + 63) / 64, z), dim3(64), G, out,
+               nside, d.DW, d.DH, gap, p.add_corners);
+        LAUNCH("k_gap_cols_seq", k_gap_lines<true>, dim3((d.DW + 63) / 64, z), dim3(64), G, out,
+               nside, d.DW, d.DH, gap, p.add_corners);
     }
 }
 
-void launch_adaptive_mean(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D,
-                          float* tmp) {
-    const dim3 g = grid2d(d.DW, d.DH), b(64, 4);
+void launch_adaptive_mean(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                          int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& S) {
+    const dim3 gr = grid2d(d.DW, d.DH, g * nside), b(64, 4);
     if (p.subsampling) {
-        LAUNCH("k_mean_h", (k_adaptive_mean<false, 4>), g, b, D, D, tmp, d.DW, d.DH);
-        LAUNCH("k_mean_v", (k_adaptive_mean<true, 4>), g, b, tmp, D, D, d.DW, d.DH);
+        LAUNCH("k_mean_h", (k_adaptive_mean<false, 4>), gr, b, G, out, S, nside, d.DW, d.DH);
+        LAUNCH("k_mean_v", (k_adaptive_mean<true, 4>), gr, b, G, out, S, nside, d.DW, d.DH);
     } else {
-        LAUNCH("k_mean_h", (k_adaptive_mean<false, 8>), g, b, D, D, tmp, d.DW, d.DH);
-        LAUNCH("k_mean_v", (k_adaptive_mean<true, 8>), g, b, tmp, D, D, d.DW, d.DH);
+        LAUNCH("k_mean_h", (k_adaptive_mean<false, 8>), gr, b, G, out, S, nside, d.DW, d.DH);
+        LAUNCH("k_mean_v", (k_adaptive_mean<true, 8>), gr, b, G, out, S, nside, d.DW, d.DH);
     }
 }
 
-void launch_median(const LaunchCtx& cx, const Dims& d, float* D, float* tmp) {
-    const dim3 g = grid2d(d.DW, d.DH), b(64, 4);
-    // horizontal pass D -> tmp, vertical pass gates on D, reads tmp, writes D
-    LAUNCH("k_median_h", k_median<false>, g, b, D, D, tmp, d.DW, d.DH);
-    LAUNCH("k_median_v", k_median<true>, g, b, D, tmp, D, d.DW, d.DH);
+void launch_median(const LaunchCtx& cx, const Dims& d, int32_t g, int32_t nside, const GroupDev& G,
+                   const DevMaps& out, const PostScratch& S) {
+    const dim3 gr = grid2d(d.DW, d.DH, g * nside), b(64, 4);
+    LAUNCH("k_median_h", k_median<false>, gr, b, G, out, S, nside, d.DW, d.DH);
+    LAUNCH("k_median_v", k_median<true>, gr, b, G, out, S, nside, d.DW, d.DH);
 }
 
 }  // namespace svh

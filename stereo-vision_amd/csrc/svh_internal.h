@@ -19,12 +19,27 @@ struct Dims {
     int32_t step;        // candidate lattice step (elas.cpp:453-457)
     int32_t Wc, Hc;      // candidate lattice (elas.cpp:460-463)
     int32_t gw, gh;      // disparity grid (elas.cpp:98-99)
+    int32_t gwords;      // 32-bit words of one grid cell's disparity bit set
 };
 Dims make_dims(const svh_elas_params& p, int32_t W, int32_t H);
 
-// One rasterisation record per triangle and image side, prepared on the host
-// with the reference's float arithmetic (elas.cpp:1026-1072) so that span
-// boundaries cannot differ; the device only evaluates a*u+b per column.
+// A lane processes a GROUP of up to kMaxGroup independent pairs per kernel
+// launch (blockIdx.z / .y = pair): per-launch work is large enough to fill 256
+// CUs and launch gaps are paid once per group, not once per pair.
+constexpr int kMaxGroup = 16;
+
+// Per-pair header, uploaded with the support points and triangle lists after
+// the host stage.  Triangles of all pairs and both sides are packed in one
+// array; tri_end[] are running ends in (pair, side) order.
+struct GroupHdr {
+    int32_t npairs;
+    int32_t active[kMaxGroup];          // 0: fewer than 3 support points -> outputs untouched
+    int32_t sup_off[kMaxGroup + 1];     // support point offsets (points, not ints)
+    int32_t tri_end[2 * kMaxGroup];     // cumulative triangle count after (pair, side)
+};
+
+// One rasterisation record per triangle and image side, computed on the device
+// by k_prior with the reference's arithmetic (elas.cpp:605-680, 1026-1072).
 struct TriRaster {
     int32_t uA, uB, uC;        // (int32)A_u, (int32)B_u, (int32)C_u
     float ACa, ACb;            // long edge
@@ -34,26 +49,21 @@ struct TriRaster {
     int32_t valid;             // |plane_a|<0.7 && |plane_d|<0.7
 };
 
-// Host-side result of stages E4(second half)..E9 for one pair.
+// Host-side result of stages E4(second half)..E7 for one pair.
 struct HostPrior {
     std::vector<int32_t> support;            // n x (u,v,d)
     std::vector<int32_t> tri[2];             // n x 3
-    std::vector<float> planes[2];            // n x 6 (t1a,t1b,t1c,t2a,t2b,t2c)
-    std::vector<TriRaster> raster[2];
-    std::vector<int32_t> cell_off[2];        // cells+1 prefix offsets into cell_d
-    std::vector<uint16_t> cell_d[2];         // ascending disparities per cell
-    std::vector<int32_t> P;                  // prior table (elas.cpp:984-992)
-    int32_t plane_radius;
 };
 
 // E5/E6 + list + corners (elas.cpp:174-318, 495-523); dcan is modified in place
 void support_from_candidates(const svh_elas_params& p, const Dims& d, int16_t* dcan,
                              std::vector<int32_t>& support);
-// E7 (both sides), E8, raster records, E9, prior table.  Returns false when a
-// triangulation fails.
-bool build_prior(const svh_elas_params& p, const Dims& d, HostPrior& hp);
-// reference-layout grid (int32 [gh][gw][disp_max+2]) for the stage tap
-void expand_grid(const svh_elas_params& p, const Dims& d, const HostPrior& hp, int side,
+// E7, both sides.  Returns false when a triangulation fails.
+bool triangulate_support(HostPrior& hp);
+// prior table + plane radius (elas.cpp:984-993)
+void prior_table(const svh_elas_params& p, std::vector<int32_t>& P, int32_t* plane_radius);
+// reference-layout grid (int32 [gh][gw][disp_max+2]) from the device bit sets, for the tap
+void expand_grid(const svh_elas_params& p, const Dims& d, const uint32_t* mask,
                  std::vector<int32_t>& grid);
 
 int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap);
@@ -70,37 +80,64 @@ struct LaunchCtx {
     void* stream;
     Profiler* prof;
 };
+
+// images of a group: image k of pair j starts at I[k] + j*stride, rows pitch apart
 struct DevImages {
-    const uint8_t* I[2];   // left, right
-    int32_t pitch[2];
+    const uint8_t* I[2];
+    size_t stride;
+    int32_t pitch;
+};
+// disparity maps of a group: map k of pair j starts at D[k] + j*stride (floats)
+struct DevMaps {
+    float* D[2];
+    size_t stride;
 };
 
-void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t W, int32_t H, int32_t half,
-                       uint8_t* desc1, uint8_t* desc2);
-void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, const uint8_t* desc1,
-                    const uint8_t* desc2, int16_t* dcan);
-void launch_owner(const LaunchCtx& cx, const Dims& d, const TriRaster* r1, int32_t n1, const TriRaster* r2,
-                  int32_t n2, int32_t subsampling, int32_t* owner1, int32_t* owner2);
-struct MatchArgs {
-    const uint8_t* desc[2];
-    const int32_t* owner[2];
-    const TriRaster* raster[2];
-    const int32_t* cell_off[2];
-    const uint16_t* cell_d[2];
-    const int32_t* P;          // device prior table
-    float* D[2];
+// everything phase B needs, all device pointers
+struct GroupDev {
+    const GroupHdr* hdr;       // device copy
+    const int32_t* support;    // packed (u,v,d)
+    const int32_t* tri;        // packed corner triples, (pair, side) order
+    const int32_t* P;          // prior table
+    TriRaster* raster;         // packed like tri
+    float* planes;             // 6 floats per triangle (t1a..t2c), packed like tri
+    uint32_t* seed;            // [g][2][cells][gwords]
+    uint32_t* mask;            // [g][2][cells][gwords] dilated
+    const uint8_t* desc;       // [g][2][N*16]
+    int32_t* owner;            // [g][2][N]
+    float* Draw;               // [g][2][DN]
     int32_t plane_radius;
 };
-void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, const MatchArgs& a);
-void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, const float* D1raw,
-               const float* D2raw, float* D1, float* D2);
-// speckle removal: labels/runlen/counts are scratch of DW*DH int32 each
-void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D,
-                     int32_t* labels, int32_t* runlen, int32_t* counts);
-void launch_gap(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D, float* tmp);
-void launch_adaptive_mean(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, float* D,
-                          float* tmp);
-void launch_median(const LaunchCtx& cx, const Dims& d, float* D, float* tmp);
+
+void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t g, int32_t W, int32_t H,
+                       int32_t half, uint8_t* desc);
+void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                    const uint8_t* desc, int16_t* dcan);
+// planes + raster records + grid bit sets for the whole group
+void launch_prior(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                  int32_t total_sup, int32_t total_tri, const GroupDev& G);
+void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                  int32_t total_tri, const GroupDev& G);
+void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                  const GroupDev& G);
+void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+               const GroupDev& G, const DevMaps& out);
+// post-processing of nside maps per pair, in place on `out`; scratch arrays are
+// [g][nside][DN]
+struct PostScratch {
+    float* tmp;
+    int32_t* labels;
+    int32_t* runlen;
+    int32_t* counts;
+};
+void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                     int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& s);
+void launch_gap(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& s);
+void launch_adaptive_mean(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                          int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& s);
+void launch_median(const LaunchCtx& cx, const Dims& d, int32_t g, int32_t nside, const GroupDev& G,
+                   const DevMaps& out, const PostScratch& s);
 
 }  // namespace svh
 #endif

@@ -195,7 +195,13 @@ class Elas:
 
 
 def set_lanes(n):
+    """pipeline lanes (HIP stream + host worker each) per device"""
     return lib().svh_elas_set_lanes(n)
+
+
+def set_group(n):
+    """pairs pushed through each kernel launch by one lane (1..16)"""
+    return lib().svh_elas_set_group(n)
 
 
 def device_count():
