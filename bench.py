@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="pairs per step and GPU")
     ap.add_argument("--lanes", type=int, default=0, help="pipeline lanes per GPU (0 = auto)")
     ap.add_argument("--group", type=int, default=4, help="pairs per kernel launch (1..16)")
+    ap.add_argument("--spinup", type=float, default=1.0,
+                    help="seconds of untimed steps before the warmup (GPU clocks, lane buffers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -174,6 +176,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup:   # untimed: clocks up, lanes allocated
+        step()
     for _ in range(args.warmup):
         step()
     barrier()

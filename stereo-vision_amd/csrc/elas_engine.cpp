@@ -670,6 +670,8 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
                           const std::function<GroupIO(int32_t, int32_t)>& io_of) {
     int32_t rc = require_device(e->device);
     if (rc) return rc;
+    rc = check_params(e->p, dims[0], dims[1]);
+    if (rc) return rc;
     const int32_t G = std::max(1, std::min(g_group.load(), kMaxGroup));
     const int32_t ngroups = (n + G - 1) / G;
     const int lanes = std::min<int>(g_lanes.load(), ngroups);
@@ -679,6 +681,9 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
     std::vector<std::string> errs(std::max(lanes, 1));
     auto worker = [&](int w) {
         Lane* L = acquire_lane(e->device);
+        // size the lane's buffers before taking work: allocation synchronises the
+        // device and must not land in the middle of other lanes' launches later
+        if (hipSetDevice(L->device) == hipSuccess) (void)L->ensure(e->p, dims[0], dims[1], G);
         for (;;) {
             int32_t gi = next.fetch_add(1);
             if (gi >= ngroups) break;

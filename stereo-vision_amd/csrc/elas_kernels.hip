@@ -13,6 +13,8 @@
 // Each kernel cites the reference lines whose result it reproduces.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "svh_internal.h"
 
 namespace svh {
@@ -218,6 +220,118 @@ __global__ __launch_bounds__(256) void k_support(const uint8_t* __restrict__ des
         }
     }
     if (lane == 0) dcan_all[(size_t)pair * P.Wc * P.Hc + cand] = (int16_t)out;
+}
+
+// LDS-staged variant.  The global version above re-reads every descriptor row
+// segment once per candidate (~600 MB of L2 traffic per KITTI pair: L2-bound).
+// Here one block owns kSB consecutive candidates of one lattice row and stages
+// the two descriptor rows v-2 / v+2 of both images, over the column span any
+// of its candidates can touch, in LDS once (~30 KB for disp_max 255); all SAD
+// operands then come from LDS as conflict-free ds_read_b128 (consecutive lanes
+// = consecutive disparities = consecutive 16-byte slots).
+constexpr int kSB = 16;
+
+struct StripView {
+    const uint4* base;   // LDS, two rows of `w` slots: row 0 = v-2, row 1 = v+2
+    int x0, w;
+    __device__ __forceinline__ uint4 at(int row, int x) const { return base[row * w + (x - x0)]; }
+};
+
+__device__ __forceinline__ int support_match_lds(const StripView& own, const StripView& oth,
+                                                 const uint4 centre, int u, int v, bool right,
+                                                 const SupportParams& P, int lane) {
+    if (!(u >= 5 && u <= P.W - 6 && v >= 5 && v <= P.H - 6)) return -1;
+    if ((int)texture16(centre) < P.support_texture) return -1;
+    const int dmin = P.disp_min > 0 ? P.disp_min : 0;
+    int dmax = right ? P.W - u - 5 : u - 5;
+    dmax = dmax < P.disp_max ? dmax : P.disp_max;
+    if (dmax - dmin < 10) return -1;
+    const uint4 r0 = own.at(0, u - 2), r1 = own.at(0, u + 2);
+    const uint4 r2 = own.at(1, u - 2), r3 = own.at(1, u + 2);
+    uint32_t best1 = 0xFFFFFFFFu, best2 = 0xFFFFFFFFu;
+    for (int d0 = dmin; d0 <= dmax; d0 += kWave) {
+        const int d = d0 + lane;
+        if (d <= dmax) {
+            const int uw = right ? u + d : u - d;
+            uint32_t e = sad16(r0, oth.at(0, uw - 2));
+            e += sad16(r1, oth.at(0, uw + 2));
+            e += sad16(r2, oth.at(1, uw - 2));
+            e += sad16(r3, oth.at(1, uw + 2));
+            const uint32_t key = (e << 16) | (uint32_t)d;
+            if (key < best1) {
+                best2 = best1;
+                best1 = key;
+            } else if (key < best2) {
+                best2 = key;
+            }
+        }
+    }
+    const uint32_t m1 = wave_min_u32(best1);
+    const uint32_t m2 = wave_min_u32(best1 == m1 ? best2 : best1);
+    if (m1 == 0xFFFFFFFFu || m2 == 0xFFFFFFFFu) return -1;
+    const float e1 = (float)(m1 >> 16), e2 = (float)(m2 >> 16);
+    if (e1 < __fmul_rn(P.support_threshold, e2)) return (int)(m1 & 0xFFFFu);
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void k_support_lds(const uint8_t* __restrict__ desc_all,
+                                                     int16_t* __restrict__ dcan_all,
+                                                     SupportParams P) {
+    extern __shared__ uint4 s_strip[];
+    const int pair = blockIdx.z, vc = blockIdx.y;
+    const int uc0 = blockIdx.x * kSB;
+    const int ncand = (P.Wc - uc0) < kSB ? (P.Wc - uc0) : kSB;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    int16_t* dcan = dcan_all + (size_t)pair * P.Wc * P.Hc + (size_t)vc * P.Wc + uc0;
+    const int v = vc * P.step;
+    // whole strip outside the matchable rows: results are known without any data
+    if (vc == 0 || v < 5 || v > P.H - 6) {
+        if (threadIdx.x < ncand) dcan[threadIdx.x] = (vc == 0 || uc0 + (int)threadIdx.x == 0) ? 0 : -1;
+        return;
+    }
+    const size_t N16 = (size_t)P.W * P.H;
+    const uint4* d1 = reinterpret_cast<const uint4*>(desc_all) + (size_t)(2 * pair) * N16;
+    const uint4* d2 = d1 + N16;
+    const int u_lo = uc0 * P.step, u_hi = (uc0 + ncand - 1) * P.step;
+    // column spans (see header comment); clipped to the image
+    int xl0 = u_lo - P.disp_max - 2, xl1 = u_hi + P.disp_max + 2;
+    int xr0 = u_lo - P.disp_max - 2, xr1 = u_hi + 2;
+    xl0 = xl0 > 0 ? xl0 : 0;
+    xr0 = xr0 > 0 ? xr0 : 0;
+    xl1 = xl1 < P.W - 1 ? xl1 : P.W - 1;
+    xr1 = xr1 < P.W - 1 ? xr1 : P.W - 1;
+    const int wl = xl1 - xl0 + 1, wr = xr1 - xr0 + 1;
+    uint4* sL = s_strip;
+    uint4* sR = s_strip + 2 * wl;
+    for (int i = threadIdx.x; i < 2 * wl; i += 256) {
+        const int row = i >= wl, x = i - row * wl;
+        sL[i] = d1[(size_t)(v + (row ? 2 : -2)) * P.W + xl0 + x];
+    }
+    for (int i = threadIdx.x; i < 2 * wr; i += 256) {
+        const int row = i >= wr, x = i - row * wr;
+        sR[i] = d2[(size_t)(v + (row ? 2 : -2)) * P.W + xr0 + x];
+    }
+    __syncthreads();
+    const StripView L = {sL, xl0, wl}, R = {sR, xr0, wr};
+    for (int c = wave; c < ncand; c += 4) {
+        const int uc = uc0 + c, u = uc * P.step;
+        int out = 0;  // column 0 stays at calloc's 0
+        if (uc > 0) {
+            out = -1;
+            const bool in = u >= 5 && u <= P.W - 6;
+            const uint4 c1 = in ? d1[(size_t)v * P.W + u] : make_uint4(0, 0, 0, 0);
+            const int d = support_match_lds(L, R, c1, u, v, false, P, lane);
+            if (d >= 0) {
+                const int ub = u - d;   // >= 5 because d <= u-5
+                const uint4 c2 = d2[(size_t)v * P.W + ub];
+                const int dd = support_match_lds(R, L, c2, ub, v, true, P, lane);
+                const int diff = d > dd ? d - dd : dd - d;
+                if (dd >= 0 && diff <= P.lr_threshold) out = d;
+            }
+        }
+        if (lane == 0) dcan[c] = (int16_t)out;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -445,23 +559,44 @@ struct MatchParams {
     int disp_max, match_texture, plane_radius;
 };
 
+// kLds: one block = 256 consecutive pixels of one row; the slice of the OTHER
+// image's descriptor row that any candidate of the block can address
+// ([u_lo-disp_max, u_hi] on the left, [u_lo, u_hi+disp_max] on the right) is
+// staged in LDS once (8 KB for disp_max 255) instead of ~13 L2 reads per pixel.
+template <bool kLds>
 __global__ __launch_bounds__(256) void k_match(GroupDev G, MatchParams P) {
+    extern __shared__ uint4 s_row[];
     const int z = blockIdx.z, pair = z >> 1, side = z & 1;
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= P.DW || y >= P.DH) return;
     if (!G.hdr->active[pair]) return;
+    const int x = kLds ? blockIdx.x * 256 + threadIdx.x : blockIdx.x * 64 + threadIdx.x;
+    const int y = kLds ? blockIdx.y : blockIdx.y * 4 + threadIdx.y;
     const size_t N = (size_t)P.W * P.H;
-    const int u = P.sub ? 2 * x : x, v = P.sub ? 2 * y : y;
+    const int mul = P.sub ? 2 : 1;
+    const int v = y * mul;
+    int line = v < P.H - 3 ? v : P.H - 3;
+    line = line > 2 ? line : 2;
+    const uint4* oth_line =
+        reinterpret_cast<const uint4*>(G.desc + (size_t)(z ^ 1) * N * 16) + (size_t)line * P.W;
+    int s0 = 0;
+    if (kLds) {
+        const int x_lo = blockIdx.x * 256;
+        int x_hi = x_lo + 255;
+        x_hi = x_hi < P.DW - 1 ? x_hi : P.DW - 1;
+        int lo = side ? x_lo * mul : x_lo * mul - P.disp_max;
+        int hi = side ? x_hi * mul + P.disp_max : x_hi * mul;
+        lo = lo > 0 ? lo : 0;
+        hi = hi < P.W - 1 ? hi : P.W - 1;
+        s0 = lo;
+        for (int i = threadIdx.x; i <= hi - lo; i += 256) s_row[i] = oth_line[lo + i];
+        __syncthreads();
+    }
+    if (x >= P.DW || y >= P.DH) return;
+    const int u = x * mul;
     float out = -10.f;
     const int t = G.owner[(size_t)z * N + (size_t)v * P.W + u];
     if (t >= 0 && u >= 2 && u < P.W - 2) {
-        int line = v < P.H - 3 ? v : P.H - 3;
-        line = line > 2 ? line : 2;
         const uint4* own_line =
             reinterpret_cast<const uint4*>(G.desc + (size_t)z * N * 16) + (size_t)line * P.W;
-        const uint4* oth_line =
-            reinterpret_cast<const uint4*>(G.desc + (size_t)(z ^ 1) * N * 16) + (size_t)line * P.W;
         const uint4 own = own_line[u];
         if ((int)texture16(own) >= P.match_texture) {
             const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
@@ -475,8 +610,7 @@ __global__ __launch_bounds__(256) void k_match(GroupDev G, MatchParams P) {
             int dhi = d_plane + P.plane_radius;
             dhi = dhi < P.disp_max ? dhi : P.disp_max;
             const int cell = (v / P.grid_size) * P.gw + u / P.grid_size;
-            const uint32_t* bits =
-                G.mask + ((size_t)z * P.gw * P.gh + cell) * P.gwords;
+            const uint32_t* bits = G.mask + ((size_t)z * P.gw * P.gh + cell) * P.gwords;
             int min_val = 10000, min_d = -1;
             for (int w = 0; w < P.gwords; w++) {
                 uint32_t b = bits[w];
@@ -486,7 +620,8 @@ __global__ __launch_bounds__(256) void k_match(GroupDev G, MatchParams P) {
                     if (dc < dlo || dc > dhi) {
                         const int uw = side ? u + dc : u - dc;
                         if (uw < 2 || uw >= P.W - 2) continue;
-                        const int val = (int)sad16(own, oth_line[uw]);
+                        const uint4 o = kLds ? s_row[uw - s0] : oth_line[uw];
+                        const int val = (int)sad16(own, o);
                         if (val < min_val) {
                             min_val = val;
                             min_d = dc;
@@ -499,7 +634,8 @@ __global__ __launch_bounds__(256) void k_match(GroupDev G, MatchParams P) {
                 if (uw < 2 || uw >= P.W - 2) continue;
                 int dd = dc - d_plane;
                 dd = dd < 0 ? -dd : dd;
-                const int val = (int)sad16(own, oth_line[uw]) + (valid ? G.P[dd] : 0);
+                const uint4 o = kLds ? s_row[uw - s0] : oth_line[uw];
+                const int val = (int)sad16(own, o) + (valid ? G.P[dd] : 0);
                 if (val < min_val) {
                     min_val = val;
                     min_d = dc;
@@ -963,8 +1099,19 @@ void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d
     P.disp_min = p.disp_min; P.disp_max = p.disp_max;
     P.support_texture = p.support_texture; P.lr_threshold = p.lr_threshold;
     P.support_threshold = p.support_threshold;
-    const int cands = d.Wc * d.Hc;
-    LAUNCH("k_support", k_support, dim3((cands + 3) / 4, g), dim3(256), desc, dcan, P);
+    // LDS need of the staged variant: two rows of both strips (16 B slots)
+    const int span = (kSB - 1) * d.step;
+    const size_t wl = (size_t)std::min(d.W, span + 2 * p.disp_max + 5);
+    const size_t wr = (size_t)std::min(d.W, span + p.disp_max + 5);
+    const size_t lds = 2 * (wl + wr) * sizeof(uint4);
+    if (lds <= 64 * 1024) {
+        Timed timed_(cx, "k_support");
+        hipLaunchKernelGGL(k_support_lds, dim3((d.Wc + kSB - 1) / kSB, d.Hc, g), dim3(256), lds,
+                           (hipStream_t)cx.stream, desc, dcan, P);
+    } else {
+        const int cands = d.Wc * d.Hc;
+        LAUNCH("k_support", k_support, dim3((cands + 3) / 4, g), dim3(256), desc, dcan, P);
+    }
 }
 
 void launch_prior(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
@@ -996,7 +1143,14 @@ void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     P.W = d.W; P.H = d.H; P.DW = d.DW; P.DH = d.DH; P.gw = d.gw; P.gh = d.gh; P.gwords = d.gwords;
     P.grid_size = p.grid_size; P.sub = p.subsampling; P.disp_max = p.disp_max;
     P.match_texture = p.match_texture; P.plane_radius = G.plane_radius;
-    LAUNCH("k_match", k_match, grid2d(d.DW, d.DH, 2 * g), dim3(64, 4), G, P);
+    const size_t lds = (size_t)(256 * (p.subsampling ? 2 : 1) + p.disp_max + 1) * sizeof(uint4);
+    if (lds <= 64 * 1024) {
+        Timed timed_(cx, "k_match");
+        hipLaunchKernelGGL(k_match<true>, dim3((d.DW + 255) / 256, d.DH, 2 * g), dim3(256), lds,
+                           (hipStream_t)cx.stream, G, P);
+    } else {
+        LAUNCH("k_match", k_match<false>, grid2d(d.DW, d.DH, 2 * g), dim3(64, 4), G, P);
+    }
 }
 
 void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
