@@ -23,13 +23,24 @@ namespace {
 
 constexpr int kWave = 64;
 
+// Wave-wide unsigned minimum, result uniform in all lanes.  Six DPP steps on the
+// VALU (quad swaps, half-row / row mirrors, then the two row broadcasts of GFX9)
+// instead of six ds_bpermute round trips through the LDS crossbar.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ uint32_t dpp_min_step(uint32_t v) {
+    // lanes without a valid source (or masked rows) read back `v` itself
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, kCtrl, kRowMask, 0xF, false);
+    return o < v ? o : v;
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t other = (uint32_t)__shfl_xor((int)v, o, kWave);
-        v = other < v ? other : v;
-    }
-    return v;
+    v = dpp_min_step<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_min_step<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_min_step<0x141, 0xF>(v);   // row_half_mirror
+    v = dpp_min_step<0x140, 0xF>(v);   // row_mirror        -> every lane: min of its row of 16
+    v = dpp_min_step<0x142, 0xA>(v);   // row_bcast:15      -> rows 1,3 fold in rows 0,2
+    v = dpp_min_step<0x143, 0xC>(v);   // row_bcast:31      -> row 3 (lane 63) holds the minimum
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // sum |a.byte - b.byte| over 16 bytes (== psadbw lanes 0+4, elas.cpp:406-414)
@@ -226,10 +237,11 @@ __global__ __launch_bounds__(256) void k_support(const uint8_t* __restrict__ des
 // segment once per candidate (~600 MB of L2 traffic per KITTI pair: L2-bound).
 // Here one block owns kSB consecutive candidates of one lattice row and stages
 // the two descriptor rows v-2 / v+2 of both images, over the column span any
-// of its candidates can touch, in LDS once (~30 KB for disp_max 255); all SAD
+// of its candidates can touch, in LDS once (~35 KB for disp_max 255); all SAD
 // operands then come from LDS as conflict-free ds_read_b128 (consecutive lanes
 // = consecutive disparities = consecutive 16-byte slots).
-constexpr int kSB = 16;
+constexpr int kSB = 32;          // candidates per block
+constexpr int kSThreads = 512;   // 8 waves share one pair of strips
 
 struct StripView {
     const uint4* base;   // LDS, two rows of `w` slots: row 0 = v-2, row 1 = v+2
@@ -274,7 +286,7 @@ __device__ __forceinline__ int support_match_lds(const StripView& own, const Str
     return -1;
 }
 
-__global__ __launch_bounds__(256) void k_support_lds(const uint8_t* __restrict__ desc_all,
+__global__ __launch_bounds__(kSThreads) void k_support_lds(const uint8_t* __restrict__ desc_all,
                                                      int16_t* __restrict__ dcan_all,
                                                      SupportParams P) {
     extern __shared__ uint4 s_strip[];
@@ -304,17 +316,17 @@ __global__ __launch_bounds__(256) void k_support_lds(const uint8_t* __restrict__
     const int wl = xl1 - xl0 + 1, wr = xr1 - xr0 + 1;
     uint4* sL = s_strip;
     uint4* sR = s_strip + 2 * wl;
-    for (int i = threadIdx.x; i < 2 * wl; i += 256) {
+    for (int i = threadIdx.x; i < 2 * wl; i += kSThreads) {
         const int row = i >= wl, x = i - row * wl;
         sL[i] = d1[(size_t)(v + (row ? 2 : -2)) * P.W + xl0 + x];
     }
-    for (int i = threadIdx.x; i < 2 * wr; i += 256) {
+    for (int i = threadIdx.x; i < 2 * wr; i += kSThreads) {
         const int row = i >= wr, x = i - row * wr;
         sR[i] = d2[(size_t)(v + (row ? 2 : -2)) * P.W + xr0 + x];
     }
     __syncthreads();
     const StripView L = {sL, xl0, wl}, R = {sR, xr0, wr};
-    for (int c = wave; c < ncand; c += 4) {
+    for (int c = wave; c < ncand; c += kSThreads / kWave) {
         const int uc = uc0 + c, u = uc * P.step;
         int out = 0;  // column 0 stays at calloc's 0
         if (uc > 0) {
@@ -1106,7 +1118,7 @@ void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d
     const size_t lds = 2 * (wl + wr) * sizeof(uint4);
     if (lds <= 64 * 1024) {
         Timed timed_(cx, "k_support");
-        hipLaunchKernelGGL(k_support_lds, dim3((d.Wc + kSB - 1) / kSB, d.Hc, g), dim3(256), lds,
+        hipLaunchKernelGGL(k_support_lds, dim3((d.Wc + kSB - 1) / kSB, d.Hc, g), dim3(kSThreads), lds,
                            (hipStream_t)cx.stream, desc, dcan, P);
     } else {
         const int cands = d.Wc * d.Hc;
