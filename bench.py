@@ -192,11 +192,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the only collective on the path: a tiny per-rank result record over RCCL
-        rec = torch.tensor([float(B * args.steps), float((dD1[0] >= 0).sum().item())],
-                           dtype=torch.float64, device=dev)
-        allrec = [torch.zeros_like(rec) for _ in range(world)]
-        dist.all_gather(allrec, rec)
-        total_pairs = int(sum(r[0].item() for r in allrec))
+        from svhip import shard
+        recs = shard.gather_records([float(B * args.steps), float((dD1[0] >= 0).sum().item())],
+                                    dist, dev)
+        total_pairs = int(recs[:, 0].sum())
     else:
         total_pairs = B * args.steps
 

@@ -169,6 +169,13 @@ int32_t svh_profile_get(int32_t index, const char** name, double* total_ms, int6
  * Returns the triangle count or a negative error.                            */
 int32_t svh_delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap);
 
+/* Lattice filters + support list (libelas/src/elas.cpp:174-318, 495-523) as the
+ * engine runs them between the two device phases.  dcan = candidate lattice
+ * [Hc][Wc] as produced by the support kernel, modified in place.  support
+ * receives up to cap (u,v,d) triples; returns the point count.               */
+int32_t svh_elas_support_from_candidates(const svh_elas_params* p, int32_t width, int32_t height,
+                                         int16_t* dcan, int32_t* support, int32_t cap);
+
 #ifdef __cplusplus
 }
 #endif

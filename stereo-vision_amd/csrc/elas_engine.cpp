@@ -751,6 +751,18 @@ int32_t svh_elas_process_batch_device(svh_elas* e, int32_t n, const uint8_t* dI1
     });
 }
 
+int32_t svh_elas_support_from_candidates(const svh_elas_params* p, int32_t width, int32_t height,
+                                         int16_t* dcan, int32_t* support, int32_t cap) {
+    if (!p || !dcan || !support) return fail(SVH_ERR_BAD_ARG, "null argument");
+    const Dims d = make_dims(*p, width, height);
+    std::vector<int32_t> s;
+    support_from_candidates(*p, d, dcan, s);
+    const int32_t n = (int32_t)(s.size() / 3);
+    for (int32_t i = 0; i < n && i < cap; i++)
+        for (int k = 0; k < 3; k++) support[3 * i + k] = s[3 * i + k];
+    return n;
+}
+
 int32_t svh_elas_set_group(int32_t pairs) {
     if (pairs < 1) pairs = 1;
     if (pairs > kMaxGroup) pairs = kMaxGroup;

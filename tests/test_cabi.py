@@ -1,0 +1,120 @@
+"""CPU-side checks of the product library: it loads, exports every symbol that
+include/svh.h declares, its host-resident stages (lattice filters, Delaunay)
+match the oracle / the real Triangle, and it refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+@pytest.fixture(scope="module")
+def S():
+    import svhip
+    svhip.lib()
+    return svhip
+
+
+def test_exports_every_declared_symbol(S):
+    hdr = open(os.path.join(H.ROOT, "include", "svh.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(svh_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 15
+    lib = S.lib()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_param_presets_match_reference(S):
+    for setting, mine in ((0, H.robotics()), (1, H.middlebury())):
+        p = S.default_params(setting)
+        assert bytes(p) == bytes(mine)
+        if H.have_ref_elas():
+            q = H.ElasParams()
+            H.ref_elas().ref_elas_params_default(C.byref(q), setting)
+            assert bytes(q) == bytes(p)
+
+
+@pytest.mark.parametrize("case", ["urban1_robotics", "urban2_stereomapper", "urban3_demo",
+                                  "cones_middlebury"])
+def test_delaunay_matches_golden_triangle_lists(case, S):
+    z = np.load(os.path.join(H.GOLDEN, case + ".npz"))
+    s = z["support"].reshape(-1, 3)
+    for side, key in ((0, "tri1"), (1, "tri2")):
+        pts = np.stack([s[:, 0] - side * s[:, 2], s[:, 1]], 1).astype(np.float32)
+        assert np.array_equal(S.delaunay(pts), z[key].reshape(-1, 3))
+
+
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs the real Triangle in oracle/_ref")
+def test_delaunay_matches_triangle_fuzz(S):
+    rng = np.random.default_rng(5)
+    for trial in range(120):
+        n = int(rng.integers(3, 300))
+        kind = trial % 5
+        if kind == 0:      # 5-px lattice: many co-circular ties
+            pts = np.unique(rng.integers(1, 50, (n, 2)) * 5, axis=0)
+            rng.shuffle(pts)
+        elif kind == 1:    # lattice with duplicate points
+            pts = rng.integers(1, 16, (n, 2)) * 5
+        elif kind == 2:    # even-integer lattice with duplicates (libviso2 outlier filter)
+            pts = rng.integers(0, 200, (n, 2)) * 2
+        elif kind == 3:    # collinear runs
+            x = rng.integers(0, 100, n)
+            pts = np.stack([x, x * 0 + 7], 1)
+        else:              # half-pixel coordinates
+            pts = rng.integers(0, 2000, (n, 2)) / 2.0
+        pts = pts.astype(np.float32)
+        if len(np.unique(pts, axis=0)) < 3:
+            continue
+        assert np.array_equal(S.delaunay(pts), H.ref_triangulate(pts)), (trial, kind)
+
+
+def test_host_support_stage_matches_oracle(S, oracle_lib):
+    """lattice filters + list on the host == oracle (in-place, u-major semantics)"""
+    lib = S.lib()
+    rng = np.random.default_rng(3)
+    for prm, w, h in ((H.robotics(), 1242, 375), (H.middlebury(), 640, 480),
+                      (H.robotics(candidate_stepsize=4), 400, 240)):
+        wc = C.c_int32()
+        hc = C.c_int32()
+        oracle_lib.orc_dcan_dims(C.byref(prm), w, h, C.byref(wc), C.byref(hc))
+        # a plausible lattice: smooth disparity field, ~45 % invalid, a few outliers
+        yy, xx = np.mgrid[0:hc.value, 0:wc.value]
+        d = (20 + 0.1 * xx + 0.2 * yy + rng.integers(-1, 2, xx.shape)).astype(np.int16)
+        d[rng.random(d.shape) < 0.45] = -1
+        d[rng.random(d.shape) < 0.02] = 150
+        d[0, :] = 0
+        d[:, 0] = 0
+        a = d.copy()
+        b = d.copy()
+        cap = wc.value * hc.value + 6
+        sa = np.zeros((cap, 3), np.int32)
+        sb = np.zeros((cap, 3), np.int32)
+        na = oracle_lib.orc_support_filter(C.byref(prm), H._p(a), w, h, H._p(sa), cap)
+        nb = lib.svh_elas_support_from_candidates(C.byref(prm), w, h, H._p(b), H._p(sb), cap)
+        assert na == nb and na > 10
+        assert np.array_equal(sa[:na], sb[:nb]) and np.array_equal(a, b)
+
+
+def test_refuses_to_run_without_a_gpu(S):
+    """no CPU fallback: without a HIP device the call fails loudly, outputs untouched"""
+    if S.device_count() > 0:
+        pytest.skip("a GPU is present")
+    l, r = H.golden_pair("urban3_640x240")
+    D1 = np.full(l.shape, -7.0, np.float32)
+    D2 = D1.copy()
+    with pytest.raises(S.SvhError) as ei:
+        S.Elas(H.robotics()).process(l, r, D1, D2)
+    assert ei.value.code == S.ERR_NO_DEVICE
+    assert np.all(D1 == -7.0) and np.all(D2 == -7.0)
+
+
+def test_cxx_dropin_header_builds():
+    """include/elas.h + the reference call sites compile and link against the C-ABI"""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(H.ROOT, "tests", "cxx"), "all"],
+                          stdout=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(H.ROOT, "tests", "cxx", "elas_dropin"))

@@ -132,3 +132,20 @@ def test_batch_equals_single(svhip):
     for i in range(n):
         rc, a, b = svhip.Elas(prm).process(I1[i], I2[i])
         assert rc == 0 and np.array_equal(a, D1[i]) and np.array_equal(b, D2[i])
+
+
+@pytest.mark.parametrize("mode,crop,case", [("demo", "urban3_640x240", "urban3_demo"),
+                                            ("mapper", "urban2_1242x375", "urban2_stereomapper")])
+def test_cxx_dropin_call_sites(mode, crop, case, svhip, tmp_path):
+    """the reference's own call sites (main.cpp:61-64, stereothread.cpp:76-114) compiled
+    against include/elas.h reproduce the reference's output bit for bit"""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(H.ROOT, "tests", "cxx"), "all"],
+                          stdout=subprocess.DEVNULL)
+    exe = os.path.join(H.ROOT, "tests", "cxx", "elas_dropin")
+    o1, o2 = str(tmp_path / "d1.f32"), str(tmp_path / "d2.f32")
+    subprocess.check_call([exe, os.path.join(H.GOLDEN, crop + "_left.pgm"),
+                           os.path.join(H.GOLDEN, crop + "_right.pgm"), mode, o1, o2])
+    z = np.load(os.path.join(H.GOLDEN, case + ".npz"))
+    assert np.array_equal(np.fromfile(o1, np.float32), z["d1"])
+    assert np.array_equal(np.fromfile(o2, np.float32), z["d2"])
