@@ -176,6 +176,76 @@ int32_t svh_delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap);
 int32_t svh_elas_support_from_candidates(const svh_elas_params* p, int32_t width, int32_t height,
                                          int16_t* dcan, int32_t* support, int32_t cap);
 
+/* ======================================================================== */
+/* Matcher (libviso2)                                                        */
+/* ======================================================================== */
+/* Matcher::parameters -- libviso2/src/matcher.h:41-69 (defaults: constructor) */
+typedef struct svh_matcher_params {
+    int32_t nms_n;
+    int32_t nms_tau;
+    int32_t match_binsize;
+    int32_t match_radius;
+    int32_t match_disp_tolerance;
+    int32_t outlier_disp_tolerance;
+    int32_t outlier_flow_tolerance;
+    int32_t multi_stage;
+    int32_t half_resolution;
+    int32_t refinement;
+    double  f, cu, cv, base;       /* calibration, only used for match prediction */
+} svh_matcher_params;
+void svh_matcher_params_default(svh_matcher_params* p);
+
+/* Matcher::p_match -- libviso2/src/matcher.h:87-102, same field order */
+typedef struct svh_p_match {
+    float u1p, v1p; int32_t i1p;
+    float u2p, v2p; int32_t i2p;
+    float u1c, v1c; int32_t i1c;
+    float u2c, v2c; int32_t i2c;
+} svh_p_match;
+
+typedef struct svh_matcher svh_matcher;
+
+/* Matcher::Matcher(parameters) / ~Matcher() -- matcher.cpp:33-98 */
+svh_matcher* svh_matcher_create(const svh_matcher_params* p);
+void         svh_matcher_destroy(svh_matcher* m);
+/* Matcher::setIntrinsics -- matcher.h:78-84 */
+void svh_matcher_set_intrinsics(svh_matcher* m, double f, double cu, double cv, double base);
+/* Matcher::pushBack(I1,I2,dims,replace) -- matcher.cpp:102-205.  I2 may be NULL
+ * (single-image variant, matcher.h:118).  dims = {width,height,bytes_per_line}. */
+int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* I2,
+                              const int32_t* dims, int32_t replace);
+/* Matcher::matchFeatures(method, Tr_delta) -- matcher.cpp:209-293.  method 0 flow,
+ * 1 stereo, 2 quad.  Tr_delta: 16 doubles row-major (4x4) or NULL.               */
+int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double* Tr_delta);
+/* Matcher::bucketFeatures -- matcher.cpp:297-343 (std::random_shuffle on the host) */
+int32_t svh_matcher_bucket_features(svh_matcher* m, int32_t max_features, float bucket_width,
+                                    float bucket_height);
+/* Matcher::getMatches -- matcher.h:146: copies up to cap matches, returns the count */
+int32_t svh_matcher_get_matches(svh_matcher* m, svh_p_match* out, int32_t cap);
+/* Matcher::getGain -- matcher.cpp:347-389 */
+float   svh_matcher_get_gain(svh_matcher* m, const int32_t* inliers, int32_t n);
+
+/* parity taps */
+enum svh_matcher_table {            /* feature tables, 12 x int32 per feature      */
+    SVH_M_1P1 = 0, SVH_M_1P2, SVH_M_2P1, SVH_M_2P2,   /* previous: left sparse/dense, right .. */
+    SVH_M_1C1, SVH_M_1C2, SVH_M_2C1, SVH_M_2C2        /* current                               */
+};
+int32_t svh_matcher_get_features(svh_matcher* m, int32_t table, int32_t* out, int32_t cap);
+enum svh_matcher_stage {
+    SVH_M_SPARSE_RAW = 0,   /* svh_p_match[]  after matching(), 1st pass (matcher.cpp:269)     */
+    SVH_M_SPARSE,           /* after removeOutliers (matcher.cpp:270)                          */
+    SVH_M_RANGES,           /* float[bins][16]: u_min[4],u_max[4],v_min[4],v_max[4] (:273)     */
+    SVH_M_DENSE_RAW,        /* after matching(), 2nd pass (:276)                               */
+    SVH_M_DENSE_REFINED,    /* after refinement (:279)                                         */
+    SVH_M_DENSE,            /* after removeOutliers (:281) == getMatches before bucketing      */
+    SVH_M_STAGE_COUNT
+};
+int32_t svh_matcher_get_stage(svh_matcher* m, int32_t stage, void* buf, size_t cap, size_t* size);
+/* filter images of the current left frame for parity checks:
+ * 0 du, 1 dv (matching resolution), 2 du_full, 3 dv_full (u8); 4 f1 blob, 5 f2 checkerboard (i16) */
+int32_t svh_matcher_get_filter(svh_matcher* m, int32_t which, void* buf, size_t cap, size_t* size,
+                               int32_t* dims3);
+
 #ifdef __cplusplus
 }
 #endif

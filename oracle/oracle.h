@@ -73,6 +73,26 @@ void     orc_elas_run_free(orc_run* r);
 int32_t  orc_elas_process(const svh_elas_params* p, const uint8_t* I1, const uint8_t* I2,
                           float* D1, float* D2, const int32_t* dims, orc_triangulate_fn tri_fn);
 
+/* ---- libviso2 Matcher (oracle/viso_oracle.cpp) ---------------------------- */
+/* Same call surface as the svh_matcher_* C-ABI (include/svh.h); the Delaunay
+ * triangulator of removeOutliers is supplied by the caller. */
+typedef struct orc_matcher orc_matcher;
+void         orc_matcher_params_default(svh_matcher_params* p);
+orc_matcher* orc_matcher_create(const svh_matcher_params* p);
+void         orc_matcher_destroy(orc_matcher* m);
+void         orc_matcher_set_triangulator(orc_matcher* m, orc_triangulate_fn fn);
+void         orc_matcher_set_intrinsics(orc_matcher* m, double f, double cu, double cv, double base);
+int32_t      orc_matcher_push_back(orc_matcher* m, const uint8_t* I1, const uint8_t* I2,
+                                   const int32_t* dims, int32_t replace);
+int32_t      orc_matcher_match_features(orc_matcher* m, int32_t method, const double* Tr_delta);
+int32_t      orc_matcher_bucket_features(orc_matcher* m, int32_t max_features, float bw, float bh);
+float        orc_matcher_get_gain(orc_matcher* m, const int32_t* inliers, int32_t n);
+int32_t      orc_matcher_get_matches(orc_matcher* m, svh_p_match* out, int32_t cap);
+int32_t      orc_matcher_get_features(orc_matcher* m, int32_t table, int32_t* out, int32_t cap);
+int64_t      orc_matcher_get_stage(orc_matcher* m, int32_t stage, void* buf, int64_t cap);
+int64_t      orc_matcher_get_filter(orc_matcher* m, int32_t which, void* buf, int64_t cap,
+                                    int32_t* dims3);
+
 #ifdef __cplusplus
 }
 #endif

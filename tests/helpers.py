@@ -343,3 +343,216 @@ def compare_runs(a, b, stages=None, skip=()):
             out.append((STAGE_NAMES[s], int((x.view(np.uint8) != y.view(np.uint8)).sum())
                         if x.dtype != np.float32 else int((x != y).sum())))
     return out
+
+
+# ----------------------------------------------------------------------------- libviso2 Matcher
+class MatcherParams(C.Structure):
+    """svh_matcher_params (include/svh.h) == Matcher::parameters (libviso2/src/matcher.h:41-69)."""
+    _fields_ = [
+        ("nms_n", C.c_int32), ("nms_tau", C.c_int32), ("match_binsize", C.c_int32),
+        ("match_radius", C.c_int32), ("match_disp_tolerance", C.c_int32),
+        ("outlier_disp_tolerance", C.c_int32), ("outlier_flow_tolerance", C.c_int32),
+        ("multi_stage", C.c_int32), ("half_resolution", C.c_int32), ("refinement", C.c_int32),
+        ("f", C.c_double), ("cu", C.c_double), ("cv", C.c_double), ("base", C.c_double),
+    ]
+
+    def copy(self, **kw):
+        q = MatcherParams.from_buffer_copy(bytes(self))
+        for k, v in kw.items():
+            setattr(q, k, v)
+        return q
+
+
+def matcher_defaults(**kw):
+    """Matcher::parameters() -- libviso2/src/matcher.h:56-68"""
+    return MatcherParams(3, 50, 50, 200, 2, 5, 5, 1, 1, 1, 0.0, 0.0, 0.0, 0.0).copy(**kw)
+
+
+P_MATCH = np.dtype([("u1p", "f4"), ("v1p", "f4"), ("i1p", "i4"), ("u2p", "f4"), ("v2p", "f4"),
+                    ("i2p", "i4"), ("u1c", "f4"), ("v1c", "f4"), ("i1c", "i4"), ("u2c", "f4"),
+                    ("v2c", "f4"), ("i2c", "i4")])
+(M_SPARSE_RAW, M_SPARSE, M_RANGES, M_DENSE_RAW, M_DENSE_REFINED, M_DENSE, M_STAGE_COUNT) = range(7)
+M_STAGE_NAMES = ["sparse_raw", "sparse", "ranges", "dense_raw", "dense_refined", "dense"]
+M_TABLES = ["1p1", "1p2", "2p1", "2p2", "1c1", "1c2", "2c1", "2c2"]
+
+_ref_viso = None
+
+
+def ref_viso_path():
+    return os.path.join(ROOT, "oracle", "_ref", "libref_viso.so")
+
+
+def have_ref_viso():
+    return os.path.exists(ref_viso_path())
+
+
+def ref_viso():
+    global _ref_viso
+    if _ref_viso is None:
+        lib = C.CDLL(ref_viso_path())
+        lib.ref_init(1)
+        lib.ref_matcher_create.restype = C.c_void_p
+        lib.ref_matcher_create.argtypes = [C.POINTER(MatcherParams)]
+        for f in ("ref_matcher_destroy", "ref_matcher_push_back", "ref_matcher_match",
+                  "ref_matcher_match_staged", "ref_matcher_get_stage", "ref_matcher_get_features",
+                  "ref_matcher_get_filter", "ref_matcher_set_intrinsics", "ref_matcher_get_matches",
+                  "ref_matcher_bucket", "ref_matcher_gain"):
+            getattr(lib, f)
+        lib.ref_matcher_destroy.argtypes = [C.c_void_p]
+        lib.ref_matcher_push_back.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        lib.ref_matcher_match.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.ref_matcher_match_staged.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.ref_matcher_get_stage.restype = C.c_int64
+        lib.ref_matcher_get_stage.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        lib.ref_matcher_get_features.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        lib.ref_matcher_get_filter.restype = C.c_int64
+        lib.ref_matcher_get_filter.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+        lib.ref_matcher_set_intrinsics.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+        lib.ref_matcher_get_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        lib.ref_matcher_bucket.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float]
+        lib.ref_matcher_gain.restype = C.c_float
+        lib.ref_matcher_gain.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        lib.ref_viso_triangulate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        _ref_viso = lib
+    return _ref_viso
+
+
+class MatcherBase:
+    """shared driver over the three Matcher implementations (prefix = ref_/orc_/svh_)"""
+
+    def __init__(self, lib, prefix, params):
+        self.lib, self.px = lib, prefix
+        self.params = params
+        self.h = getattr(lib, prefix + "matcher_create")(C.byref(params))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(self.lib, self.px + "matcher_destroy")(self.h)
+            self.h = None
+
+    def _f(self, name):
+        return getattr(self.lib, self.px + "matcher_" + name)
+
+    def set_intrinsics(self, f, cu, cv, base):
+        self._f("set_intrinsics")(self.h, f, cu, cv, base)
+
+    def push_back(self, I1, I2=None, replace=False):
+        I1 = np.ascontiguousarray(I1, np.uint8)
+        p2 = None
+        if I2 is not None:
+            I2 = np.ascontiguousarray(I2, np.uint8)
+            p2 = _p(I2)
+        return self._f("push_back")(self.h, _p(I1), p2, dims_of(I1), 1 if replace else 0)
+
+    def features(self, table):
+        n = self._f("get_features")(self.h, table, None, 0)
+        out = np.zeros((max(n, 0), 12), np.int32)
+        if n > 0:
+            self._f("get_features")(self.h, table, _p(out), n)
+        return out
+
+    def filter_image(self, which):
+        dims = (C.c_int32 * 3)()
+        if self.px == "svh_":
+            sz = C.c_size_t(0)
+            self._f("get_filter")(self.h, which, None, 0, C.byref(sz), dims)
+            buf = np.zeros(sz.value, np.uint8)
+            self._f("get_filter")(self.h, which, _p(buf), sz.value, C.byref(sz), dims)
+        else:
+            n = self._f("get_filter")(self.h, which, None, 0, dims)
+            buf = np.zeros(max(n, 0), np.uint8)
+            self._f("get_filter")(self.h, which, _p(buf), n, dims)
+        a = buf.view(np.int16 if which >= 4 else np.uint8)
+        return a.reshape(dims[1], dims[2])[:, :dims[0]], tuple(dims)
+
+    def stage(self, stage):
+        if self.px == "svh_":
+            sz = C.c_size_t(0)
+            self._f("get_stage")(self.h, stage, None, 0, C.byref(sz))
+            buf = np.zeros(sz.value, np.uint8)
+            if sz.value:
+                self._f("get_stage")(self.h, stage, _p(buf), sz.value, C.byref(sz))
+        else:
+            n = self._f("get_stage")(self.h, stage, None, 0)
+            buf = np.zeros(max(n, 0), np.uint8)
+            if n > 0:
+                self._f("get_stage")(self.h, stage, _p(buf), n)
+        return buf.view(np.float32) if stage == M_RANGES else buf.view(P_MATCH)
+
+    def matches(self):
+        n = self._f("get_matches")(self.h, None, 0)
+        out = np.zeros(max(n, 0), P_MATCH)
+        if n > 0:
+            self._f("get_matches")(self.h, _p(out), n)
+        return out
+
+
+class RefMatcher(MatcherBase):
+    def __init__(self, params):
+        super().__init__(ref_viso(), "ref_", params)
+
+    def match(self, method, Tr=None, staged=True):
+        t = None if Tr is None else _p(np.ascontiguousarray(Tr, np.float64))
+        (self.lib.ref_matcher_match_staged if staged else self.lib.ref_matcher_match)(self.h, method, t)
+
+    def bucket(self, max_features, bw, bh):
+        return self.lib.ref_matcher_bucket(self.h, max_features, bw, bh)
+
+    def gain(self, inliers):
+        a = np.ascontiguousarray(inliers, np.int32)
+        return self.lib.ref_matcher_gain(self.h, _p(a), len(a))
+
+
+class OracleMatcher(MatcherBase):
+    def __init__(self, params, tri_fn=None):
+        lib = oracle()
+        lib.orc_matcher_create.restype = C.c_void_p
+        lib.orc_matcher_create.argtypes = [C.POINTER(MatcherParams)]
+        lib.orc_matcher_destroy.argtypes = [C.c_void_p]
+        lib.orc_matcher_set_triangulator.argtypes = [C.c_void_p, C.c_void_p]
+        lib.orc_matcher_set_intrinsics.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+        lib.orc_matcher_push_back.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        lib.orc_matcher_match_features.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.orc_matcher_get_stage.restype = C.c_int64
+        lib.orc_matcher_get_stage.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        lib.orc_matcher_get_features.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        lib.orc_matcher_get_filter.restype = C.c_int64
+        lib.orc_matcher_get_filter.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+        lib.orc_matcher_get_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        lib.orc_matcher_bucket_features.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float]
+        lib.orc_matcher_get_gain.restype = C.c_float
+        lib.orc_matcher_get_gain.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        super().__init__(lib, "orc_", params)
+        if tri_fn is None:
+            tri_fn = C.cast(ref_viso().ref_viso_triangulate, C.c_void_p)
+        self._tri = tri_fn   # keep callbacks alive
+        lib.orc_matcher_set_triangulator(self.h, tri_fn if isinstance(tri_fn, C.c_void_p)
+                                         else C.cast(tri_fn, C.c_void_p))
+
+    def match(self, method, Tr=None, staged=True):
+        t = None if Tr is None else _p(np.ascontiguousarray(Tr, np.float64))
+        return self.lib.orc_matcher_match_features(self.h, method, t)
+
+    def bucket(self, max_features, bw, bh):
+        return self.lib.orc_matcher_bucket_features(self.h, max_features, bw, bh)
+
+    def gain(self, inliers):
+        a = np.ascontiguousarray(inliers, np.int32)
+        return self.lib.orc_matcher_get_gain(self.h, _p(a), len(a))
+
+
+def compare_matchers(a, b, method=2):
+    """list of (what, n_mismatch) between two matcher drivers after push_back x2 + match"""
+    out = []
+    for tb in range(8):
+        x, y = a.features(tb), b.features(tb)
+        out.append(("table_" + M_TABLES[tb], -1 if x.shape != y.shape else int((x != y).sum())))
+    for s in range(M_STAGE_COUNT):
+        x, y = a.stage(s), b.stage(s)
+        if s == M_RANGES:
+            # only the stages the method uses are defined (matcher.cpp:1003-1025)
+            ns = 4 if method == 2 else 2
+            x = x.reshape(-1, 4, 4)[:, :, :ns] if len(x) else x
+            y = y.reshape(-1, 4, 4)[:, :, :ns] if len(y) else y
+        out.append((M_STAGE_NAMES[s], -1 if x.shape != y.shape else int((x != y).sum())))
+    return out
