@@ -42,7 +42,8 @@ namespace svh {
 static thread_local std::string t_error;
 static thread_local int t_device = 0;
 
-static int fail(int code, const std::string& msg) {
+// shared by the Elas and Matcher engines: text behind svh_last_error()
+int fail(int code, const std::string& msg) {
     t_error = msg;
     return code;
 }

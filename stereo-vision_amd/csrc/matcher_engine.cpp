@@ -1,0 +1,651 @@
+// Engine behind the svh_matcher_* C-ABI (include/svh.h): libviso2's Matcher.
+//
+//   pushBack       device: half-resolution image, 5x5 Sobel (matching and full
+//                  resolution), blob + checkerboard responses, two non-maximum
+//                  suppressions with ordered compaction, 32-byte descriptors.
+//                  Feature tables stay on the device; only the four counts come
+//                  back.  (reference: matcher.cpp:102-205, 780-878)
+//   matchFeatures  device: bin indices, circular matching (one thread per query
+//                  feature, four dependent hops), ordered compaction, 5x5
+//                  relocation on the full-resolution Sobel images.
+//                  host: Delaunay outlier vote and per-bin prior statistics on
+//                  a few hundred / thousand matches (matcher.cpp:209-293).
+//
+// One object per visual-odometry instance, used by one thread at a time (like
+// the reference's, viso.cpp:33); every object owns its stream and buffers, so
+// objects on different threads do not interact.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "matcher_internal.h"
+
+namespace svh {
+
+int fail(int code, const std::string& msg);   // elas_engine.cpp: sets svh_last_error()
+static int mfail(int code, const std::string& msg) { return fail(code, msg); }
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return mfail(SVH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+template <typename T>
+static hipError_t dalloc(T** p, size_t count) {
+    return hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T));
+}
+
+// device-resident data of one camera image of one frame
+struct DevView {
+    bool valid = false;
+    int32_t w = 0, h = 0, bpl = 0;       // full resolution
+    int32_t mw = 0, mh = 0, mbpl = 0;    // matching resolution
+    int32_t half = -1;
+    uint8_t *I = nullptr, *Ih = nullptr, *du = nullptr, *dv = nullptr, *du_full = nullptr,
+            *dv_full = nullptr;
+    int16_t *f1 = nullptr, *f2 = nullptr;
+    int32_t* tab[2] = {nullptr, nullptr};   // sparse, dense
+    int32_t cap[2] = {0, 0};
+    int32_t* cnt = nullptr;                 // device: n_sparse, n_dense
+    int32_t n[2] = {0, 0};                  // host copy
+    int32_t *off[2] = {nullptr, nullptr}, *ids[2] = {nullptr, nullptr};
+    int32_t nbins = 0;
+    std::vector<uint8_t> host;              // full image on the host (getGain)
+
+    void release() {
+        (void)hipFree(I); (void)hipFree(Ih); (void)hipFree(du); (void)hipFree(dv); (void)hipFree(du_full);
+        (void)hipFree(dv_full); (void)hipFree(f1); (void)hipFree(f2); (void)hipFree(cnt);
+        for (int k = 0; k < 2; k++) {
+            (void)hipFree(tab[k]); (void)hipFree(off[k]); (void)hipFree(ids[k]);
+            tab[k] = off[k] = ids[k] = nullptr;
+            cap[k] = 0;
+        }
+        I = Ih = du = dv = du_full = dv_full = nullptr;
+        f1 = f2 = nullptr;
+        cnt = nullptr;
+        w = h = 0;
+        half = -1;
+        nbins = 0;
+        valid = false;
+    }
+};
+
+}  // namespace svh
+
+using namespace svh;
+
+struct svh_matcher {
+    svh_matcher_params p;
+    int32_t margin;
+    int device;
+    hipStream_t stream;
+    DevView prev[2], cur[2];
+    int32_t dims_p[3], dims_c[3];
+    // scratch
+    int4* slots = nullptr;
+    int32_t* flags = nullptr;
+    int32_t slot_cap = 0;
+    int32_t* cursor = nullptr;
+    int32_t cursor_cap = 0;
+    svh_p_match *pm_slots = nullptr, *pm_out = nullptr;
+    int32_t *pm_flags = nullptr, *pm_count = nullptr;
+    int32_t pm_cap = 0;
+    int32_t* pixel_owner = nullptr;
+    size_t owner_cap = 0;
+    float* ranges_dev = nullptr;
+    int32_t ranges_cap = 0;
+    uint8_t* h_stage = nullptr;   // pinned upload staging for images
+    size_t h_stage_cap = 0;
+    // results
+    std::vector<svh_p_match> m1, m2;
+    std::vector<float> ranges;    // [bins][16]
+    std::vector<svh_p_match> stage[SVH_M_STAGE_COUNT];
+};
+
+namespace svh {
+
+static int ensure_view(svh_matcher* m, DevView& V, int32_t w, int32_t h, int32_t bpl) {
+    const svh_matcher_params& p = m->p;
+    if (V.w == w && V.h == h && V.bpl == bpl && V.half == p.half_resolution) return SVH_OK;
+    V.release();
+    V.w = w; V.h = h; V.bpl = bpl;
+    V.half = p.half_resolution;
+    if (p.half_resolution) {
+        V.mw = w / 2;
+        V.mh = h / 2;
+        V.mbpl = V.mw + 15 - (V.mw - 1) % 16;   // matcher.cpp:751-756
+    } else {
+        V.mw = w; V.mh = h; V.mbpl = bpl;
+    }
+    const size_t fn = (size_t)bpl * h, mn = (size_t)V.mbpl * V.mh;
+    HIP_TRY(dalloc(&V.I, fn));
+    HIP_TRY(dalloc(&V.du, mn));
+    HIP_TRY(dalloc(&V.dv, mn));
+    HIP_TRY(dalloc(&V.f1, mn));
+    HIP_TRY(dalloc(&V.f2, mn));
+    if (p.half_resolution) {
+        HIP_TRY(dalloc(&V.Ih, mn));
+        HIP_TRY(dalloc(&V.du_full, fn));
+        HIP_TRY(dalloc(&V.dv_full, fn));
+    }
+    HIP_TRY(dalloc(&V.cnt, 2));
+    HIP_TRY(hipMemsetAsync(V.cnt, 0, 2 * sizeof(int32_t), m->stream));
+    int32_t ns = p.nms_n * 3;
+    if (ns > 10) ns = std::max(p.nms_n, 10);           // matcher.cpp:824-828
+    const int32_t nn[2] = {ns, p.nms_n};
+    for (int k = 0; k < 2; k++) {
+        V.cap[k] = 4 * mnms_blocks(V.mw, nn[k], m->margin) * mnms_blocks(V.mh, nn[k], m->margin);
+        HIP_TRY(dalloc(&V.tab[k], (size_t)12 * V.cap[k]));
+        HIP_TRY(dalloc(&V.ids[k], (size_t)V.cap[k]));
+    }
+    return SVH_OK;
+}
+
+static int ensure_scratch(svh_matcher* m, int32_t slot_need, int32_t pm_need, size_t owner_need) {
+    if (slot_need > m->slot_cap) {
+        (void)hipFree(m->slots); (void)hipFree(m->flags);
+        HIP_TRY(dalloc(&m->slots, (size_t)slot_need));
+        HIP_TRY(dalloc(&m->flags, (size_t)slot_need));
+        m->slot_cap = slot_need;
+    }
+    if (pm_need > m->pm_cap) {
+        (void)hipFree(m->pm_slots); (void)hipFree(m->pm_out); (void)hipFree(m->pm_flags);
+        HIP_TRY(dalloc(&m->pm_slots, (size_t)pm_need));
+        HIP_TRY(dalloc(&m->pm_out, (size_t)pm_need));
+        HIP_TRY(dalloc(&m->pm_flags, (size_t)pm_need));
+        m->pm_cap = pm_need;
+    }
+    if (!m->pm_count) HIP_TRY(dalloc(&m->pm_count, 1));
+    if (owner_need > m->owner_cap) {
+        (void)hipFree(m->pixel_owner);
+        HIP_TRY(dalloc(&m->pixel_owner, owner_need));
+        m->owner_cap = owner_need;
+    }
+    return SVH_OK;
+}
+
+// M1..M5  Matcher::computeFeatures   matcher.cpp:780-878
+static int compute_features(svh_matcher* m, DevView& V, const uint8_t* src, int32_t pitch) {
+    const svh_matcher_params& p = m->p;
+    hipStream_t s = m->stream;
+    const size_t fn = (size_t)V.bpl * V.h;
+    if (fn > m->h_stage_cap) {
+        (void)hipHostFree(m->h_stage);
+        HIP_TRY(hipHostMalloc((void**)&m->h_stage, fn));
+        m->h_stage_cap = fn;
+    }
+    // rows are packed at the aligned pitch in pinned memory, then one linear DMA
+    HIP_TRY(hipStreamSynchronize(s));   // staging buffer is shared by both images
+    memset(m->h_stage, 0, fn);
+    for (int32_t v = 0; v < V.h; v++) memcpy(m->h_stage + (size_t)v * V.bpl, src + (size_t)v * pitch, V.w);
+    V.host.assign(m->h_stage, m->h_stage + fn);
+    HIP_TRY(hipMemcpyAsync(V.I, m->h_stage, fn, hipMemcpyHostToDevice, s));
+    const uint8_t* Im = V.I;
+    if (p.half_resolution) {
+        mlaunch_half(s, V.I, V.bpl, V.Ih, V.mw, V.mh, V.mbpl);
+        Im = V.Ih;
+        mlaunch_filters(s, V.I, V.w, V.h, V.bpl, V.du_full, V.dv_full, nullptr, nullptr);
+    }
+    mlaunch_filters(s, Im, V.mw, V.mh, V.mbpl, V.du, V.dv, V.f1, V.f2);
+    const int32_t scale = p.half_resolution ? 2 : 1;
+    int32_t ns = p.nms_n * 3;
+    if (ns > 10) ns = std::max(p.nms_n, 10);
+    int rc = ensure_scratch(m, std::max(V.cap[0], V.cap[1]), 0, 0);
+    if (rc) return rc;
+    if (p.multi_stage)
+        mlaunch_features(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, ns, p.nms_tau, m->margin, scale,
+                         m->slots, m->flags, V.tab[0], V.cnt + 0);
+    else
+        HIP_TRY(hipMemsetAsync(V.cnt, 0, sizeof(int32_t), s));
+    mlaunch_features(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, p.nms_n, p.nms_tau, m->margin, scale,
+                     m->slots, m->flags, V.tab[1], V.cnt + 1);
+    HIP_TRY(hipMemcpyAsync(V.n, V.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    V.nbins = 0;   // bin indices are (re)built by matchFeatures for the current bin grid
+    V.valid = true;
+    return SVH_OK;
+}
+
+static int ensure_bins(svh_matcher* m, DevView& V, int32_t ub, int32_t vb) {
+    const int32_t nb = 4 * ub * vb;
+    if (V.nbins == nb) return SVH_OK;
+    for (int k = 0; k < 2; k++) {
+        (void)hipFree(V.off[k]);
+        HIP_TRY(dalloc(&V.off[k], (size_t)nb + 1));
+    }
+    if (nb > m->cursor_cap) {
+        (void)hipFree(m->cursor);
+        HIP_TRY(dalloc(&m->cursor, (size_t)nb));
+        m->cursor_cap = nb;
+    }
+    for (int k = 0; k < 2; k++)
+        mlaunch_bin_index(m->stream, V.tab[k], V.cnt + k, ub, vb, m->p.match_binsize, V.off[k], V.ids[k],
+                          m->cursor);
+    V.nbins = nb;
+    return SVH_OK;
+}
+
+// M9  Matcher::removeOutliers   matcher.cpp:1383-1570 (host: Delaunay + edge votes)
+static int remove_outliers(const svh_matcher_params& p, std::vector<svh_p_match>& pm, int32_t method) {
+    if (pm.size() <= 3) return SVH_OK;
+    const int32_t n = (int32_t)pm.size();
+    std::vector<float> pts((size_t)2 * n);
+    for (int32_t i = 0; i < n; i++) {
+        pts[2 * i] = pm[i].u1c;
+        pts[2 * i + 1] = pm[i].v1c;
+    }
+    std::vector<int32_t> tri((size_t)3 * (2 * n + 16));
+    const int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 16);
+    if (nt < 0) return mfail(SVH_ERR_UNSUPPORTED, "outlier triangulation failed");
+    std::vector<int32_t> votes(n, 0);
+    const float ft = (float)p.outlier_flow_tolerance, dt = (float)p.outlier_disp_tolerance;
+    for (int32_t t = 0; t < nt; t++) {
+        const int32_t* c = &tri[3 * t];
+        static const int e[3][2] = {{0, 1}, {1, 2}, {0, 2}};
+        for (int k = 0; k < 3; k++) {
+            const svh_p_match& a = pm[c[e[k][0]]];
+            const svh_p_match& b = pm[c[e[k][1]]];
+            bool ok = true;
+            if (method == 1) {
+                ok = fabsf((a.u1c - a.u2c) - (b.u1c - b.u2c)) < dt;
+            } else {
+                if (method == 2) ok = fabsf((a.u1p - a.u2p) - (b.u1p - b.u2p)) < dt;
+                const float fu = (a.u1c - a.u1p) - (b.u1c - b.u1p), fv = (a.v1c - a.v1p) - (b.v1c - b.v1p);
+                ok = ok && fabsf(fu) + fabsf(fv) < ft;
+            }
+            if (ok) {
+                votes[c[e[k][0]]]++;
+                votes[c[e[k][1]]]++;
+            }
+        }
+    }
+    size_t w = 0;
+    for (int32_t i = 0; i < n; i++)
+        if (votes[i] >= 4) pm[w++] = pm[i];
+    pm.resize(w);
+    return SVH_OK;
+}
+
+// M10  Matcher::computePriorStatistics   matcher.cpp:882-1032
+static void prior_statistics(svh_matcher* m, const std::vector<svh_p_match>& pm, int32_t method,
+                             int32_t ub, int32_t vb) {
+    const svh_matcher_params& p = m->p;
+    const int32_t stages = method == 2 ? 4 : 2, nb = ub * vb;
+    const float big = 1000000.f;
+    std::vector<float> lo((size_t)nb * 8, big), hi((size_t)nb * 8, -big);
+    std::vector<uint8_t> seen(nb, 0);
+    const float bs = (float)p.match_binsize;
+    for (const svh_p_match& it : pm) {
+        float d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (method == 0) {
+            d[0] = it.u1p - it.u1c; d[1] = it.v1p - it.v1c; d[2] = it.u1c - it.u1p; d[3] = it.v1c - it.v1p;
+        } else if (method == 1) {
+            d[0] = it.u2c - it.u1c; d[2] = it.u1c - it.u2c;
+        } else {
+            d[0] = it.u2p - it.u1p;
+            d[2] = it.u2c - it.u2p; d[3] = it.v2c - it.v2p;
+            d[4] = it.u1c - it.u2c;
+            d[6] = it.u1p - it.u1c; d[7] = it.v1p - it.v1c;
+        }
+        const float ru = method < 2 ? it.u1c : it.u1p, rv = method < 2 ? it.v1c : it.v1p;
+        const int32_t cu = (int32_t)floorf(ru / bs), cv = (int32_t)floorf(rv / bs);
+        auto cl = [](int32_t x, int32_t n) { return std::min(std::max(x, 0), n - 1); };
+        for (int32_t vbn = cl(cv - 1, vb); vbn <= cl(cv + 1, vb); vbn++)
+            for (int32_t ubn = cl(cu - 1, ub); ubn <= cl(cu + 1, ub); ubn++) {
+                const size_t b = (size_t)vbn * ub + ubn;
+                seen[b] = 1;
+                for (int k = 0; k < stages * 2; k++) {
+                    if (d[k] < lo[b * 8 + k]) lo[b * 8 + k] = d[k];
+                    if (d[k] > hi[b * 8 + k]) hi[b * 8 + k] = d[k];
+                }
+            }
+    }
+    m->ranges.assign((size_t)nb * 16, 0.f);
+    for (int32_t b = 0; b < nb; b++)
+        for (int i = 0; i < stages; i++)
+            for (int ax = 0; ax < 2; ax++) {
+                float mn = seen[b] ? lo[(size_t)b * 8 + 2 * i + ax] : (float)-p.match_radius;
+                float mx = seen[b] ? hi[(size_t)b * 8 + 2 * i + ax] : (float)+p.match_radius;
+                const float span = mx - mn;
+                if (span < 20) {   // search window of at least 20 px
+                    mn -= ceilf((20 - span) / 2);
+                    mx += ceilf((20 - span) / 2);
+                }
+                // layout: u_min[4], u_max[4], v_min[4], v_max[4]
+                m->ranges[(size_t)b * 16 + (ax ? 8 : 0) + i] = mn;
+                m->ranges[(size_t)b * 16 + (ax ? 12 : 4) + i] = mx;
+            }
+}
+
+static FeatView view_of(const DevView& V, int dense) {
+    FeatView f;
+    f.rec = V.tab[dense];
+    f.count = V.cnt + dense;
+    f.off = V.off[dense];
+    f.ids = V.ids[dense];
+    return f;
+}
+
+static SobelView sobel_of(const DevView& V, bool half) {
+    SobelView s;
+    s.du = half ? V.du_full : V.du;
+    s.dv = half ? V.dv_full : V.dv;
+    s.w = V.w; s.h = V.h; s.bpl = V.bpl;
+    return s;
+}
+
+// one matching() pass on the device; result copied to `out`
+static int run_matching(svh_matcher* m, int dense, int32_t method, bool use_prior, const double* Tr,
+                        std::vector<svh_p_match>& out, bool refine, std::vector<svh_p_match>* raw_tap) {
+    const svh_matcher_params& p = m->p;
+    hipStream_t s = m->stream;
+    MatchParams P;
+    memset(&P, 0, sizeof(P));
+    P.method = method;
+    P.width = m->dims_c[0];
+    P.height = m->dims_c[1];
+    P.ub = (int32_t)ceilf((float)m->dims_c[0] / (float)p.match_binsize);
+    P.vb = (int32_t)ceilf((float)m->dims_c[1] / (float)p.match_binsize);
+    P.binsize = p.match_binsize;
+    P.match_radius = p.match_radius;
+    P.match_disp_tolerance = p.match_disp_tolerance;
+    P.has_tr = Tr ? 1 : 0;
+    P.f = p.f; P.cu = p.cu; P.cv = p.cv; P.base = p.base;
+    if (Tr) memcpy(P.tr, Tr, sizeof(P.tr));
+    const DevView& q = method == 2 ? m->prev[0] : m->cur[0];
+    const int32_t nq = q.n[dense];
+    int rc = ensure_scratch(m, 0, std::max(nq, 1), method < 2 ? (size_t)P.width * P.height : 0);
+    if (rc) return rc;
+    mlaunch_match(s, P, view_of(m->prev[0], dense), view_of(m->prev[1], dense), view_of(m->cur[0], dense),
+                  view_of(m->cur[1], dense), nq, m->ranges_dev, use_prior ? 1 : 0, m->pm_slots, m->pm_flags,
+                  m->pixel_owner, m->pm_out, m->pm_count);
+    int32_t count = 0;
+    if (refine && raw_tap) {
+        HIP_TRY(hipMemcpyAsync(&count, m->pm_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        raw_tap->resize(count);
+        if (count)
+            HIP_TRY(hipMemcpy(raw_tap->data(), m->pm_out, count * sizeof(svh_p_match), hipMemcpyDeviceToHost));
+    }
+    if (refine) {
+        const bool half = p.half_resolution != 0;
+        mlaunch_refine(s, m->pm_out, m->pm_count, nq, method, m->margin, sobel_of(m->prev[0], half),
+                       sobel_of(m->prev[1], half), sobel_of(m->cur[0], half), sobel_of(m->cur[1], half));
+    }
+    HIP_TRY(hipMemcpyAsync(&count, m->pm_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    out.resize(count);
+    if (count) HIP_TRY(hipMemcpy(out.data(), m->pm_out, count * sizeof(svh_p_match), hipMemcpyDeviceToHost));
+    if (!refine && raw_tap) *raw_tap = out;
+    return SVH_OK;
+}
+
+}  // namespace svh
+
+extern "C" {
+
+void svh_matcher_params_default(svh_matcher_params* p) {
+    // Matcher::parameters::parameters()   libviso2/src/matcher.h:56-68
+    p->nms_n = 3;
+    p->nms_tau = 50;
+    p->match_binsize = 50;
+    p->match_radius = 200;
+    p->match_disp_tolerance = 2;
+    p->outlier_disp_tolerance = 5;
+    p->outlier_flow_tolerance = 5;
+    p->multi_stage = 1;
+    p->half_resolution = 1;
+    p->refinement = 1;
+    p->f = p->cu = p->cv = p->base = 0;
+}
+
+svh_matcher* svh_matcher_create(const svh_matcher_params* p) {
+    if (!p) return nullptr;
+    svh_matcher* m = new svh_matcher();
+    m->p = *p;
+    m->margin = 8 + 1;                                      // matcher.cpp:56
+    if (p->half_resolution) m->p.match_radius /= 2;         // matcher.cpp:59-62
+    m->device = 0;
+    (void)hipGetDevice(&m->device);
+    m->stream = nullptr;
+    memset(m->dims_p, 0, sizeof(m->dims_p));
+    memset(m->dims_c, 0, sizeof(m->dims_c));
+    return m;
+}
+
+void svh_matcher_destroy(svh_matcher* m) {
+    if (!m) return;
+    if (m->stream) {
+        (void)hipSetDevice(m->device);
+        (void)hipStreamSynchronize(m->stream);
+        for (int k = 0; k < 2; k++) {
+            m->prev[k].release();
+            m->cur[k].release();
+        }
+        (void)hipFree(m->slots); (void)hipFree(m->flags); (void)hipFree(m->cursor); (void)hipFree(m->pm_slots);
+        (void)hipFree(m->pm_out); (void)hipFree(m->pm_flags); (void)hipFree(m->pm_count);
+        (void)hipFree(m->pixel_owner); (void)hipFree(m->ranges_dev); (void)hipHostFree(m->h_stage);
+        (void)hipStreamDestroy(m->stream);
+    }
+    delete m;
+}
+
+void svh_matcher_set_intrinsics(svh_matcher* m, double f, double cu, double cv, double base) {
+    if (!m) return;
+    m->p.f = f; m->p.cu = cu; m->p.cv = cv; m->p.base = base;
+}
+
+int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* I2, const int32_t* dims,
+                              int32_t replace) {
+    if (!m || !dims) return mfail(SVH_ERR_BAD_ARG, "null argument");
+    const int32_t w = dims[0], h = dims[1], pitch = dims[2];
+    if (w <= 0 || h <= 0 || pitch < w || I1 == 0) {
+        // matcher.cpp:110-114
+        fprintf(stderr, "ERROR: Image dimension mismatch!\n");
+        return SVH_ERR_BAD_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return mfail(SVH_ERR_NO_DEVICE, "no HIP device visible: libsvhip has no CPU fallback");
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->stream) HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    if (!replace) {
+        // ring buffer: current -> previous; the old previous buffers are recycled
+        for (int k = 0; k < 2; k++) {
+            std::swap(m->prev[k], m->cur[k]);
+            m->cur[k].valid = false;
+        }
+        memcpy(m->dims_p, m->dims_c, sizeof(m->dims_p));
+    } else {
+        m->cur[0].valid = m->cur[1].valid = false;
+    }
+    m->dims_c[0] = w;
+    m->dims_c[1] = h;
+    m->dims_c[2] = w + 16 - w % 16;   // +16 even when w % 16 == 0 (matcher.cpp:173)
+    const uint8_t* src[2] = {I1, I2};
+    for (int k = 0; k < 2; k++) {
+        if (!src[k]) continue;
+        int rc = ensure_view(m, m->cur[k], w, h, m->dims_c[2]);
+        if (rc) return rc;
+        rc = compute_features(m, m->cur[k], src[k], pitch);
+        if (rc) return rc;
+    }
+    return SVH_OK;
+}
+
+int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double* Tr) {
+    if (!m) return mfail(SVH_ERR_BAD_ARG, "null argument");
+    const svh_matcher_params& p = m->p;
+    if (p.refinement == 2)
+        return mfail(SVH_ERR_UNSUPPORTED, "refinement=2 (parabolic fitting) is not implemented on the device");
+    // sanity checks: return silently, previous matches stay (matcher.cpp:216-259)
+    auto missing = [&](const DevView& V, int dense) { return !V.valid || V.n[dense] == 0; };
+    const bool need_1p = method == 0 || method >= 2, need_2p = method >= 2;
+    const bool need_2c = method >= 1;
+    for (int dense = 1; dense >= (p.multi_stage ? 0 : 1); dense--) {
+        if (need_1p && missing(m->prev[0], dense)) return SVH_OK;
+        if (need_2p && missing(m->prev[1], dense)) return SVH_OK;
+        if (missing(m->cur[0], dense)) return SVH_OK;
+        if (need_2c && missing(m->cur[1], dense)) return SVH_OK;
+    }
+    if (method > 2) method = 2;
+    HIP_TRY(hipSetDevice(m->device));
+    for (int s = 0; s < SVH_M_STAGE_COUNT; s++) m->stage[s].clear();
+    m->m1.clear();
+    m->m2.clear();
+    const int32_t ub = (int32_t)ceilf((float)m->dims_c[0] / (float)p.match_binsize);
+    const int32_t vb = (int32_t)ceilf((float)m->dims_c[1] / (float)p.match_binsize);
+    DevView* views[4] = {&m->prev[0], &m->prev[1], &m->cur[0], &m->cur[1]};
+    const bool used[4] = {need_1p, need_2p, true, need_2c};
+    // an unused view may be empty: give it valid (empty) bin tables anyway
+    for (int v = 0; v < 4; v++) {
+        if (!views[v]->valid && !used[v]) continue;
+        if (!views[v]->valid) continue;
+        int rc = ensure_bins(m, *views[v], ub, vb);
+        if (rc) return rc;
+    }
+    if (ub * vb > m->ranges_cap) {
+        (void)hipFree(m->ranges_dev);
+        HIP_TRY(dalloc(&m->ranges_dev, (size_t)16 * ub * vb));
+        m->ranges_cap = ub * vb;
+    }
+    int rc;
+    if (p.multi_stage) {
+        rc = run_matching(m, 0, method, false, Tr, m->m1, false, &m->stage[SVH_M_SPARSE_RAW]);
+        if (rc) return rc;
+        rc = remove_outliers(p, m->m1, method);
+        if (rc) return rc;
+        m->stage[SVH_M_SPARSE] = m->m1;
+        prior_statistics(m, m->m1, method, ub, vb);
+        HIP_TRY(hipMemcpyAsync(m->ranges_dev, m->ranges.data(), m->ranges.size() * sizeof(float),
+                               hipMemcpyHostToDevice, m->stream));
+        rc = run_matching(m, 1, method, true, Tr, m->m2, p.refinement > 0, &m->stage[SVH_M_DENSE_RAW]);
+    } else {
+        rc = run_matching(m, 1, method, false, Tr, m->m2, p.refinement > 0, &m->stage[SVH_M_DENSE_RAW]);
+    }
+    if (rc) return rc;
+    m->stage[SVH_M_DENSE_REFINED] = m->m2;
+    rc = remove_outliers(p, m->m2, method);
+    if (rc) return rc;
+    m->stage[SVH_M_DENSE] = m->m2;
+    return SVH_OK;
+}
+
+// Matcher::bucketFeatures   matcher.cpp:297-343 (host; std::random_shuffle like the reference)
+int32_t svh_matcher_bucket_features(svh_matcher* m, int32_t max_features, float bw, float bh) {
+    if (!m) return 0;
+    float u_max = 0, v_max = 0;
+    for (const svh_p_match& q : m->m2) {
+        if (q.u1c > u_max) u_max = q.u1c;
+        if (q.v1c > v_max) v_max = q.v1c;
+    }
+    const int32_t cols = (int32_t)floorf(u_max / bw) + 1, rows = (int32_t)floorf(v_max / bh) + 1;
+    std::vector<std::vector<svh_p_match>> buckets((size_t)cols * rows);
+    for (const svh_p_match& q : m->m2)
+        buckets[(size_t)((int32_t)floorf(q.v1c / bh)) * cols + (int32_t)floorf(q.u1c / bw)].push_back(q);
+    m->m2.clear();
+    for (auto& b : buckets) {
+        // same shuffle as std::random_shuffle(first,last) of libstdc++: rand() % (i+1)
+        for (size_t i = 1; i < b.size(); i++) std::swap(b[i], b[(size_t)rand() % (i + 1)]);
+        for (size_t i = 0; i < b.size() && (int32_t)i < max_features; i++) m->m2.push_back(b[i]);
+    }
+    return (int32_t)m->m2.size();
+}
+
+int32_t svh_matcher_get_matches(svh_matcher* m, svh_p_match* out, int32_t cap) {
+    if (!m) return 0;
+    for (int32_t i = 0; i < (int32_t)m->m2.size() && i < cap && out; i++) out[i] = m->m2[i];
+    return (int32_t)m->m2.size();
+}
+
+// Matcher::getGain + mean   matcher.cpp:347-389, 1825-1837
+float svh_matcher_get_gain(svh_matcher* m, const int32_t* inliers, int32_t n) {
+    if (!m || !m->prev[0].valid || !m->cur[0].valid || m->m2.empty() || n == 0) return 1;
+    auto meanf = [](const DevView& V, int32_t u0, int32_t u1, int32_t v0, int32_t v1) {
+        float s = 0;
+        for (int32_t v = v0; v <= v1; v++)
+            for (int32_t u = u0; u <= u1; u++) s += (float)V.host[(size_t)v * V.bpl + u];
+        return s /= (float)((u1 - u0 + 1) * (v1 - v0 + 1));
+    };
+    auto cl = [](int32_t x, int32_t hi) { return std::min(std::max(x, 0), hi); };
+    float gain = 0;
+    int32_t num = 0;
+    for (int32_t q = 0; q < n; q++) {
+        if (inliers[q] >= (int32_t)m->m2.size()) continue;
+        const svh_p_match& it = m->m2[inliers[q]];
+        const int32_t W = m->dims_p[0], H = m->dims_p[1];
+        const float mp = meanf(m->prev[0], cl((int32_t)it.u1p - 3, W), cl((int32_t)it.u1p + 3, W),
+                               cl((int32_t)it.v1p - 3, H), cl((int32_t)it.v1p + 3, H));
+        const float mc = meanf(m->cur[0], cl((int32_t)it.u1c - 3, W), cl((int32_t)it.u1c + 3, W),
+                               cl((int32_t)it.v1c - 3, H), cl((int32_t)it.v1c + 3, H));
+        if (mp > 10) {
+            gain += mc / mp;
+            num++;
+        }
+    }
+    return num > 0 ? gain / (float)num : 1;
+}
+
+int32_t svh_matcher_get_features(svh_matcher* m, int32_t table, int32_t* out, int32_t cap) {
+    if (!m || table < 0 || table > 7) return SVH_ERR_BAD_ARG;
+    DevView& V = (table < 4 ? m->prev : m->cur)[(table >> 1) & 1];
+    const int dense = table & 1;
+    if (!V.valid) return 0;
+    const int32_t n = V.n[dense];
+    if (out && n > 0) {
+        if (hipSetDevice(m->device) != hipSuccess) return SVH_ERR_HIP;
+        if (hipMemcpy(out, V.tab[dense], sizeof(int32_t) * 12 * std::min(n, cap), hipMemcpyDeviceToHost) !=
+            hipSuccess)
+            return mfail(SVH_ERR_HIP, "feature table copy failed");
+    }
+    return n;
+}
+
+int32_t svh_matcher_get_stage(svh_matcher* m, int32_t stage, void* buf, size_t cap, size_t* size) {
+    if (!m || stage < 0 || stage >= SVH_M_STAGE_COUNT) return SVH_ERR_BAD_ARG;
+    const void* src;
+    size_t n;
+    if (stage == SVH_M_RANGES) {
+        src = m->ranges.data();
+        n = m->ranges.size() * sizeof(float);
+    } else {
+        src = m->stage[stage].data();
+        n = m->stage[stage].size() * sizeof(svh_p_match);
+    }
+    if (size) *size = n;
+    if (!buf) return SVH_OK;
+    if (cap < n) return mfail(SVH_ERR_BAD_ARG, "stage buffer too small");
+    if (n) memcpy(buf, src, n);
+    return SVH_OK;
+}
+
+int32_t svh_matcher_get_filter(svh_matcher* m, int32_t which, void* buf, size_t cap, size_t* size,
+                               int32_t* dims3) {
+    if (!m || which < 0 || which > 5) return SVH_ERR_BAD_ARG;
+    const DevView& V = m->cur[0];
+    if (!V.valid) return SVH_ERR_BAD_ARG;
+    const bool full = which == 2 || which == 3;
+    if (full && !V.du_full) return SVH_ERR_BAD_ARG;
+    const int32_t d[3] = {full ? V.w : V.mw, full ? V.h : V.mh, full ? V.bpl : V.mbpl};
+    const void* src[6] = {V.du, V.dv, V.du_full, V.dv_full, V.f1, V.f2};
+    const size_t n = (size_t)d[2] * d[1] * (which >= 4 ? 2 : 1);
+    if (size) *size = n;
+    if (dims3) memcpy(dims3, d, sizeof(d));
+    if (!buf) return SVH_OK;
+    if (cap < n) return mfail(SVH_ERR_BAD_ARG, "filter buffer too small");
+    if (hipSetDevice(m->device) != hipSuccess ||
+        hipMemcpy(buf, src[which], n, hipMemcpyDeviceToHost) != hipSuccess)
+        return mfail(SVH_ERR_HIP, "filter image copy failed");
+    return SVH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// Internal declarations of the Matcher path (kernels <-> engine).
+#ifndef SVH_MATCHER_INTERNAL_H
+#define SVH_MATCHER_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/svh.h"
+
+namespace svh {
+
+// a feature table on the device with its bin index (CSR over class x v_bin x u_bin)
+struct FeatView {
+    const int32_t* rec;     // [n][12]: u, v, 0, class, d1..d8
+    const int32_t* count;   // device-resident n
+    const int32_t* off;     // [4*vb*ub + 1]
+    const int32_t* ids;     // feature indices, ascending inside each bin
+};
+
+// Sobel images used by the refinement (full resolution when half_resolution is on)
+struct SobelView {
+    const uint8_t* du;
+    const uint8_t* dv;
+    int32_t w, h, bpl;
+};
+
+struct MatchParams {
+    int32_t method;
+    int32_t width, height;        // current frame (bin grid, pixel-owner map)
+    int32_t ub, vb, binsize;
+    int32_t match_radius, match_disp_tolerance;
+    int32_t has_tr;
+    double f, cu, cv, base;
+    double tr[12];                // rows 0..2 of Tr_delta
+};
+
+void mlaunch_half(void* stream, const uint8_t* I, int bpl, uint8_t* out, int hw, int hh, int hbpl);
+// f1 == nullptr: Sobel only
+void mlaunch_filters(void* stream, const uint8_t* I, int w, int h, int bpl, uint8_t* du, uint8_t* dv,
+                     int16_t* f1, int16_t* f2);
+int  mnms_blocks(int extent, int n, int margin);
+void mlaunch_features(void* stream, const int16_t* f1, const int16_t* f2, const uint8_t* du,
+                      const uint8_t* dv, int w, int h, int bpl, int n, int tau, int margin, int scale,
+                      int4* slots, int32_t* flags, int32_t* table, int32_t* count);
+void mlaunch_bin_index(void* stream, const int32_t* table, const int32_t* count, int ub, int vb,
+                       int binsize, int32_t* off, int32_t* ids, int32_t* cursor);
+void mlaunch_match(void* stream, const MatchParams& P, const FeatView& m1p, const FeatView& m2p,
+                   const FeatView& m1c, const FeatView& m2c, int nquery_cap, const float* ranges,
+                   int use_prior, svh_p_match* slots, int32_t* flags, int32_t* pixel_owner,
+                   svh_p_match* out, int32_t* out_count);
+void mlaunch_refine(void* stream, svh_p_match* m, const int32_t* count, int cap, int method, int margin,
+                    const SobelView& s1p, const SobelView& s2p, const SobelView& s1c,
+                    const SobelView& s2c);
+
+int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap);
+
+}  // namespace svh
+#endif

@@ -1,0 +1,575 @@
+// HIP kernels (gfx950) of the libviso2 Matcher path: feature extraction for
+// Matcher::pushBack and the circular matcher / refinement of
+// Matcher::matchFeatures.  Integer stencil, rank and SAD work; bit-exact with
+// the reference, including the ORDER of the feature lists (match indices are
+// positions in those lists):
+//   * non-maximum suppression writes one slot per (block, class) in the
+//     reference's scan order (u-block outer, v-block inner, classes f1min,
+//     f1max, f2min, f2max) and an order-preserving compaction packs them;
+//   * bin index lists are kept in ascending feature index, candidate bins are
+//     walked u outer / v inner, strict "<" keeps the first minimum.
+// Each kernel cites the reference lines whose result it reproduces.
+#include <hip/hip_runtime.h>
+
+#include "matcher_internal.h"
+
+namespace svh {
+
+namespace {
+
+__device__ __forceinline__ int32_t sat_u8(int32_t x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
+
+// ---------------------------------------------------------------------------
+// M1  Matcher::createHalfResolutionImage   libviso2/src/matcher.cpp:760-776
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_half(const uint8_t* __restrict__ I, int bpl,
+                                              uint8_t* __restrict__ out, int hw, int hh, int hbpl) {
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= hw || y >= hh) return;
+    const uint8_t* r0 = I + (size_t)(2 * y) * bpl + 2 * x;
+    const uint8_t* r1 = r0 + bpl;
+    out[(size_t)y * hbpl + x] = (uint8_t)(((int)r0[0] + r0[1] + r1[0] + r1[1]) / 4);
+}
+
+// ---------------------------------------------------------------------------
+// M2  filter::sobel5x5   libviso2/src/filter.cpp:474 (+306-361, 154-222, 93-152)
+// M3  filter::blob5x5 / checkerboard5x5   filter.cpp:507-532, 492-497
+// One 64x16 tile per block; the 8-bit tile with a 2-pixel halo is staged in LDS
+// and all four 5x5 responses are taken from it.  Defined on rows 2..h-3, cols
+// 2..w-3 (0 elsewhere), which covers everything the matcher ever reads.
+// ---------------------------------------------------------------------------
+constexpr int FX = 64, FY = 16;
+
+template <bool kFeatures>
+__global__ __launch_bounds__(256) void k_filters(const uint8_t* __restrict__ I, int w, int h, int bpl,
+                                                 uint8_t* __restrict__ du, uint8_t* __restrict__ dv,
+                                                 int16_t* __restrict__ f1, int16_t* __restrict__ f2) {
+    __shared__ uint8_t s[FY + 4][FX + 8];
+    const int x0 = blockIdx.x * FX, y0 = blockIdx.y * FY;
+    const int tid = threadIdx.y * FX + threadIdx.x;
+    for (int i = tid; i < (FY + 4) * (FX + 4); i += 256) {
+        const int r = i / (FX + 4), c = i - r * (FX + 4);
+        const int y = y0 - 2 + r, x = x0 - 2 + c;
+        s[r][c] = (x >= 0 && x < w && y >= 0 && y < h) ? I[(size_t)y * bpl + x] : 0;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= w) return;
+#pragma unroll
+    for (int k = 0; k < FY / 4; k++) {
+        const int ty = threadIdx.y + 4 * k, y = y0 + ty;
+        if (y >= h) break;
+        int odu = 0, odv = 0, of1 = 0, of2 = 0;
+        if (x >= 2 && x < w - 2 && y >= 2 && y < h - 2) {
+            int p[5][5];
+#pragma unroll
+            for (int r = 0; r < 5; r++)
+#pragma unroll
+                for (int c = 0; c < 5; c++) p[r][c] = s[ty + r][threadIdx.x + c];
+            int S[5], T[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                S[c] = p[0][c] + 4 * p[1][c] + 6 * p[2][c] + 4 * p[3][c] + p[4][c];  // vertical 1 4 6 4 1
+                T[c] = p[0][c] + 2 * p[1][c] - 2 * p[3][c] - p[4][c];                // vertical 1 2 0 -2 -1
+            }
+            odu = sat_u8(((S[0] + 2 * S[1] - 2 * S[3] - S[4]) >> 7) + 128);
+            odv = sat_u8(((T[0] + 4 * T[1] + 6 * T[2] + 4 * T[3] + T[4]) >> 7) + 128);
+            if (kFeatures) {
+                int s5 = 0, s3 = 0, ck = 0;
+#pragma unroll
+                for (int r = 0; r < 5; r++)
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        s5 += p[r][c];
+                        if (r >= 1 && r <= 3 && c >= 1 && c <= 3) s3 += p[r][c];
+                        const int sr = r < 2 ? 1 : (r > 2 ? -1 : 0), sc = c < 2 ? 1 : (c > 2 ? -1 : 0);
+                        ck += sr * sc * p[r][c];
+                    }
+                of1 = -s5 + 2 * s3 + 7 * p[2][2];
+                of2 = ck;
+            }
+        }
+        const size_t o = (size_t)y * bpl + x;
+        du[o] = (uint8_t)odu;
+        dv[o] = (uint8_t)odv;
+        if (kFeatures) {
+            f1[o] = (int16_t)of1;
+            f2[o] = (int16_t)of2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// M4  Matcher::nonMaximumSuppression   matcher.cpp:395-530
+// One thread per (n+1)x(n+1) block.  Slot = (iblock*nj + jblock)*4 + class.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nms(const int16_t* __restrict__ f1,
+                                             const int16_t* __restrict__ f2, int w, int h, int bpl,
+                                             int n, int tau, int margin, int ni, int nj,
+                                             int4* __restrict__ slots, int32_t* __restrict__ flags) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= ni * nj) return;
+    const int ib = b / nj, jb = b - ib * nj;
+    const int i = n + margin + ib * (n + 1), j = n + margin + jb * (n + 1);
+    const int16_t* F[2] = {f1, f2};
+    int mini[2], minj[2], maxi[2], maxj[2], minv[2], maxv[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        mini[k] = maxi[k] = i;
+        minj[k] = maxj[k] = j;
+        minv[k] = maxv[k] = F[k][(size_t)j * bpl + i];
+    }
+    for (int i2 = i; i2 <= i + n; i2++)
+        for (int j2 = j; j2 <= j + n; j2++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int c = F[k][(size_t)j2 * bpl + i2];
+                if (c < minv[k]) {
+                    mini[k] = i2; minj[k] = j2; minv[k] = c;
+                } else if (c > maxv[k]) {
+                    maxi[k] = i2; maxj[k] = j2; maxv[k] = c;
+                }
+            }
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++) {
+            const bool is_min = mm == 0;
+            const int ci = is_min ? mini[k] : maxi[k], cj = is_min ? minj[k] : maxj[k];
+            const int cv = is_min ? minv[k] : maxv[k];
+            const int ie = min(ci + n, w - 1 - margin), je = min(cj + n, h - 1 - margin);
+            bool ok = true;
+            for (int i2 = ci - n; ok && i2 <= ie; i2++)
+                for (int j2 = cj - n; j2 <= je; j2++) {
+                    const int c = F[k][(size_t)j2 * bpl + i2];
+                    const bool beats = is_min ? c < cv : c > cv;
+                    if (beats && (i2 < i || i2 > i + n || j2 < j || j2 > j + n)) {
+                        ok = false;
+                        break;
+                    }
+                }
+            ok = ok && (is_min ? cv <= -tau : cv >= tau);
+            const int slot = b * 4 + 2 * k + mm;
+            flags[slot] = ok ? 1 : 0;
+            if (ok) slots[slot] = make_int4(ci, cj, cv, 2 * k + mm);
+        }
+}
+
+// ---------------------------------------------------------------------------
+// Order-preserving compaction by one workgroup: thread t owns a contiguous
+// chunk of slots, an LDS scan of the per-thread counts gives its output base.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int block_exclusive_scan_1024(int value, int* total) {
+    __shared__ int s_scan[1024];
+    const int t = threadIdx.x;
+    s_scan[t] = value;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int add = t >= off ? s_scan[t - off] : 0;
+        __syncthreads();
+        s_scan[t] += add;
+        __syncthreads();
+    }
+    *total = s_scan[1023];
+    return s_scan[t] - value;
+}
+
+// M5  descriptor + record packing   matcher.cpp:534-579, 854-877
+__global__ __launch_bounds__(1024) void k_compact_features(const int4* __restrict__ slots,
+                                                           const int32_t* __restrict__ flags,
+                                                           int nslots, const uint8_t* __restrict__ du,
+                                                           const uint8_t* __restrict__ dv, int bpl,
+                                                           int scale, int32_t* __restrict__ table,
+                                                           int32_t* __restrict__ count) {
+    const int t = threadIdx.x;
+    const int chunk = (nslots + 1023) / 1024;
+    const int lo = t * chunk, hi = min(lo + chunk, nslots);
+    int mine = 0;
+    for (int s = lo; s < hi; s++) mine += flags[s];
+    int total;
+    int base = block_exclusive_scan_1024(mine, &total);
+    for (int s = lo; s < hi; s++) {
+        if (!flags[s]) continue;
+        const int4 m = slots[s];
+        int32_t* rec = table + (size_t)12 * base++;
+        rec[0] = m.x * scale;
+        rec[1] = m.y * scale;
+        rec[2] = 0;
+        rec[3] = m.w;
+        // 16 (du,dv) pairs around (u, v-1): rows -5,-3,-1,+1,+3,+5 relative to v
+        const ptrdiff_t m1 = (ptrdiff_t)(m.y - 1) * bpl + m.x;
+        const ptrdiff_t m3 = m1 - 2 * bpl, m5 = m3 - 2 * bpl, p1 = m1 + 2 * bpl, p3 = p1 + 2 * bpl,
+                        p5 = p3 + 2 * bpl;
+        const ptrdiff_t at[16] = {m1 - 3, p1 - 3, m1 - 1, p1 - 1, m1 + 3, p1 + 3, m1 + 1, p1 + 1,
+                                  m5 - 1, p5 - 1, m5 + 1, p5 + 1, m3 - 5, p3 - 5, m3 + 5, p3 + 5};
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t b0 = du[at[2 * q]], b1 = dv[at[2 * q]];
+            const uint32_t b2 = du[at[2 * q + 1]], b3 = dv[at[2 * q + 1]];
+            rec[4 + q] = (int32_t)(b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+        }
+    }
+    if (t == 0) *count = total;
+}
+
+// ---------------------------------------------------------------------------
+// M6  Matcher::createIndexVector   matcher.cpp:1036-1057
+// CSR over class x v_bin x u_bin; every list ends up in ascending feature index
+// (the reference's push_back order).  One workgroup per table.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_bin_index(const int32_t* __restrict__ table,
+                                                    const int32_t* __restrict__ count, int ub, int vb,
+                                                    int binsize, int32_t* __restrict__ off,
+                                                    int32_t* __restrict__ ids,
+                                                    int32_t* __restrict__ cursor) {
+    const int n = *count, nb = 4 * ub * vb, t = threadIdx.x;
+    for (int b = t; b <= nb; b += 1024) off[b] = 0;
+    for (int b = t; b < nb; b += 1024) cursor[b] = 0;
+    __syncthreads();
+    auto bin_of = [&](int i) {
+        const int32_t* r = table + (size_t)12 * i;
+        int u_bin = (int)floorf(__fdiv_rn((float)r[0], (float)binsize));
+        int v_bin = (int)floorf(__fdiv_rn((float)r[1], (float)binsize));
+        u_bin = u_bin < ub - 1 ? u_bin : ub - 1;
+        v_bin = v_bin < vb - 1 ? v_bin : vb - 1;
+        return (r[3] * vb + v_bin) * ub + u_bin;
+    };
+    for (int i = t; i < n; i += 1024) atomicAdd(&off[bin_of(i) + 1], 1);
+    __syncthreads();
+    if (t == 0)
+        for (int b = 0; b < nb; b++) off[b + 1] += off[b];
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {
+        const int b = bin_of(i);
+        ids[off[b] + atomicAdd(&cursor[b], 1)] = i;
+    }
+    __syncthreads();
+    for (int b = t; b < nb; b += 1024) {   // short lists: insertion sort to ascending index
+        const int lo = off[b], hi = off[b + 1];
+        for (int a = lo + 1; a < hi; a++) {
+            const int key = ids[a];
+            int q = a - 1;
+            while (q >= lo && ids[q] > key) {
+                ids[q + 1] = ids[q];
+                q--;
+            }
+            ids[q + 1] = key;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// M7  Matcher::findMatch   matcher.cpp:1061-1157
+// Sequential walk in the reference's order: u_bin outer, v_bin inner, list order,
+// strict "<" on a double cost.  fp64 / fp32 expressions use the non-contracted
+// IEEE intrinsics so windows and predicted-position costs round identically.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sad32(const int32_t* a, const int32_t* b) {
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s = __builtin_amdgcn_sad_u8((uint32_t)a[k], (uint32_t)b[k], s);
+    return s;
+}
+
+__device__ int find_match(const MatchParams& P, const FeatView& t1, int i1, const FeatView& t2,
+                          const float* __restrict__ ranges, int stat_bin, int stage, bool flow,
+                          bool use_prior, double u_, double v_) {
+    int min_ind = 0;
+    double min_cost = 10000000;
+    const int32_t* r1 = t1.rec + (size_t)12 * i1;
+    const int u1 = r1[0], v1 = r1[1], c = r1[3];
+    int32_t d1[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) d1[k] = r1[4 + k];
+    float u_min, u_max, v_min, v_max;
+    if (use_prior) {
+        const float* rg = ranges + (size_t)16 * stat_bin;   // u_min[4],u_max[4],v_min[4],v_max[4]
+        u_min = __fadd_rn((float)u1, rg[0 + stage]);
+        u_max = __fadd_rn((float)u1, rg[4 + stage]);
+        v_min = __fadd_rn((float)v1, rg[8 + stage]);
+        v_max = __fadd_rn((float)v1, rg[12 + stage]);
+    } else {
+        u_min = (float)(u1 - P.match_radius);
+        u_max = (float)(u1 + P.match_radius);
+        v_min = (float)(v1 - P.match_radius);
+        v_max = (float)(v1 + P.match_radius);
+    }
+    if (!flow) {
+        v_min = (float)(v1 - P.match_disp_tolerance);
+        v_max = (float)(v1 + P.match_disp_tolerance);
+    }
+    const float bs = (float)P.binsize;
+    auto bin = [&](float x, int nb) {
+        int b = (int)floorf(__fdiv_rn(x, bs));
+        b = b > 0 ? b : 0;
+        return b < nb - 1 ? b : nb - 1;
+    };
+    const int ub0 = bin(u_min, P.ub), ub1 = bin(u_max, P.ub);
+    const int vb0 = bin(v_min, P.vb), vb1 = bin(v_max, P.vb);
+    const bool predicted = u_ >= 0 && v_ >= 0;
+    for (int u_bin = ub0; u_bin <= ub1; u_bin++)
+        for (int v_bin = vb0; v_bin <= vb1; v_bin++) {
+            const int b = (c * P.vb + v_bin) * P.ub + u_bin;
+            const int lo = t2.off[b], hi = t2.off[b + 1];
+            for (int q = lo; q < hi; q++) {
+                const int i2 = t2.ids[q];
+                const int32_t* r2 = t2.rec + (size_t)12 * i2;
+                const float u2 = (float)r2[0], v2 = (float)r2[1];
+                if (u2 >= u_min && u2 <= u_max && v2 >= v_min && v2 <= v_max) {
+                    double cost = (double)sad32(d1, r2 + 4);
+                    if (predicted) {
+                        const double du = __dsub_rn((double)r2[0], u_), dv = __dsub_rn((double)r2[1], v_);
+                        const double dist = __dsqrt_rn(__dadd_rn(__dmul_rn(du, du), __dmul_rn(dv, dv)));
+                        cost = __dadd_rn(cost, __dmul_rn(4.0, dist));
+                    }
+                    if (cost < min_cost) {
+                        min_ind = i2;
+                        min_cost = cost;
+                    }
+                }
+            }
+        }
+    return min_ind;
+}
+
+__device__ __forceinline__ int stat_bin_of(const MatchParams& P, int u, int v) {
+    int u_bin = (int)floorf(__fdiv_rn((float)u, (float)P.binsize));
+    int v_bin = (int)floorf(__fdiv_rn((float)v, (float)P.binsize));
+    u_bin = u_bin < P.ub - 1 ? u_bin : P.ub - 1;
+    v_bin = v_bin < P.vb - 1 ? v_bin : P.vb - 1;
+    return v_bin * P.ub + u_bin;
+}
+
+__device__ __forceinline__ svh_p_match mk(float u1p, float v1p, int i1p, float u2p, float v2p, int i2p,
+                                          float u1c, float v1c, int i1c, float u2c, float v2c, int i2c) {
+    svh_p_match m;
+    m.u1p = u1p; m.v1p = v1p; m.i1p = i1p; m.u2p = u2p; m.v2p = v2p; m.i2p = i2p;
+    m.u1c = u1c; m.v1c = v1c; m.i1c = i1c; m.u2c = u2c; m.v2c = v2c; m.i2c = i2c;
+    return m;
+}
+
+// M8  Matcher::matching   matcher.cpp:1161-1379 -- one thread per query feature.
+// flags: 0 = no match, 1 = match.  For flow/stereo the "pixel not matched yet"
+// rule (first query in index order wins) is resolved by k_match_dedupe.
+__global__ __launch_bounds__(128) void k_match(MatchParams P, FeatView m1p, FeatView m2p, FeatView m1c,
+                                               FeatView m2c, const float* __restrict__ ranges,
+                                               int use_prior, svh_p_match* __restrict__ out,
+                                               int32_t* __restrict__ flags,
+                                               int32_t* __restrict__ pixel_owner) {
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    const FeatView& q = P.method == 2 ? m1p : m1c;
+    if (i >= *q.count) return;
+    int ok = 0;
+    svh_p_match m = mk(-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    const int32_t* r = q.rec + (size_t)12 * i;
+    const int uq = r[0], vq = r[1];
+    const int sb = stat_bin_of(P, uq, vq);
+    if (P.method == 0) {
+        const int i1p = find_match(P, m1c, i, m1p, ranges, sb, 0, true, use_prior, -1, -1);
+        const int i1c2 = find_match(P, m1p, i1p, m1c, ranges, sb, 1, true, use_prior, -1, -1);
+        if (i1c2 == i) {
+            const int32_t* rp = m1p.rec + (size_t)12 * i1p;
+            m = mk((float)rp[0], (float)rp[1], i1p, -1, -1, -1, (float)uq, (float)vq, i, -1, -1, -1);
+            ok = 1;
+        }
+    } else if (P.method == 1) {
+        const int i2c = find_match(P, m1c, i, m2c, ranges, sb, 0, false, use_prior, -1, -1);
+        const int i1c2 = find_match(P, m2c, i2c, m1c, ranges, sb, 1, false, use_prior, -1, -1);
+        if (i1c2 == i) {
+            const int32_t* r2 = m2c.rec + (size_t)12 * i2c;
+            if (uq >= r2[0]) {
+                m = mk(-1, -1, -1, -1, -1, -1, (float)uq, (float)vq, i, (float)r2[0], (float)r2[1], i2c);
+                ok = 1;
+            }
+        }
+    } else {
+        const int i2p = find_match(P, m1p, i, m2p, ranges, sb, 0, false, use_prior, -1, -1);
+        const int32_t* r2p = m2p.rec + (size_t)12 * i2p;
+        const int u2p = r2p[0], v2p = r2p[1];
+        double pu = -1, pv = -1, bu = -1, bv = -1;
+        if (P.has_tr) {
+            // predicted position in the current right image (matcher.cpp:1312-1327)
+            double d = __dsub_rn((double)uq, (double)u2p);
+            d = d > 1.0 ? d : 1.0;
+            const double x1p = __ddiv_rn(__dmul_rn(__dsub_rn((double)uq, P.cu), P.base), d);
+            const double y1p = __ddiv_rn(__dmul_rn(__dsub_rn((double)vq, P.cv), P.base), d);
+            const double z1p = __ddiv_rn(__dmul_rn(P.f, P.base), d);
+            const double* T = P.tr;
+            const double x2c = __dsub_rn(__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(T[0], x1p), __dmul_rn(T[1], y1p)),
+                                                             __dmul_rn(T[2], z1p)), T[3]), P.base);
+            const double y2c = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(T[4], x1p), __dmul_rn(T[5], y1p)),
+                                                   __dmul_rn(T[6], z1p)), T[7]);
+            const double z2c = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(T[8], x1p), __dmul_rn(T[9], y1p)),
+                                                   __dmul_rn(T[10], z1p)), T[11]);
+            pu = __dadd_rn(__ddiv_rn(__dmul_rn(P.f, x2c), z2c), P.cu);
+            pv = __dadd_rn(__ddiv_rn(__dmul_rn(P.f, y2c), z2c), P.cv);
+            bu = (double)uq;
+            bv = (double)vq;
+        }
+        const int i2c = find_match(P, m2p, i2p, m2c, ranges, sb, 1, true, use_prior, pu, pv);
+        const int i1c = find_match(P, m2c, i2c, m1c, ranges, sb, 2, false, use_prior, -1, -1);
+        const int i1p2 = find_match(P, m1c, i1c, m1p, ranges, sb, 3, true, use_prior, bu, bv);
+        if (i1p2 == i) {
+            const int32_t* r2c = m2c.rec + (size_t)12 * i2c;
+            const int32_t* r1c = m1c.rec + (size_t)12 * i1c;
+            if (uq >= u2p && r1c[0] >= r2c[0]) {
+                m = mk((float)uq, (float)vq, i, (float)u2p, (float)v2p, i2p, (float)r1c[0], (float)r1c[1], i1c,
+                       (float)r2c[0], (float)r2c[1], i2c);
+                ok = 1;
+            }
+        }
+    }
+    if (ok && P.method < 2) atomicMin(&pixel_owner[(size_t)vq * P.width + uq], i);
+    flags[i] = ok;
+    if (ok) out[i] = m;
+}
+
+// flow / stereo: keep a match only if its query is the first one on its pixel
+__global__ __launch_bounds__(256) void k_match_dedupe(const int32_t* __restrict__ n, int width,
+                                                      const svh_p_match* __restrict__ m,
+                                                      int32_t* __restrict__ flags,
+                                                      const int32_t* __restrict__ pixel_owner) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= *n || !flags[i]) return;
+    const int u = (int)m[i].u1c, v = (int)m[i].v1c;
+    if (pixel_owner[(size_t)v * width + u] != i) flags[i] = 0;
+}
+
+__global__ __launch_bounds__(1024) void k_compact_matches(const svh_p_match* __restrict__ in,
+                                                          const int32_t* __restrict__ flags,
+                                                          const int32_t* __restrict__ nslots_ptr,
+                                                          svh_p_match* __restrict__ out,
+                                                          int32_t* __restrict__ count) {
+    const int nslots = *nslots_ptr;
+    const int t = threadIdx.x;
+    const int chunk = (nslots + 1023) / 1024;
+    const int lo = min(t * chunk, nslots), hi = min(lo + chunk, nslots);
+    int mine = 0;
+    for (int s = lo; s < hi; s++) mine += flags[s];
+    int total;
+    int base = block_exclusive_scan_1024(mine, &total);
+    for (int s = lo; s < hi; s++)
+        if (flags[s]) out[base++] = in[s];
+    if (t == 0) *count = total;
+}
+
+// ---------------------------------------------------------------------------
+// M11  Matcher::relocateMinimum / refinement (refinement == 1)
+//      matcher.cpp:1666-1711, 1715-1821; computeSmallDescriptor :583-611
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void small_desc(const uint8_t* du, const uint8_t* dv, int bpl, int u, int v,
+                                           uint32_t d[4]) {
+    const ptrdiff_t a2 = (ptrdiff_t)v * bpl + u, a1 = a2 - bpl, a0 = a1 - bpl, a3 = a2 + bpl, a4 = a3 + bpl;
+    d[0] = du[a0] | (du[a1 - 2] << 8) | (du[a1] << 16) | ((uint32_t)du[a1 + 2] << 24);
+    d[1] = du[a2 - 1] | (du[a2] << 8) | (du[a2] << 16) | ((uint32_t)du[a2 + 1] << 24);
+    d[2] = du[a3 - 2] | (du[a3] << 8) | (du[a3 + 2] << 16) | ((uint32_t)du[a4] << 24);
+    d[3] = dv[a1] | (dv[a2 - 1] << 8) | (dv[a2 + 1] << 16) | ((uint32_t)dv[a3] << 24);
+}
+
+__device__ void relocate(const SobelView& s1, const SobelView& s2, int margin, float u1, float v1,
+                         float* u2, float* v2) {
+    if (*u2 - 2 < margin || *u2 + 2 > s2.w - 1 - margin || *v2 - 2 < margin || *v2 + 2 > s2.h - 1 - margin)
+        return;
+    uint32_t ref[4], d[4];
+    small_desc(s1.du, s1.dv, s1.bpl, (int)u1, (int)v1, ref);
+    int best = 0, best_cost = 0;
+    for (int k = 0; k < 25; k++) {
+        small_desc(s2.du, s2.dv, s2.bpl, (int)*u2 + k % 5 - 2, (int)*v2 + k / 5 - 2, d);
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) c = __builtin_amdgcn_sad_u8(ref[q], d[q], c);
+        if (k == 0 || (int)c < best_cost) {
+            best = k;
+            best_cost = (int)c;
+        }
+    }
+    // u2 += (float)(min_ind%5) - 2.0  (double arithmetic, then back to float)
+    *u2 = (float)((double)*u2 + ((double)(float)(best % 5) - 2.0));
+    *v2 = (float)((double)*v2 + ((double)(float)(best / 5) - 2.0));
+}
+
+__global__ __launch_bounds__(128) void k_refine(svh_p_match* __restrict__ m,
+                                                const int32_t* __restrict__ count, int method, int margin,
+                                                SobelView s1p, SobelView s2p, SobelView s1c,
+                                                SobelView s2c) {
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= *count) return;
+    svh_p_match q = m[i];
+    if (method == 0 || method == 2) relocate(s1c, s1p, margin, q.u1c, q.v1c, &q.u1p, &q.v1p);
+    if (method == 1 || method == 2) relocate(s1c, s2c, margin, q.u1c, q.v1c, &q.u2c, &q.v2c);
+    if (method == 2) relocate(s1c, s2p, margin, q.u1c, q.v1c, &q.u2p, &q.v2p);
+    m[i] = q;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+void mlaunch_half(void* stream, const uint8_t* I, int bpl, uint8_t* out, int hw, int hh, int hbpl) {
+    hipLaunchKernelGGL(k_half, dim3((hw + 63) / 64, (hh + 3) / 4), dim3(64, 4), 0, (hipStream_t)stream, I, bpl,
+                       out, hw, hh, hbpl);
+}
+
+void mlaunch_filters(void* stream, const uint8_t* I, int w, int h, int bpl, uint8_t* du, uint8_t* dv,
+                     int16_t* f1, int16_t* f2) {
+    dim3 grid((w + FX - 1) / FX, (h + FY - 1) / FY), block(FX, 4);
+    if (f1)
+        hipLaunchKernelGGL(k_filters<true>, grid, block, 0, (hipStream_t)stream, I, w, h, bpl, du, dv, f1, f2);
+    else
+        hipLaunchKernelGGL(k_filters<false>, grid, block, 0, (hipStream_t)stream, I, w, h, bpl, du, dv, f1, f2);
+}
+
+int mnms_blocks(int extent, int n, int margin) {
+    int c = 0;
+    for (int i = n + margin; i < extent - n - margin; i += n + 1) c++;
+    return c;
+}
+
+void mlaunch_features(void* stream, const int16_t* f1, const int16_t* f2, const uint8_t* du,
+                      const uint8_t* dv, int w, int h, int bpl, int n, int tau, int margin, int scale,
+                      int4* slots, int32_t* flags, int32_t* table, int32_t* count) {
+    hipStream_t s = (hipStream_t)stream;
+    const int ni = mnms_blocks(w, n, margin), nj = mnms_blocks(h, n, margin);
+    const int nb = ni * nj;
+    if (nb > 0)
+        hipLaunchKernelGGL(k_nms, dim3((nb + 255) / 256), dim3(256), 0, s, f1, f2, w, h, bpl, n, tau, margin,
+                           ni, nj, slots, flags);
+    hipLaunchKernelGGL(k_compact_features, dim3(1), dim3(1024), 0, s, slots, flags, nb * 4, du, dv, bpl, scale,
+                       table, count);
+}
+
+void mlaunch_bin_index(void* stream, const int32_t* table, const int32_t* count, int ub, int vb,
+                       int binsize, int32_t* off, int32_t* ids, int32_t* cursor) {
+    hipLaunchKernelGGL(k_bin_index, dim3(1), dim3(1024), 0, (hipStream_t)stream, table, count, ub, vb, binsize,
+                       off, ids, cursor);
+}
+
+void mlaunch_match(void* stream, const MatchParams& P, const FeatView& m1p, const FeatView& m2p,
+                   const FeatView& m1c, const FeatView& m2c, int nquery_cap, const float* ranges,
+                   int use_prior, svh_p_match* slots, int32_t* flags, int32_t* pixel_owner,
+                   svh_p_match* out, int32_t* out_count) {
+    hipStream_t s = (hipStream_t)stream;
+    const FeatView& q = P.method == 2 ? m1p : m1c;
+    if (P.method < 2)
+        (void)hipMemsetAsync(pixel_owner, 0x7F, (size_t)P.width * P.height * sizeof(int32_t), s);
+    if (nquery_cap > 0) {
+        hipLaunchKernelGGL(k_match, dim3((nquery_cap + 127) / 128), dim3(128), 0, s, P, m1p, m2p, m1c, m2c,
+                           ranges, use_prior, slots, flags, pixel_owner);
+        if (P.method < 2)
+            hipLaunchKernelGGL(k_match_dedupe, dim3((nquery_cap + 255) / 256), dim3(256), 0, s, q.count,
+                               P.width, slots, flags, pixel_owner);
+    }
+    hipLaunchKernelGGL(k_compact_matches, dim3(1), dim3(1024), 0, s, slots, flags, q.count, out, out_count);
+}
+
+void mlaunch_refine(void* stream, svh_p_match* m, const int32_t* count, int cap, int method, int margin,
+                    const SobelView& s1p, const SobelView& s2p, const SobelView& s1c,
+                    const SobelView& s2c) {
+    if (cap <= 0) return;
+    hipLaunchKernelGGL(k_refine, dim3((cap + 127) / 128), dim3(128), 0, (hipStream_t)stream, m, count, method,
+                       margin, s1p, s2p, s1c, s2c);
+}
+
+}  // namespace svh

@@ -556,3 +556,48 @@ def compare_matchers(a, b, method=2):
             y = y.reshape(-1, 4, 4)[:, :, :ns] if len(y) else y
         out.append((M_STAGE_NAMES[s], -1 if x.shape != y.shape else int((x != y).sum())))
     return out
+
+
+class ProductMatcher(MatcherBase):
+    """svh_matcher_* through the C-ABI of libsvhip.so (the HIP path)"""
+
+    def __init__(self, params):
+        import svhip
+        lib = svhip.lib()
+        lib.svh_matcher_create.restype = C.c_void_p
+        lib.svh_matcher_create.argtypes = [C.POINTER(MatcherParams)]
+        lib.svh_matcher_destroy.argtypes = [C.c_void_p]
+        lib.svh_matcher_set_intrinsics.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+        lib.svh_matcher_push_back.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        lib.svh_matcher_match_features.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.svh_matcher_get_stage.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
+                                              C.POINTER(C.c_size_t)]
+        lib.svh_matcher_get_features.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        lib.svh_matcher_get_filter.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
+                                               C.POINTER(C.c_size_t), C.c_void_p]
+        lib.svh_matcher_get_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        lib.svh_matcher_bucket_features.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float]
+        lib.svh_matcher_get_gain.restype = C.c_float
+        lib.svh_matcher_get_gain.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        self._svhip = svhip
+        super().__init__(lib, "svh_", params)
+
+    def push_back(self, I1, I2=None, replace=False):
+        rc = super().push_back(I1, I2, replace)
+        if rc < 0:
+            raise self._svhip.SvhError(rc, self._svhip.last_error())
+        return rc
+
+    def match(self, method, Tr=None, staged=True):
+        t = None if Tr is None else _p(np.ascontiguousarray(Tr, np.float64))
+        rc = self.lib.svh_matcher_match_features(self.h, method, t)
+        if rc < 0:
+            raise self._svhip.SvhError(rc, self._svhip.last_error())
+        return rc
+
+    def bucket(self, max_features, bw, bh):
+        return self.lib.svh_matcher_bucket_features(self.h, max_features, bw, bh)
+
+    def gain(self, inliers):
+        a = np.ascontiguousarray(inliers, np.int32)
+        return self.lib.svh_matcher_get_gain(self.h, _p(a), len(a))
