@@ -98,6 +98,43 @@ def cpu_baseline(I1, I2, params, budget_s=15.0):
             "host": _cpu_model(), "host_cores": os.cpu_count()}
 
 
+def matcher_bench(iters=40):
+    """secondary metric (BASELINE.json configs[4]): libviso2 Matcher on the reference's quad
+    (1344x391): ms per stereo frame for pushBack + matchFeatures(2), device vs reference CPU"""
+    import helpers as Hh
+    im = [Hh.read_pgm(os.path.join(Hh.GOLDEN, "viso_%s.pgm" % k)) for k in ("I1p", "I2p", "I1c", "I2c")]
+    prm = Hh.matcher_defaults()
+
+    def run(m, n):
+        m.push_back(im[0], im[1])
+        t_push = t_match = 0.0
+        nm = 0
+        for i in range(n):
+            a, b = (im[2], im[3]) if i % 2 == 0 else (im[0], im[1])
+            t = time.perf_counter()
+            m.push_back(a, b)
+            t_push += time.perf_counter() - t
+            t = time.perf_counter()
+            m.match(2, staged=False)
+            t_match += time.perf_counter() - t
+            nm = len(m.matches())
+        return 1e3 * t_push / n, 1e3 * t_match / n, nm
+
+    dev = Hh.ProductMatcher(prm)
+    run(dev, 3)
+    push, match, nm = run(dev, iters)
+    out = {"workload": "quad match on libviso2/img I1p/I2p/I1c/I2c 1344x391, default parameters",
+           "pushBack_ms": push, "matchFeatures_ms": match, "frame_ms": push + match,
+           "frames_per_s": 1e3 / (push + match), "matches": nm}
+    if Hh.have_ref_viso():
+        ref = Hh.RefMatcher(prm)
+        ref.lib.ref_init(0)
+        rp, rm, rn = run(ref, 12)
+        out["cpu_reference"] = {"pushBack_ms": rp, "matchFeatures_ms": rm, "frame_ms": rp + rm,
+                                "matches": rn, "cores": 1, "kind": "reference"}
+    return out
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -248,6 +285,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(I1, I2, params)
+            out["matcher"] = matcher_bench()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

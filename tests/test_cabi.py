@@ -118,3 +118,14 @@ def test_cxx_dropin_header_builds():
     subprocess.check_call(["make", "-C", os.path.join(H.ROOT, "tests", "cxx"), "all"],
                           stdout=subprocess.DEVNULL)
     assert os.path.exists(os.path.join(H.ROOT, "tests", "cxx", "elas_dropin"))
+
+
+def test_matcher_refuses_to_run_without_a_gpu(S):
+    if S.device_count() > 0:
+        pytest.skip("a GPU is present")
+    m = H.ProductMatcher(H.matcher_defaults())
+    I = H.read_pgm(os.path.join(H.GOLDEN, "viso_I1p.pgm"))
+    with pytest.raises(S.SvhError) as ei:
+        m.push_back(I, I)
+    assert ei.value.code == S.ERR_NO_DEVICE
+    assert len(m.matches()) == 0

@@ -109,3 +109,35 @@ def test_bad_dims_message(capfd):
     rc = m.lib.svh_matcher_push_back(m.h, H._p(I), H._p(I), dims, 0)
     assert rc != 0
     assert "Image dimension mismatch" in capfd.readouterr().err
+
+
+@pytest.mark.parametrize("predict", [False, True])
+def test_cxx_dropin_visual_odometry_call_sequence(predict, tmp_path, oracle_lib):
+    """viso_stereo.cpp:41-68 replayed through include/matcher.h reproduces the oracle"""
+    import subprocess
+    if not H.have_ref_viso():
+        pytest.skip("needs oracle/_ref")
+    subprocess.check_call(["make", "-C", os.path.join(H.ROOT, "tests", "cxx"), "all"],
+                          stdout=subprocess.DEVNULL)
+    exe = os.path.join(H.ROOT, "tests", "cxx", "matcher_dropin")
+    out = str(tmp_path / "m.bin")
+    args = [exe] + [os.path.join(H.GOLDEN, "viso_%s.pgm" % k) for k in ("I1p", "I2p", "I1c", "I2c")] + [out]
+    if predict:
+        args.append("predict")
+    txt = subprocess.check_output(args).decode()
+    got = np.fromfile(out, H.P_MATCH)
+    prm = H.matcher_defaults()
+    a = H.OracleMatcher(prm)
+    a.set_intrinsics(645.24, 635.96, 194.13, 0.5707)
+    im = quad()
+    push_quad(a, im)
+    tr = np.eye(4)
+    tr[2, 3] = -0.75
+    a.match(2, tr if predict else None)
+    want = a.matches()
+    assert len(got) == len(want) and (got == want).all()
+    C.CDLL(None).srand(0)
+    nb = a.bucket(2, 50.0, 50.0)
+    g = a.gain(np.arange(0, nb, 3))
+    assert "matches %d" % nb in txt
+    assert "gain %.6f" % g in txt
