@@ -44,11 +44,10 @@ int main(int argc, char** argv) {
         }
     const bool predict = argc > 6;
 
-    // viso.cpp:33-36: one long-lived matcher per VO object, rand seeded once
+    // viso.cpp:33-36: one long-lived matcher per VO object
     Matcher::parameters param;
     Matcher* _matcher = new Matcher(param);
     _matcher->setIntrinsics(645.24, 635.96, 194.13, 0.5707);
-    srand(0);
 
     int32_t dims[3] = {w, h, w};
     // frame 0 (viso_stereo.cpp:44): nothing to match yet
@@ -68,6 +67,9 @@ int main(int argc, char** argv) {
     if (!f) return 2;
     fwrite(_p_matched.data(), sizeof(Matcher::p_match), _p_matched.size(), f);
     fclose(f);
+    // viso.cpp:36 seeds libc's rand() once at start-up; here it is re-seeded right before the
+    // shuffle so that the comparison does not depend on other rand() users in the process
+    srand(0);
     _matcher->bucketFeatures(2, 50, 50);
     _p_matched = _matcher->getMatches();
     printf("matches %zu\n", _p_matched.size());
