@@ -527,7 +527,13 @@ __global__ __launch_bounds__(256) void k_grid_dilate(GroupDev G, int slots, int 
 // overwrite an earlier one on the few pixels both cover; findMatch's early-outs
 // depend on the pixel only, so "owner = highest triangle index covering the
 // pixel" is exact.  One wave per triangle: 16 columns x 4 row phases per step.
+// Two passes instead of one atomicMax per pixel:
 // ---------------------------------------------------------------------------
+// kFix = false: plain stores (on the rare multiply covered pixel an arbitrary
+// coverer lands); kFix = true: every triangle re-reads its pixels and raises the
+// ones a lower index won with atomicMax.  Per-pixel atomics are thereby limited
+// to the handful of contested pixels (4-53 per image in the survey's probes).
+template <bool kFix>
 __global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri, int W, int H, int sub) {
     const int T = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
     const int lane = threadIdx.x & 63;
@@ -554,7 +560,13 @@ __global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri, int W,
             vb = vb < H ? vb : H;
             for (int v = va + rp; v < vb; v += 4) {
                 if (sub && (v & 1)) continue;
-                atomicMax(&owner[(size_t)v * W + u], t);
+                int32_t* px = &owner[(size_t)v * W + u];
+                if (kFix) {
+                    if (__hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t)
+                        atomicMax(px, t);
+                } else {
+                    *px = t;
+                }
             }
         }
     }
@@ -571,16 +583,14 @@ struct MatchParams {
     int disp_max, match_texture, plane_radius;
 };
 
-// kLds: one block = 256 consecutive pixels of one row; the slice of the OTHER
-// image's descriptor row that any candidate of the block can address
-// ([u_lo-disp_max, u_hi] on the left, [u_lo, u_hi+disp_max] on the right) is
-// staged in LDS once (8 KB for disp_max 255) instead of ~13 L2 reads per pixel.
+// kLds: one block = one row of the disparity map; the OTHER image's descriptor
+// row is staged in LDS once (19.9 KB at W = 1242) and every candidate SAD reads
+// it from there instead of ~13 L2 reads per pixel; no row is loaded twice.
 template <bool kLds>
-__global__ __launch_bounds__(256) void k_match(GroupDev G, MatchParams P) {
+__global__ __launch_bounds__(kLds ? 512 : 256) void k_match(GroupDev G, MatchParams P) {
     extern __shared__ uint4 s_row[];
     const int z = blockIdx.z, pair = z >> 1, side = z & 1;
     if (!G.hdr->active[pair]) return;
-    const int x = kLds ? blockIdx.x * 256 + threadIdx.x : blockIdx.x * 64 + threadIdx.x;
     const int y = kLds ? blockIdx.y : blockIdx.y * 4 + threadIdx.y;
     const size_t N = (size_t)P.W * P.H;
     const int mul = P.sub ? 2 : 1;
@@ -589,20 +599,14 @@ __global__ __launch_bounds__(256) void k_match(GroupDev G, MatchParams P) {
     line = line > 2 ? line : 2;
     const uint4* oth_line =
         reinterpret_cast<const uint4*>(G.desc + (size_t)(z ^ 1) * N * 16) + (size_t)line * P.W;
-    int s0 = 0;
+    const int s0 = 0;
     if (kLds) {
-        const int x_lo = blockIdx.x * 256;
-        int x_hi = x_lo + 255;
-        x_hi = x_hi < P.DW - 1 ? x_hi : P.DW - 1;
-        int lo = side ? x_lo * mul : x_lo * mul - P.disp_max;
-        int hi = side ? x_hi * mul + P.disp_max : x_hi * mul;
-        lo = lo > 0 ? lo : 0;
-        hi = hi < P.W - 1 ? hi : P.W - 1;
-        s0 = lo;
-        for (int i = threadIdx.x; i <= hi - lo; i += 256) s_row[i] = oth_line[lo + i];
+        for (int i = threadIdx.x; i < P.W; i += 512) s_row[i] = oth_line[i];
         __syncthreads();
     }
-    if (x >= P.DW || y >= P.DH) return;
+    for (int x = kLds ? (int)threadIdx.x : (int)(blockIdx.x * 64 + threadIdx.x); x < P.DW;
+         x += kLds ? 512 : P.DW) {
+    if (y >= P.DH) return;
     const int u = x * mul;
     float out = -10.f;
     const int t = G.owner[(size_t)z * N + (size_t)v * P.W + u];
@@ -657,6 +661,7 @@ __global__ __launch_bounds__(256) void k_match(GroupDev G, MatchParams P) {
         }
     }
     G.Draw[(size_t)z * P.DW * P.DH + (size_t)y * P.DW + x] = out;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1145,7 +1150,9 @@ void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     hipStream_t s = (hipStream_t)cx.stream;
     (void)hipMemsetAsync(G.owner, 0xFF, (size_t)2 * g * d.W * d.H * sizeof(int32_t), s);
     if (total_tri == 0) return;
-    LAUNCH("k_owner", k_owner, dim3((total_tri + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
+    LAUNCH("k_owner", k_owner<false>, dim3((total_tri + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
+           p.subsampling);
+    LAUNCH("k_owner_fix", k_owner<true>, dim3((total_tri + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
            p.subsampling);
 }
 
@@ -1155,10 +1162,10 @@ void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     P.W = d.W; P.H = d.H; P.DW = d.DW; P.DH = d.DH; P.gw = d.gw; P.gh = d.gh; P.gwords = d.gwords;
     P.grid_size = p.grid_size; P.sub = p.subsampling; P.disp_max = p.disp_max;
     P.match_texture = p.match_texture; P.plane_radius = G.plane_radius;
-    const size_t lds = (size_t)(256 * (p.subsampling ? 2 : 1) + p.disp_max + 1) * sizeof(uint4);
+    const size_t lds = (size_t)d.W * sizeof(uint4);
     if (lds <= 64 * 1024) {
         Timed timed_(cx, "k_match");
-        hipLaunchKernelGGL(k_match<true>, dim3((d.DW + 255) / 256, d.DH, 2 * g), dim3(256), lds,
+        hipLaunchKernelGGL(k_match<true>, dim3(1, d.DH, 2 * g), dim3(512), lds,
                            (hipStream_t)cx.stream, G, P);
     } else {
         LAUNCH("k_match", k_match<false>, grid2d(d.DW, d.DH, 2 * g), dim3(64, 4), G, P);
