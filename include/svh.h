@@ -116,6 +116,9 @@ int32_t svh_elas_set_lanes(int32_t lanes);
 /* pairs a lane pushes through each kernel launch (1..16): batches are cut into
  * groups of this many consecutive pairs */
 int32_t svh_elas_set_group(int32_t pairs);
+/* 1: mask + gap interpolation + adaptive mean run as one LDS-tiled kernel when
+ * the parameters allow it; 0 (default, faster on MI355X so far): separate kernels */
+int32_t svh_elas_set_fused_post(int32_t on);
 
 /* Stage taps for parity tests: after a successful svh_elas_process() the
  * intermediate of the given stage (of the last pair processed through handle

@@ -220,6 +220,7 @@ static std::mutex g_mu;
 static std::map<int, Pool*> g_pools;
 static std::atomic<int> g_lanes{8};
 static std::atomic<int> g_group{4};
+static std::atomic<int> g_fused{0};   // measured slower than the separate kernels on MI355X (133 vs 104 us for G=8): off by default
 
 static Pool* pool_for(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -475,17 +476,30 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     // place on them: no final copy
     DevMaps out;
     if (io.out_device) {
-        out.D[0] = io.dD[0]; out.D[1] = io.dD[1]; out.stride = io.out_stride;
+        out.D[0] = io.dD[0]; out.D[1] = io.dD[1]; out.stride[0] = out.stride[1] = io.out_stride;
     } else {
-        out.D[0] = L.D; out.D[1] = L.D + DN; out.stride = 2 * DN;
+        out.D[0] = L.D; out.D[1] = L.D + DN; out.stride[0] = out.stride[1] = 2 * DN;
     }
     const PostScratch ps = {L.tmp, L.labels, L.runlen, L.counts};
+    const int nside = p.postprocess_only_left ? 1 : 2;
+    if (!(taps && taps->enabled) && g_fused.load() && post_fusable(p)) {
+        // fused tail: the L/R check writes the maps that get post-processed into
+        // scratch, the others straight to the output; one kernel does the rest
+        DevMaps mid = out;
+        for (int k = 0; k < nside; k++) {
+            mid.D[k] = L.tmp + (size_t)k * DN;
+            mid.stride[k] = (size_t)nside * DN;
+        }
+        launch_lr(cx, p, d, g, G, mid);
+        launch_segments_label(cx, p, d, g, nside, G, mid, ps);
+        launch_post_fused(cx, p, d, g, nside, G, mid, out, ps);
+        goto copy_out;
+    }
     launch_lr(cx, p, d, g, G, out);
     if (taps && taps->enabled) {
         rc = tap_dev(L, taps, SVH_ELAS_D1_LR, out.D[0], DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_LR, out.D[1], DN); if (rc) return rc;
     }
-    const int nside = p.postprocess_only_left ? 1 : 2;
     launch_segments(cx, p, d, g, nside, G, out, ps);
     if (taps && taps->enabled) {
         rc = tap_dev(L, taps, SVH_ELAS_D1_SEG, out.D[0], DN); if (rc) return rc;
@@ -499,6 +513,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     if (p.filter_adaptive_mean) launch_adaptive_mean(cx, p, d, g, nside, G, out, ps);
     if (p.filter_median) launch_median(cx, d, g, nside, G, out, ps);
 
+copy_out:
     if (!io.out_device)
         for (int32_t j = 0; j < g; j++) {
             if (!hdr->active[j]) continue;
@@ -762,6 +777,11 @@ int32_t svh_elas_support_from_candidates(const svh_elas_params* p, int32_t width
     for (int32_t i = 0; i < n && i < cap; i++)
         for (int k = 0; k < 3; k++) support[3 * i + k] = s[3 * i + k];
     return n;
+}
+
+int32_t svh_elas_set_fused_post(int32_t on) {
+    g_fused.store(on ? 1 : 0);
+    return SVH_OK;
 }
 
 int32_t svh_elas_set_group(int32_t pairs) {
