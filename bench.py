@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--group", type=int, default=4, help="pairs per kernel launch (1..16)")
     ap.add_argument("--spinup", type=float, default=1.0,
                     help="seconds of untimed steps before the warmup (GPU clocks, lane buffers)")
+    ap.add_argument("--profile-in-timed-region", type=int, default=1,
+                    help="1: HIP-event kernel timing is on during the timed steps (roofline comes "
+                         "from exactly those launches); 0: a separate pass after them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -218,12 +221,32 @@ def main():
         step()
     for _ in range(args.warmup):
         step()
+    # which kernel dominates?  one profiled, untimed step with every kernel bracketed
+    in_region = bool(args.profile_in_timed_region) and rank == 0
+    prof_all = {}
+    if rank == 0:
+        S.lib().svh_profile_only.argtypes = [C.c_char_p]
+        S.lib().svh_profile_only(None)
+        S.lib().svh_profile_reset()
+        S.lib().svh_profile_enable(1)
+        step()
+        S.lib().svh_profile_enable(0)
+        prof_all = read_profile(S)
+    if in_region and prof_all:
+        # timed region: HIP events only around the dominant kernel (2 records per group)
+        dom0 = max(prof_all, key=lambda k: prof_all[k][0])
+        S.lib().svh_profile_only(dom0.encode())
+        S.lib().svh_profile_reset()
+        S.lib().svh_profile_enable(1)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if in_region:
+        S.lib().svh_profile_enable(0)
+        S.lib().svh_profile_only(None)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -236,16 +259,11 @@ def main():
     else:
         total_pairs = B * args.steps
 
-    # ---- per-kernel roofline: same steps again with HIP-event timing on each
-    # kernel's own stream (kept out of the timed region above)
+    # ---- roofline of the dominant kernel from HIP events recorded on its own stream
+    # during the timed steps (only that kernel is bracketed there: <1 % of value)
     roofline = None
     if rank == 0:
-        S.lib().svh_profile_reset()
-        S.lib().svh_profile_enable(1)
-        for _ in range(max(1, min(args.steps, 3))):
-            step()
-        S.lib().svh_profile_enable(0)
-        prof = read_profile(S)
+        prof = read_profile(S) if in_region else prof_all
         if prof:
             dom = max(prof, key=lambda k: prof[k][0])
             ms, cnt = prof[dom]
@@ -256,7 +274,20 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "avg_launch_us": 1e6 * avg_s, "alg_bytes_per_launch": abytes,
-                        "kernels_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in sorted(prof.items())}}
+                        "timed_region": bool(in_region),
+                        "kernels_us_probe_step": {k: round(1e3 * v[0] / v[1], 2)
+                                                  for k, v in sorted(prof_all.items())}}
+            # measured HBM traffic of that kernel (rocprofv3 --pmc passes, profiles/*_pmc_traffic.json)
+            try:
+                import glob
+                pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))
+                kk = pmc["kernels"].get(dom)
+                if kk:
+                    roofline["traffic"] = kk["hbm_bytes"] * min(group, B) / pmc["pairs_per_launch"]
+                    roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), " \
+                                                 "read = 2*FETCH_SIZE*1024 (gfx950), scaled to pairs per launch"
+            except (OSError, IndexError, KeyError, ValueError):
+                pass
     if world > 1:
         dist.barrier()
 

@@ -159,6 +159,7 @@ int32_t svh_elas_last_timing(svh_elas* e, const char** names, float* ms, int32_t
  * over all lanes until reset.  svh_profile_get(-1,..) returns the entry count. */
 /* ------------------------------------------------------------------------ */
 int32_t svh_profile_enable(int32_t on);
+void    svh_profile_only(const char* kernel);   /* time just this kernel (NULL: all) */
 void    svh_profile_reset(void);
 int32_t svh_profile_get(int32_t index, const char** name, double* total_ms, int64_t* launches);
 

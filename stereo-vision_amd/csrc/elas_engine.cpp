@@ -71,13 +71,17 @@ struct KernelStat {
 static std::mutex g_prof_mu;
 static std::map<std::string, KernelStat> g_prof;
 static std::atomic<int> g_prof_on{0};
+static char g_prof_only[64] = "";   // when non-empty only this kernel is timed
 
 struct EventProfiler : Profiler {
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> ev;          // 2 per launch
     std::vector<const char*> names;
     size_t used = 0;
+    bool skipping = false;
     void begin(const char* kernel) override {
+        skipping = g_prof_only[0] && strcmp(kernel, g_prof_only) != 0;
+        if (skipping) return;
         if (ev.size() < 2 * (used + 1)) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -89,7 +93,7 @@ struct EventProfiler : Profiler {
         (void)hipEventRecord(ev[2 * used], stream);
     }
     void end() override {
-        if (ev.size() < 2 * (used + 1)) return;
+        if (skipping || ev.size() < 2 * (used + 1)) return;
         (void)hipEventRecord(ev[2 * used + 1], stream);
         used++;
     }
@@ -561,6 +565,13 @@ int32_t svh_set_device(int32_t device) {
 int32_t svh_profile_enable(int32_t on) {
     g_prof_on.store(on ? 1 : 0);
     return SVH_OK;
+}
+
+/* restrict the timer to one kernel name (NULL or "" = all kernels) */
+void svh_profile_only(const char* kernel) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    strncpy(g_prof_only, kernel ? kernel : "", sizeof(g_prof_only) - 1);
+    g_prof_only[sizeof(g_prof_only) - 1] = 0;
 }
 
 void svh_profile_reset(void) {

@@ -75,6 +75,9 @@ def test_stages_match_oracle_on_golden(case, svhip, oracle_lib):
     (13, 256, 160, {"support_texture": 30, "ipol_gap_width": 7}),
     (14, 400, 240, {"disp_max": 63, "grid_size": 16, "candidate_stepsize": 4}),
     (15, 1242, 375, {}),                                  # BASELINE config size
+    (16, 322, 201, {"subsampling": 1}),                   # half-resolution output (elas.h:83-85)
+    (17, 1242, 375, {"subsampling": 1, "postprocess_only_left": 0}),
+    (18, 400, 240, {"subsampling": 1, "candidate_stepsize": 4, "support_texture": 30}),
 ])
 @pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
 def test_stages_match_oracle_synthetic(seed, w, h, kw, svhip, oracle_lib):

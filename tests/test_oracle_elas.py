@@ -68,6 +68,8 @@ def test_known_answers(oracle_lib):
     (2, 333, 117, {"postprocess_only_left": 0}),      # width not a multiple of 16
     (3, 256, 160, {"support_texture": 30, "ipol_gap_width": 7}),
     (4, 400, 240, {"disp_max": 63, "grid_size": 16, "candidate_stepsize": 4}),
+    (5, 322, 201, {"subsampling": 1}),                               # GUI checkbox (maindialog.cpp:473)
+    (6, 400, 240, {"subsampling": 1, "postprocess_only_left": 0, "candidate_stepsize": 4}),
 ])
 def test_oracle_matches_reference_live(seed, w, h, kw, oracle_lib):
     l, r = H.synth_pair(w, h, seed, dmax=48)
