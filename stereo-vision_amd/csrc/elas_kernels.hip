@@ -602,11 +602,11 @@ __global__ __launch_bounds__(kLds ? 512 : 256) void k_match(GroupDev G, MatchPar
         reinterpret_cast<const uint4*>(G.desc + (size_t)(z ^ 1) * N * 16) + (size_t)line * P.W;
     const int s0 = 0;
     if (kLds) {
-        for (int i = threadIdx.x; i < P.W; i += 512) s_row[i] = oth_line[i];
+        for (int i = threadIdx.x; i < P.W; i += blockDim.x) s_row[i] = oth_line[i];
         __syncthreads();
     }
     for (int x = kLds ? (int)threadIdx.x : (int)(blockIdx.x * 64 + threadIdx.x); x < P.DW;
-         x += kLds ? 512 : P.DW) {
+         x += kLds ? (int)blockDim.x : P.DW) {
     if (y >= P.DH) return;
     const int u = x * mul;
     float out = -10.f;
@@ -1342,7 +1342,11 @@ void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     const size_t lds = (size_t)d.W * sizeof(uint4);
     if (lds <= 64 * 1024) {
         Timed timed_(cx, "k_match");
-        hipLaunchKernelGGL(k_match<true>, dim3(1, d.DH, 2 * g), dim3(512), lds,
+        // threads per row block: the row is covered in `iters` equal passes with little idle tail
+        static const int mt = getenv("SVH_MATCH_THREADS") ? atoi(getenv("SVH_MATCH_THREADS")) : 256;
+        const int iters = (d.DW + mt - 1) / mt;
+        const int threads = std::min(512, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
+        hipLaunchKernelGGL(k_match<true>, dim3(1, d.DH, 2 * g), dim3(threads), lds,
                            (hipStream_t)cx.stream, G, P);
     } else {
         LAUNCH("k_match", k_match<false>, grid2d(d.DW, d.DH, 2 * g), dim3(64, 4), G, P);
