@@ -34,6 +34,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -99,12 +100,29 @@ private:
     }
 
     // ---- exact predicates -------------------------------------------------
+    // 64-bit products when every scaled coordinate is below 2^14 (the in-circle
+    // determinant then stays under 2^61), 128-bit otherwise
+    bool narrow_ = false;
     int ccw(int32_t a, int32_t b, int32_t c) const {
+        if (narrow_) {
+            const int64_t l = (ix_[a] - ix_[c]) * (iy_[b] - iy_[c]);
+            const int64_t r = (iy_[a] - iy_[c]) * (ix_[b] - ix_[c]);
+            return l > r ? 1 : (l < r ? -1 : 0);
+        }
         i128 l = (i128)(ix_[a] - ix_[c]) * (iy_[b] - iy_[c]);
         i128 r = (i128)(iy_[a] - iy_[c]) * (ix_[b] - ix_[c]);
         return l > r ? 1 : (l < r ? -1 : 0);
     }
     int incircle(int32_t a, int32_t b, int32_t c, int32_t d) const {
+        if (narrow_) {
+            const int64_t adx = ix_[a] - ix_[d], ady = iy_[a] - iy_[d];
+            const int64_t bdx = ix_[b] - ix_[d], bdy = iy_[b] - iy_[d];
+            const int64_t cdx = ix_[c] - ix_[d], cdy = iy_[c] - iy_[d];
+            const int64_t al = adx * adx + ady * ady, bl = bdx * bdx + bdy * bdy, cl = cdx * cdx + cdy * cdy;
+            const int64_t det = al * (bdx * cdy - cdx * bdy) + bl * (cdx * ady - adx * cdy) +
+                                cl * (adx * bdy - bdx * ady);
+            return det > 0 ? 1 : (det < 0 ? -1 : 0);
+        }
         i128 adx = ix_[a] - ix_[d], ady = iy_[a] - iy_[d];
         i128 bdx = ix_[b] - ix_[d], bdy = iy_[b] - iy_[d];
         i128 cdx = ix_[c] - ix_[d], cdy = iy_[c] - iy_[d];
@@ -199,10 +217,13 @@ bool DivConq::scale_coordinates() {
     if (int_bits - min_exp + 1 > 30) return false;
     ix_.resize(n_);
     iy_.resize(n_);
+    int64_t big = 0;
     for (int32_t i = 0; i < n_; i++) {
         ix_[i] = (int64_t)std::ldexp((double)pts_[2 * i], -min_exp);
         iy_[i] = (int64_t)std::ldexp((double)pts_[2 * i + 1], -min_exp);
+        big = std::max(big, std::max(ix_[i] < 0 ? -ix_[i] : ix_[i], iy_[i] < 0 ? -iy_[i] : iy_[i]));
     }
+    narrow_ = big < (1 << 14);
     return true;
 }
 

@@ -707,17 +707,10 @@ __device__ __forceinline__ float* post_map(const DevMaps& m, int z, int nside, i
 // speckle_sim_threshold: a symmetric relation, so segments are the connected
 // components of that graph and a parallel union-find gives the same sets.
 //
-// Run-based labelling keeps the number of atomic unions near the number of
-// run-to-run contacts instead of two per pixel:
-//   k_seg_runs  : every wave (64 consecutive pixels of one row) cuts its span
-//                 into horizontally connected runs with one ballot; L[p] = index
-//                 of the run's first pixel, RL[first] = run length
-//   k_seg_link  : unions between runs -- across wave borders, and to the row
-//                 above, skipping a vertical contact when the pixel to the left
-//                 already makes the same union; finds halve paths as they go
-//   k_seg_count : one atomicAdd of the run length per run, skipped once the
-//                 component is known to be large enough; roots compressed
-//   k_seg_mask  : pixels of components below speckle_size become -10
+//   k_seg_tile   : per 64x16 tile, union-find in LDS; label = tile-local root
+//   k_seg_border : global unions only across tile borders (path-halving finds)
+//   k_seg_sum    : local sizes of merged components added to their root
+//   k_seg_mask   : pixels of components below speckle_size become -10
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int uf_find(const int32_t* L, int x) {
     int p = L[x];
@@ -761,87 +754,187 @@ __device__ __forceinline__ bool seg_joined(float a, float b, float thr) {
     return a >= 0 && b >= 0 && fabsf(a - b) <= thr;
 }
 
-__global__ __launch_bounds__(256) void k_seg_runs(GroupDev G, DevMaps m, PostScratch S, int nside,
+// Two-level labelling.  Level 1 (k_seg_tile): every 64x16 tile is labelled by a
+// union-find that lives entirely in LDS (LDS atomics, ~50 ns hops instead of
+// ~0.7 us through L2); a pixel's global label is the index of its tile-local
+// root and RL[root] holds the local component size.  Level 2 (k_seg_border):
+// only pixels on tile borders issue global unions, between tile-local roots, so
+// the global forest has one node per local component and is at most #tiles
+// deep.  k_seg_sum adds the local sizes of merged components into their root.
+constexpr int CX = 64, CY = 16;
+
+__device__ __forceinline__ int lds_find(volatile int* L, int x) {
+    int p = L[x];
+    while (p != x) {
+        x = p;
+        p = L[x];
+    }
+    return x;
+}
+
+__device__ __forceinline__ void lds_union(int* L, int a, int b) {
+    for (;;) {
+        a = lds_find(L, a);
+        b = lds_find(L, b);
+        if (a == b) return;
+        if (a > b) {
+            int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(&L[b], a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_seg_tile(GroupDev G, DevMaps m, PostScratch S, int nside,
                                                   int DW, int DH, float thr) {
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;   // wave-uniform
-    if (y >= DH) return;
+    __shared__ float sD[CY][CX];
+    __shared__ int sL[CX * CY];
+    __shared__ int sC[CX * CY];
     int pair;
     const float* D = post_map(m, blockIdx.z, nside, &pair);
     if (!G.hdr->active[pair]) return;
     const size_t zo = (size_t)blockIdx.z * DW * DH;
-    const int lane = threadIdx.x;
-    const int i = y * DW + x;
-    const bool inside = x < DW;
-    const float d = inside ? D[i] : -10.f;
-    const bool valid = d >= 0;
-    float dl = __shfl_up(d, 1, kWave);
-    if (lane == 0) dl = (x > 0 && inside) ? D[i - 1] : -10.f;
-    const bool cl = seg_joined(d, dl, thr);
-    const bool start = valid && (lane == 0 || !cl);
-    const unsigned long long starts = __ballot(start);
-    const unsigned long long invalid = __ballot(!valid);
-    if (!inside) return;
-    int label = -1, len = 0;
-    if (valid) {
-        const unsigned long long upto = starts & (~0ull >> (63 - lane));
-        const int first = 63 - __clzll((long long)upto);  // a start at or before me always exists
-        label = i - lane + first;
-        if (start) {
-            const unsigned long long stops = ((starts | invalid) >> lane) >> 1;
-            len = stops ? __ffsll((long long)stops) : (kWave - lane);
-        }
-    }
-    S.labels[zo + i] = label;
-    S.runlen[zo + i] = len;
-    S.counts[zo + i] = 0;
-}
-
-__global__ __launch_bounds__(256) void k_seg_link(GroupDev G, DevMaps m, PostScratch S, int nside,
-                                                  int DW, int DH, float thr) {
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= DW || y >= DH) return;
-    int pair;
-    const float* D = post_map(m, blockIdx.z, nside, &pair);
-    if (!G.hdr->active[pair]) return;
-    int32_t* L = S.labels + (size_t)blockIdx.z * DW * DH;
-    const int i = y * DW + x;
-    const float d = D[i];
-    if (!(d >= 0)) return;
-    const float dl = x > 0 ? D[i - 1] : -10.f;
-    const bool cl = seg_joined(d, dl, thr);
-    // a run that continues across the wave border
-    if (threadIdx.x == 0 && cl) uf_union(L, i, L[i - 1]);
-    if (y > 0) {
-        const float du = D[i - DW];
-        if (seg_joined(d, du, thr)) {
-            // p-1 ~ p, p-1 ~ q-1 and q-1 ~ q already put p and q in one set
-            bool redundant = false;
-            if (cl) {
-                const float dul = D[i - DW - 1];
-                redundant = seg_joined(dl, dul, thr) && seg_joined(du, dul, thr);
+    const int x0 = blockIdx.x * CX, y0 = blockIdx.y * CY;
+    const int tx = threadIdx.x;   // lane: a wave owns whole tile rows ty = threadIdx.y + 4k
+    // step 1: horizontal runs per row with one ballot; label = first pixel of the run
+    int len[CY / 4];
+#pragma unroll
+    for (int k = 0; k < CY / 4; k++) {
+        const int ty = threadIdx.y + 4 * k;
+        const int gx = x0 + tx, gy = y0 + ty;
+        const float d = (gx < DW && gy < DH) ? D[gy * DW + gx] : -10.f;
+        const bool valid = d >= 0;
+        const float dl = __shfl_up(d, 1, kWave);
+        const bool start = valid && (tx == 0 || !seg_joined(d, dl, thr));
+        const unsigned long long starts = __ballot(start);
+        const unsigned long long invalid = __ballot(!valid);
+        int label = -1;
+        len[k] = 0;
+        if (valid) {
+            const unsigned long long upto = starts & (~0ull >> (63 - tx));
+            label = ty * CX + (63 - __clzll((long long)upto));
+            if (start) {
+                const unsigned long long stops = ((starts | invalid) >> tx) >> 1;
+                len[k] = stops ? __ffsll((long long)stops) : (kWave - tx);
             }
-            if (!redundant) uf_union(L, L[i], L[i - DW]);
         }
+        sD[ty][tx] = d;
+        sL[ty * CX + tx] = label;
+        sC[ty * CX + tx] = 0;
+    }
+    __syncthreads();
+    // step 2: unions between runs of adjacent rows (skipped when the pixel to the
+    // left already joins the same two runs)
+#pragma unroll
+    for (int k = 0; k < CY / 4; k++) {
+        const int ty = threadIdx.y + 4 * k, i = ty * CX + tx;
+        if (ty == 0) continue;
+        const float d = sD[ty][tx], du = sD[ty - 1][tx];
+        if (!seg_joined(d, du, thr)) continue;
+        if (tx > 0) {
+            const float dl = sD[ty][tx - 1], dul = sD[ty - 1][tx - 1];
+            if (seg_joined(d, dl, thr) && seg_joined(dl, dul, thr) && seg_joined(du, dul, thr)) continue;
+        }
+        lds_union(sL, sL[i], sL[i - CX]);
+    }
+    __syncthreads();
+    // step 3: run starts find their root and add their length to it
+#pragma unroll
+    for (int k = 0; k < CY / 4; k++) {
+        const int ty = threadIdx.y + 4 * k, i = ty * CX + tx;
+        if (len[k] > 0) {
+            const int r = lds_find(sL, i);
+            atomicAdd(&sC[r], len[k]);
+            len[k] = r;               // remembered for the compression below
+        } else {
+            len[k] = -1;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CY / 4; k++)
+        if (len[k] >= 0) sL[(threadIdx.y + 4 * k) * CX + tx] = len[k];   // start -> root
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CY / 4; k++) {
+        const int ty = threadIdx.y + 4 * k, i = ty * CX + tx;
+        const int gx = x0 + tx, gy = y0 + ty;
+        if (gx >= DW || gy >= DH) continue;
+        const int gi = gy * DW + gx;
+        int label = -1, size = 0;
+        const int s = sL[i];
+        if (s >= 0) {
+            const int r = sL[s];      // pixel -> run start -> root (or start == root)
+            const int root = sL[r] == r ? r : sL[r];
+            const int ry = root / CX, rx = root - ry * CX;
+            label = (y0 + ry) * DW + (x0 + rx);
+            if (root == i) size = sC[i];   // this pixel is the tile-local root
+        }
+        S.labels[zo + gi] = label;
+        S.runlen[zo + gi] = size;
+        S.counts[zo + gi] = size;
     }
 }
 
-__global__ __launch_bounds__(256) void k_seg_count(GroupDev G, PostScratch S, int nside, int n,
-                                                   int min_size) {
+// unions across tile borders: one thread per pixel of a tile's first row / column
+__global__ __launch_bounds__(256) void k_seg_border(GroupDev G, DevMaps m, PostScratch S, int nside,
+                                                    int DW, int DH, float thr, int nhor) {
+    int pair;
+    const float* D = post_map(m, blockIdx.y, nside, &pair);
+    if (!G.hdr->active[pair]) return;
+    int32_t* L = S.labels + (size_t)blockIdx.y * DW * DH;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    int x, y, step;  // neighbour across the border is (x,y) - step
+    if (e < nhor) {             // horizontal borders: rows CY, 2CY, ...
+        const int b = e / DW;
+        x = e - b * DW;
+        y = (b + 1) * CY;
+        step = DW;
+        if (y >= DH) return;
+    } else {                    // vertical borders: columns CX, 2CX, ...
+        const int e2 = e - nhor;
+        const int nvb = (DW - 1) / CX;      // number of interior vertical borders
+        if (nvb <= 0) return;
+        const int b = e2 % nvb;
+        y = e2 / nvb;
+        x = (b + 1) * CX;
+        step = 1;
+        if (y >= DH || x >= DW) return;
+    }
+    const int i = y * DW + x;
+    const float d = D[i], q = D[i - step];
+    if (!seg_joined(d, q, thr)) return;
+    // skip when the previous pixel along the border already joins the same two components
+    const int along = step == 1 ? DW : 1;
+    const bool has_prev = step == 1 ? (y % CY != 0) : (x % CX != 0);
+    if (has_prev) {
+        const float dp = D[i - along], qp = D[i - step - along];
+        if (seg_joined(d, dp, thr) && seg_joined(q, qp, thr) && seg_joined(dp, qp, thr)) return;
+    }
+    uf_union(L, L[i], L[i - step]);
+}
+
+// add the local size of every merged tile-local component to its global root
+__global__ __launch_bounds__(256) void k_seg_sum(GroupDev G, PostScratch S, int nside, int n,
+                                                 int min_size) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     if (!G.hdr->active[blockIdx.y / nside]) return;
     const size_t zo = (size_t)blockIdx.y * n;
-    const int len = S.runlen[zo + i];
-    if (len > 0) {
+    const int size = S.runlen[zo + i];
+    if (size > 0) {
         int32_t* L = S.labels + zo;
         const int root = uf_find(L, i);
-        L[i] = root;
-        int32_t* c = S.counts + zo + root;
-        // only "below speckle_size or not" is ever asked of a count
-        if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < min_size)
-            atomicAdd(c, len);
+        if (root != i) {
+            L[i] = root;
+            int32_t* c = S.counts + zo + root;
+            // only "below speckle_size or not" is ever asked of a count
+            if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < min_size)
+                atomicAdd(c, size);
+        }
     }
 }
 
@@ -1364,10 +1457,8 @@ void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& 
     const int n = d.DW * d.DH, z = g * nside;
     int min_size = p.speckle_size;
     if (p.subsampling) min_size = (int)(sqrtf((float)p.speckle_size) * 2);  // elas.cpp:1218
-    const dim3 lin((n + 255) / 256, z), b256(256), g2 = grid2d(d.DW, d.DH, z), b2(64, 4);
-    LAUNCH("k_seg_runs", k_seg_runs, g2, b2, G, out, S, nside, d.DW, d.DH, p.speckle_sim_threshold);
-    LAUNCH("k_seg_link", k_seg_link, g2, b2, G, out, S, nside, d.DW, d.DH, p.speckle_sim_threshold);
-    LAUNCH("k_seg_count", k_seg_count, lin, b256, G, S, nside, n, min_size);
+    const dim3 lin((n + 255) / 256, z), b256(256);
+    launch_segments_label(cx, p, d, g, nside, G, out, S);
     LAUNCH("k_seg_mask", k_seg_mask, lin, b256, G, out, S, nside, n, min_size);
 }
 
@@ -1379,10 +1470,18 @@ bool post_fusable(const svh_elas_params& p) {
 void launch_segments_label(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                            int32_t nside, const GroupDev& G, const DevMaps& in, const PostScratch& S) {
     const int n = d.DW * d.DH, z = g * nside;
-    const dim3 lin((n + 255) / 256, z), b256(256), g2 = grid2d(d.DW, d.DH, z), b2(64, 4);
-    LAUNCH("k_seg_runs", k_seg_runs, g2, b2, G, in, S, nside, d.DW, d.DH, p.speckle_sim_threshold);
-    LAUNCH("k_seg_link", k_seg_link, g2, b2, G, in, S, nside, d.DW, d.DH, p.speckle_sim_threshold);
-    LAUNCH("k_seg_count", k_seg_count, lin, b256, G, S, nside, n, p.speckle_size);
+    int min_size = p.speckle_size;
+    if (p.subsampling) min_size = (int)(sqrtf((float)p.speckle_size) * 2);  // elas.cpp:1218
+    const dim3 lin((n + 255) / 256, z), b256(256);
+    const dim3 tiles((d.DW + CX - 1) / CX, (d.DH + CY - 1) / CY, z);
+    LAUNCH("k_seg_tile", k_seg_tile, tiles, dim3(CX, 4), G, in, S, nside, d.DW, d.DH,
+           p.speckle_sim_threshold);
+    const int nhor = ((d.DH - 1) / CY) * d.DW;              // pixels on interior horizontal borders
+    const int nver = ((d.DW - 1) / CX) * d.DH;              // ... and vertical ones
+    if (nhor + nver > 0)
+        LAUNCH("k_seg_border", k_seg_border, dim3((nhor + nver + 255) / 256, z), b256, G, in, S, nside,
+               d.DW, d.DH, p.speckle_sim_threshold, nhor);
+    LAUNCH("k_seg_sum", k_seg_sum, lin, b256, G, S, nside, n, min_size);
 }
 
 void launch_post_fused(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
