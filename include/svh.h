@@ -244,6 +244,8 @@ enum svh_matcher_stage {
     SVH_M_DENSE,            /* after removeOutliers (:281) == getMatches before bucketing      */
     SVH_M_STAGE_COUNT
 };
+/* stages are recorded only after svh_matcher_set_taps(m, 1) (extra device->host copies) */
+int32_t svh_matcher_set_taps(svh_matcher* m, int32_t enable);
 int32_t svh_matcher_get_stage(svh_matcher* m, int32_t stage, void* buf, size_t cap, size_t* size);
 /* filter images of the current left frame for parity checks:
  * 0 du, 1 dv (matching resolution), 2 du_full, 3 dv_full (u8); 4 f1 blob, 5 f2 checkerboard (i16) */

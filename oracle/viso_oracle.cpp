@@ -6,9 +6,7 @@
 // indices and coordinates -- against oracle/_ref/libref_viso.so and the golden
 // quad fixture (tests/test_oracle_viso.py).
 //
-// Not restated: Shewchuk's Triangle (supplied as a callback, like for ELAS)
-// and parabolicFitting (refinement == 2, a non-default branch: matcher.cpp:
-// 1574-1662); orc_matcher_match_features returns -3 for it.
+// Not restated: Shewchuk's Triangle (supplied as a callback, like for ELAS).
 #include "oracle.h"
 
 #include <math.h>
@@ -543,17 +541,119 @@ void relocate(const orc_matcher* m, const View& V1, const int32_t* dims1, const 
     v2 += (float)(best / 5) - 2.0;
 }
 
-// Matcher::refinement (refinement == 1)   matcher.cpp:1715-1821
-void refine(orc_matcher* m, std::vector<PM>& pm, int32_t method) {
-    for (size_t q = 0; q < pm.size(); q++) {
-        PM& it = pm[q];
-        if (method == 0 || method == 2)
-            relocate(m, m->cur[0], m->dims_c, m->prev[0], m->dims_p, it.u1c, it.v1c, it.u1p, it.v1p);
-        if (method == 1 || method == 2)
-            relocate(m, m->cur[0], m->dims_c, m->cur[1], m->dims_c, it.u1c, it.v1c, it.u2c, it.v2c);
-        if (method == 2)
-            relocate(m, m->cur[0], m->dims_c, m->prev[1], m->dims_p, it.u1c, it.v1c, it.u2p, it.v2p);
+// Matrix::solve for an n x n system with one right-hand side   libviso2/src/matrix.cpp:648-760
+// (Gauss-Jordan, full pivoting, ">=" pivot search: the last maximum wins)
+bool gauss_jordan(double* A, double* B, int n, double eps = 1e-20) {
+    std::vector<int> ipiv(n, 0);
+    for (int it = 0; it < n; it++) {
+        double big = 0.0;
+        int irow = 0, icol = 0;
+        for (int j = 0; j < n; j++)
+            if (ipiv[j] != 1)
+                for (int k = 0; k < n; k++)
+                    if (ipiv[k] == 0 && fabs(A[j * n + k]) >= big) {
+                        big = fabs(A[j * n + k]);
+                        irow = j;
+                        icol = k;
+                    }
+        ++ipiv[icol];
+        if (irow != icol) {
+            for (int l = 0; l < n; l++) std::swap(A[irow * n + l], A[icol * n + l]);
+            std::swap(B[irow], B[icol]);
+        }
+        if (fabs(A[icol * n + icol]) < eps) return false;
+        const double pivinv = 1.0 / A[icol * n + icol];
+        A[icol * n + icol] = 1.0;
+        for (int l = 0; l < n; l++) A[icol * n + l] *= pivinv;
+        B[icol] *= pivinv;
+        for (int ll = 0; ll < n; ll++)
+            if (ll != icol) {
+                const double dum = A[ll * n + icol];
+                A[ll * n + icol] = 0.0;
+                for (int l = 0; l < n; l++) A[ll * n + l] -= A[icol * n + l] * dum;
+                B[ll] -= B[icol] * dum;
+            }
     }
+    return true;
+}
+
+// design matrix of the 3x3 quadratic fit (matcher.cpp:1725-1733)
+const double kFitA[9][6] = {{1, 1, 1, -1, -1, 1}, {0, 1, 0, 0, -1, 1}, {1, 1, -1, 1, -1, 1},
+                            {1, 0, 0, -1, 0, 1},  {0, 0, 0, 0, 0, 1},  {1, 0, 0, 1, 0, 1},
+                            {1, 1, -1, -1, 1, 1}, {0, 1, 0, 0, 1, 1},  {1, 1, 1, 1, 1, 1}};
+
+// M11'  Matcher::parabolicFitting   matcher.cpp:1574-1662; false drops the match
+bool parabolic(const orc_matcher* m, const View& V1, const int32_t* dims1, const View& V2,
+               const int32_t* dims2, float u1, float v1, float& u2, float& v2) {
+    const bool half = m->p.half_resolution != 0;
+    const uint8_t* du1 = half ? V1.du_full.data() : V1.du.data();
+    const uint8_t* dv1 = half ? V1.dv_full.data() : V1.dv.data();
+    const uint8_t* du2 = half ? V2.du_full.data() : V2.du.data();
+    const uint8_t* dv2 = half ? V2.dv_full.data() : V2.dv.data();
+    if (u2 - 3 < m->margin || u2 + 3 > dims2[0] - 1 - m->margin || v2 - 3 < m->margin ||
+        v2 + 3 > dims2[1] - 1 - m->margin)
+        return false;
+    uint8_t ref[16], d[16];
+    descriptor16(du1, dv1, dims1[2], (int32_t)u1, (int32_t)v1, ref);
+    int32_t cost[49];
+    for (int32_t k = 0; k < 49; k++) {
+        descriptor16(du2, dv2, dims2[2], (int32_t)u2 + k % 7 - 3, (int32_t)v2 + k / 7 - 3, d);
+        cost[k] = sad_bytes(ref, d, 16);
+    }
+    int32_t min_ind = 0, min_cost = cost[0];
+    for (int32_t i = 1; i < 49; i++)
+        if (cost[i] < min_cost) {
+            min_ind = i;
+            min_cost = cost[i];
+        }
+    const int32_t du = min_ind % 7, dv = min_ind / 7;
+    if (du == 0 || du == 6 || dv == 0 || dv == 6) return false;
+    // b = At * c ; solve AtA * x = b   (Matrix::operator*: k ascending, zero-initialised sums)
+    double c[9], b[6], AtA[36];
+    for (int i = -1; i <= 1; i++)
+        for (int j = -1; j <= 1; j++) c[(i + 1) * 3 + (j + 1)] = cost[(dv + i) * 7 + (du + j)];
+    for (int r = 0; r < 6; r++) {
+        b[r] = 0;
+        for (int k = 0; k < 9; k++) b[r] += kFitA[k][r] * c[k];
+        for (int q = 0; q < 6; q++) {
+            double s = 0;
+            for (int k = 0; k < 9; k++) s += kFitA[k][r] * kFitA[k][q];
+            AtA[r * 6 + q] = s;
+        }
+    }
+    if (!gauss_jordan(AtA, b, 6)) return false;
+    float divisor = (b[2] * b[2] - 4.0 * b[0] * b[1]);
+    if (fabs(divisor) < 1e-8 || fabs(b[2]) < 1e-8) return false;
+    float ddv = (2.0 * b[0] * b[4] - b[2] * b[3]) / divisor;
+    float ddu = -(b[4] + 2.0 * b[1] * ddv) / b[2];
+    if (fabs(ddu) >= 1.0 || fabs(ddv) >= 1.0) return false;
+    u2 += (float)du - 3.0 + ddu;
+    v2 += (float)dv - 3.0 + ddv;
+    return true;
+}
+
+// Matcher::refinement   matcher.cpp:1715-1821 (1: pixel relocation, 2: parabolic fit)
+void refine(orc_matcher* m, std::vector<PM>& pm, int32_t method) {
+    const bool sub = m->p.refinement == 2;
+    std::vector<PM> keep;
+    for (size_t q = 0; q < pm.size(); q++) {
+        PM it = pm[q];
+        bool ok = true;
+        if (method == 0 || method == 2) {
+            if (sub) ok = parabolic(m, m->cur[0], m->dims_c, m->prev[0], m->dims_p, it.u1c, it.v1c, it.u1p, it.v1p);
+            else relocate(m, m->cur[0], m->dims_c, m->prev[0], m->dims_p, it.u1c, it.v1c, it.u1p, it.v1p);
+        }
+        if (ok && (method == 1 || method == 2)) {
+            if (sub) ok = parabolic(m, m->cur[0], m->dims_c, m->cur[1], m->dims_c, it.u1c, it.v1c, it.u2c, it.v2c);
+            else relocate(m, m->cur[0], m->dims_c, m->cur[1], m->dims_c, it.u1c, it.v1c, it.u2c, it.v2c);
+        }
+        if (ok && method == 2) {
+            if (sub) ok = parabolic(m, m->cur[0], m->dims_c, m->prev[1], m->dims_p, it.u1c, it.v1c, it.u2p, it.v2p);
+            else relocate(m, m->cur[0], m->dims_c, m->prev[1], m->dims_p, it.u1c, it.v1c, it.u2p, it.v2p);
+        }
+        if (ok) keep.push_back(it);
+    }
+    pm.swap(keep);
 }
 
 }  // namespace
@@ -621,7 +721,6 @@ int32_t orc_matcher_push_back(orc_matcher* m, const uint8_t* I1, const uint8_t* 
 // Matcher::matchFeatures   matcher.cpp:209-293
 int32_t orc_matcher_match_features(orc_matcher* m, int32_t method, const double* Tr) {
     const svh_matcher_params& p = m->p;
-    if (p.refinement == 2) return -3;
     auto missing = [&](const View& V, bool dense) {
         return !V.valid || (dense ? V.dense.empty() : V.sparse.empty());
     };

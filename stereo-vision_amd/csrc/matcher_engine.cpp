@@ -101,8 +101,12 @@ struct svh_matcher {
     size_t owner_cap = 0;
     float* ranges_dev = nullptr;
     int32_t ranges_cap = 0;
-    uint8_t* h_stage = nullptr;   // pinned upload staging for images
-    size_t h_stage_cap = 0;
+    uint8_t* h_stage[2] = {nullptr, nullptr};   // pinned upload staging, one per camera
+    size_t h_stage_cap[2] = {0, 0};
+    svh_p_match* h_pm = nullptr;                // pinned download staging for match lists
+    int32_t* h_cnt = nullptr;                   // pinned: match count
+    int32_t h_pm_cap = 0;
+    bool taps = false;                          // keep every intermediate stage (parity tests)
     // results
     std::vector<svh_p_match> m1, m2;
     std::vector<float> ranges;    // [bins][16]
@@ -162,7 +166,7 @@ static int ensure_scratch(svh_matcher* m, int32_t slot_need, int32_t pm_need, si
         HIP_TRY(dalloc(&m->pm_flags, (size_t)pm_need));
         m->pm_cap = pm_need;
     }
-    if (!m->pm_count) HIP_TRY(dalloc(&m->pm_count, 1));
+    if (!m->pm_count) HIP_TRY(dalloc(&m->pm_count, 2));
     if (owner_need > m->owner_cap) {
         (void)hipFree(m->pixel_owner);
         HIP_TRY(dalloc(&m->pixel_owner, owner_need));
@@ -172,21 +176,27 @@ static int ensure_scratch(svh_matcher* m, int32_t slot_need, int32_t pm_need, si
 }
 
 // M1..M5  Matcher::computeFeatures   matcher.cpp:780-878
-static int compute_features(svh_matcher* m, DevView& V, const uint8_t* src, int32_t pitch) {
+static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* src, int32_t pitch) {
     const svh_matcher_params& p = m->p;
     hipStream_t s = m->stream;
     const size_t fn = (size_t)V.bpl * V.h;
-    if (fn > m->h_stage_cap) {
-        (void)hipHostFree(m->h_stage);
-        HIP_TRY(hipHostMalloc((void**)&m->h_stage, fn));
-        m->h_stage_cap = fn;
+    if (fn > m->h_stage_cap[cam]) {
+        HIP_TRY(hipStreamSynchronize(s));
+        (void)hipHostFree(m->h_stage[cam]);
+        HIP_TRY(hipHostMalloc((void**)&m->h_stage[cam], fn));
+        m->h_stage_cap[cam] = fn;
     }
-    // rows are packed at the aligned pitch in pinned memory, then one linear DMA
-    HIP_TRY(hipStreamSynchronize(s));   // staging buffer is shared by both images
-    memset(m->h_stage, 0, fn);
-    for (int32_t v = 0; v < V.h; v++) memcpy(m->h_stage + (size_t)v * V.bpl, src + (size_t)v * pitch, V.w);
-    V.host.assign(m->h_stage, m->h_stage + fn);
-    HIP_TRY(hipMemcpyAsync(V.I, m->h_stage, fn, hipMemcpyHostToDevice, s));
+    // rows are packed at the aligned pitch in pinned memory, then one linear DMA;
+    // the previous pushBack ended with a stream sync, so the staging buffer is free
+    uint8_t* stage = m->h_stage[cam];
+    V.host.resize(fn);
+    for (int32_t v = 0; v < V.h; v++) {
+        uint8_t* row = stage + (size_t)v * V.bpl;
+        memcpy(row, src + (size_t)v * pitch, V.w);
+        memset(row + V.w, 0, V.bpl - V.w);
+    }
+    memcpy(V.host.data(), stage, fn);
+    HIP_TRY(hipMemcpyAsync(V.I, stage, fn, hipMemcpyHostToDevice, s));
     const uint8_t* Im = V.I;
     if (p.half_resolution) {
         mlaunch_half(s, V.I, V.bpl, V.Ih, V.mw, V.mh, V.mbpl);
@@ -207,11 +217,9 @@ static int compute_features(svh_matcher* m, DevView& V, const uint8_t* src, int3
     mlaunch_features(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, p.nms_n, p.nms_tau, m->margin, scale,
                      m->slots, m->flags, V.tab[1], V.cnt + 1);
     HIP_TRY(hipMemcpyAsync(V.n, V.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipGetLastError());
     V.nbins = 0;   // bin indices are (re)built by matchFeatures for the current bin grid
     V.valid = true;
-    return SVH_OK;
+    return SVH_OK;   // the caller synchronises once after both cameras
 }
 
 static int ensure_bins(svh_matcher* m, DevView& V, int32_t ub, int32_t vb) {
@@ -367,25 +375,42 @@ static int run_matching(svh_matcher* m, int dense, int32_t method, bool use_prio
     mlaunch_match(s, P, view_of(m->prev[0], dense), view_of(m->prev[1], dense), view_of(m->cur[0], dense),
                   view_of(m->cur[1], dense), nq, m->ranges_dev, use_prior ? 1 : 0, m->pm_slots, m->pm_flags,
                   m->pixel_owner, m->pm_out, m->pm_count);
-    int32_t count = 0;
-    if (refine && raw_tap) {
-        HIP_TRY(hipMemcpyAsync(&count, m->pm_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (nq > m->h_pm_cap || !m->h_cnt) {
+        (void)hipHostFree(m->h_pm);
+        HIP_TRY(hipHostMalloc((void**)&m->h_pm, (size_t)std::max(nq, 1) * sizeof(svh_p_match)));
+        if (!m->h_cnt) HIP_TRY(hipHostMalloc((void**)&m->h_cnt, sizeof(int32_t)));
+        m->h_pm_cap = std::max(nq, 1);
+    }
+    const svh_p_match* result = m->pm_out;
+    const int32_t* result_count = m->pm_count;
+    auto download = [&](std::vector<svh_p_match>& dst) -> int {
+        HIP_TRY(hipMemcpyAsync(m->h_cnt, result_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (nq > 0)
+            HIP_TRY(hipMemcpyAsync(m->h_pm, result, (size_t)nq * sizeof(svh_p_match), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        raw_tap->resize(count);
-        if (count)
-            HIP_TRY(hipMemcpy(raw_tap->data(), m->pm_out, count * sizeof(svh_p_match), hipMemcpyDeviceToHost));
+        HIP_TRY(hipGetLastError());
+        const int32_t count = std::min(*m->h_cnt, nq);
+        dst.assign(m->h_pm, m->h_pm + count);
+        return SVH_OK;
+    };
+    if (refine && raw_tap && m->taps) {
+        rc = download(*raw_tap);
+        if (rc) return rc;
     }
     if (refine) {
         const bool half = p.half_resolution != 0;
+        const int parabolic = p.refinement == 2;
         mlaunch_refine(s, m->pm_out, m->pm_count, nq, method, m->margin, sobel_of(m->prev[0], half),
-                       sobel_of(m->prev[1], half), sobel_of(m->cur[0], half), sobel_of(m->cur[1], half));
+                       sobel_of(m->prev[1], half), sobel_of(m->cur[0], half), sobel_of(m->cur[1], half),
+                       parabolic, m->pm_flags, m->pm_slots, m->pm_count + 1);
+        if (parabolic) {
+            result = m->pm_slots;
+            result_count = m->pm_count + 1;
+        }
     }
-    HIP_TRY(hipMemcpyAsync(&count, m->pm_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipGetLastError());
-    out.resize(count);
-    if (count) HIP_TRY(hipMemcpy(out.data(), m->pm_out, count * sizeof(svh_p_match), hipMemcpyDeviceToHost));
-    if (!refine && raw_tap) *raw_tap = out;
+    rc = download(out);
+    if (rc) return rc;
+    if (!refine && raw_tap && m->taps) *raw_tap = out;
     return SVH_OK;
 }
 
@@ -433,7 +458,8 @@ void svh_matcher_destroy(svh_matcher* m) {
         }
         (void)hipFree(m->slots); (void)hipFree(m->flags); (void)hipFree(m->cursor); (void)hipFree(m->pm_slots);
         (void)hipFree(m->pm_out); (void)hipFree(m->pm_flags); (void)hipFree(m->pm_count);
-        (void)hipFree(m->pixel_owner); (void)hipFree(m->ranges_dev); (void)hipHostFree(m->h_stage);
+        (void)hipFree(m->pixel_owner); (void)hipFree(m->ranges_dev); (void)hipHostFree(m->h_stage[0]);
+        (void)hipHostFree(m->h_stage[1]); (void)hipHostFree(m->h_pm); (void)hipHostFree(m->h_cnt);
         (void)hipStreamDestroy(m->stream);
     }
     delete m;
@@ -476,17 +502,17 @@ int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* 
         if (!src[k]) continue;
         int rc = ensure_view(m, m->cur[k], w, h, m->dims_c[2]);
         if (rc) return rc;
-        rc = compute_features(m, m->cur[k], src[k], pitch);
+        rc = compute_features(m, m->cur[k], k, src[k], pitch);
         if (rc) return rc;
     }
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipGetLastError());
     return SVH_OK;
 }
 
 int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double* Tr) {
     if (!m) return mfail(SVH_ERR_BAD_ARG, "null argument");
     const svh_matcher_params& p = m->p;
-    if (p.refinement == 2)
-        return mfail(SVH_ERR_UNSUPPORTED, "refinement=2 (parabolic fitting) is not implemented on the device");
     // sanity checks: return silently, previous matches stay (matcher.cpp:216-259)
     auto missing = [&](const DevView& V, int dense) { return !V.valid || V.n[dense] == 0; };
     const bool need_1p = method == 0 || method >= 2, need_2p = method >= 2;
@@ -524,7 +550,7 @@ int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double*
         if (rc) return rc;
         rc = remove_outliers(p, m->m1, method);
         if (rc) return rc;
-        m->stage[SVH_M_SPARSE] = m->m1;
+        if (m->taps) m->stage[SVH_M_SPARSE] = m->m1;
         prior_statistics(m, m->m1, method, ub, vb);
         HIP_TRY(hipMemcpyAsync(m->ranges_dev, m->ranges.data(), m->ranges.size() * sizeof(float),
                                hipMemcpyHostToDevice, m->stream));
@@ -533,10 +559,10 @@ int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double*
         rc = run_matching(m, 1, method, false, Tr, m->m2, p.refinement > 0, &m->stage[SVH_M_DENSE_RAW]);
     }
     if (rc) return rc;
-    m->stage[SVH_M_DENSE_REFINED] = m->m2;
+    if (m->taps) m->stage[SVH_M_DENSE_REFINED] = m->m2;
     rc = remove_outliers(p, m->m2, method);
     if (rc) return rc;
-    m->stage[SVH_M_DENSE] = m->m2;
+    if (m->taps) m->stage[SVH_M_DENSE] = m->m2;
     return SVH_OK;
 }
 
@@ -593,6 +619,12 @@ float svh_matcher_get_gain(svh_matcher* m, const int32_t* inliers, int32_t n) {
         }
     }
     return num > 0 ? gain / (float)num : 1;
+}
+
+int32_t svh_matcher_set_taps(svh_matcher* m, int32_t enable) {
+    if (!m) return SVH_ERR_BAD_ARG;
+    m->taps = enable != 0;
+    return SVH_OK;
 }
 
 int32_t svh_matcher_get_features(svh_matcher* m, int32_t table, int32_t* out, int32_t cap) {

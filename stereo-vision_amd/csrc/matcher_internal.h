@@ -49,9 +49,12 @@ void mlaunch_match(void* stream, const MatchParams& P, const FeatView& m1p, cons
                    const FeatView& m1c, const FeatView& m2c, int nquery_cap, const float* ranges,
                    int use_prior, svh_p_match* slots, int32_t* flags, int32_t* pixel_owner,
                    svh_p_match* out, int32_t* out_count);
+// parabolic = 0: relocateMinimum in place; 1: parabolicFitting, survivors compacted into
+// `compacted` / `compacted_count`
 void mlaunch_refine(void* stream, svh_p_match* m, const int32_t* count, int cap, int method, int margin,
                     const SobelView& s1p, const SobelView& s2p, const SobelView& s1c,
-                    const SobelView& s2c);
+                    const SobelView& s2c, int parabolic, int32_t* flags, svh_p_match* compacted,
+                    int32_t* compacted_count);
 
 int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap);
 

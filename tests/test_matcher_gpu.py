@@ -53,6 +53,7 @@ def test_matches_golden_reference_output(case):
     ({}, 2), ({"half_resolution": 0}, 2), ({"multi_stage": 0}, 2), ({"refinement": 0}, 2),
     ({"nms_n": 5, "nms_tau": 30, "match_binsize": 40}, 2), ({"half_resolution": 0}, 0),
     ({"match_radius": 120, "outlier_flow_tolerance": 3}, 1),
+    ({"refinement": 2}, 2), ({"refinement": 2, "half_resolution": 0}, 1), ({"refinement": 2}, 0),
 ])
 def test_matches_oracle_on_ragged_crop(kw, method, oracle_lib):
     """non-default parameters, width 1001 (bpl 1008); oracle = CPU restatement"""

@@ -69,6 +69,7 @@ def test_feature_tables_without_reference(oracle_lib):
     ({"half_resolution": 0}, 2), ({"multi_stage": 0}, 2), ({"refinement": 0}, 2),
     ({"nms_n": 5, "nms_tau": 30, "match_binsize": 40}, 2), ({"half_resolution": 0}, 0),
     ({"match_radius": 120, "outlier_flow_tolerance": 3}, 1),
+    ({"refinement": 2}, 2), ({"refinement": 2, "half_resolution": 0}, 1), ({"refinement": 2}, 0),
 ])
 def test_oracle_matches_reference_live(kw, method, oracle_lib):
     """non-default parameters on a crop of the quad (ragged width 1001 -> bpl 1008)"""
