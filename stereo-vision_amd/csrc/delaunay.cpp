@@ -187,6 +187,33 @@ private:
         }
     }
 
+    // The alternating-cut order is a pure function of a set of DISTINCT points (every
+    // cut takes the n/2 smallest by the lexicographic key of its axis, leaves of <= 3
+    // points are x-sorted), so it can be produced without the pivot stream: a
+    // kd-style split over two presorted lists with stable partitions.
+    std::vector<uint8_t> mark_;
+    std::vector<int32_t> tmp_;
+    void kd_order(int32_t* lx, int32_t* ly, int32_t n, int axis, int32_t*& out) {
+        if (n <= 3) {
+            for (int32_t i = 0; i < n; i++) *out++ = lx[i];
+            return;
+        }
+        const int32_t half = n >> 1;
+        int32_t* cut = axis == 0 ? lx : ly;      // list sorted by the cutting key
+        int32_t* oth = axis == 0 ? ly : lx;      // the other list is partitioned stably
+        for (int32_t i = 0; i < half; i++) mark_[cut[i]] = 1;
+        for (int32_t i = half; i < n; i++) mark_[cut[i]] = 0;
+        int32_t a = 0, b = half;
+        for (int32_t i = 0; i < n; i++) {
+            const int32_t v = oth[i];
+            if (mark_[v]) tmp_[a++] = v;
+            else          tmp_[b++] = v;
+        }
+        memcpy(oth, tmp_.data(), sizeof(int32_t) * n);
+        kd_order(lx, ly, half, 1 - axis, out);
+        kd_order(lx + half, ly + half, n - half, 1 - axis, out);
+    }
+
     void recurse(const int32_t* a, int32_t n, int axis, Handle* farleft, Handle* farright);
     void merge(Handle* farleft, Handle* innerleft, Handle* innerright, Handle* farright, int axis);
     bool scale_coordinates();
@@ -480,21 +507,57 @@ void DivConq::merge(Handle* farleft, Handle* innerleft, Handle* innerright, Hand
 int32_t DivConq::run(int32_t* out, int32_t cap) {
     if (n_ < 2) return 0;
     if (!scale_coordinates()) return SVH_ERR_UNSUPPORTED;
+    // x-sort.  For distinct points the sorted order is unique, so a plain sort is
+    // used; only when coincident points exist does the survivor depend on the
+    // reference's pivot stream, and the mirrored quicksort is run instead.
     std::vector<int32_t> order(n_);
     for (int32_t i = 0; i < n_; i++) order[i] = i;
-    sort_xy(order.data(), n_);
-    // drop coincident vertices: the first in sorted order survives
-    int32_t m = 0;
-    for (int32_t j = 1; j < n_; j++) {
-        if (X(order[m]) == X(order[j]) && Y(order[m]) == Y(order[j])) continue;
-        order[++m] = order[j];
+    auto less_xy = [&](int32_t a, int32_t b) {
+        return X(a) < X(b) || (X(a) == X(b) && Y(a) < Y(b));
+    };
+    std::sort(order.begin(), order.end(), less_xy);
+    bool dup = false;
+    for (int32_t j = 1; j < n_ && !dup; j++)
+        dup = X(order[j - 1]) == X(order[j]) && Y(order[j - 1]) == Y(order[j]);
+    int32_t m = n_;
+    if (dup) {
+        for (int32_t i = 0; i < n_; i++) order[i] = i;
+        sort_xy(order.data(), n_);
+        // drop coincident vertices: the first in sorted order survives
+        m = 0;
+        for (int32_t j = 1; j < n_; j++) {
+            if (X(order[m]) == X(order[j]) && Y(order[m]) == Y(order[j])) continue;
+            order[++m] = order[j];
+        }
+        m++;
     }
-    m++;
     if (m < 2) return 0;
-    int32_t half = m >> 1;
-    if (m - half >= 2) {
-        if (half >= 2) alternate(order.data(), half, 1);
-        alternate(order.data() + half, m - half, 1);
+    {
+        // alternating-cut order (triangle.cpp:5582-5604, 6198-6206): top cut by x at m/2,
+        // then each half starts with a y cut
+        std::vector<int32_t> ly(order.begin(), order.begin() + m), kd(m);
+        std::sort(ly.begin(), ly.end(), [&](int32_t a, int32_t b) {
+            return Y(a) < Y(b) || (Y(a) == Y(b) && X(a) < X(b));
+        });
+        mark_.assign(n_, 0);
+        tmp_.resize(m);
+        const int32_t half = m >> 1;
+        // split the y-sorted list like the x-sorted one is split at `half`
+        for (int32_t i = 0; i < half; i++) mark_[order[i]] = 1;
+        int32_t a = 0, b = half;
+        for (int32_t i = 0; i < m; i++) {
+            const int32_t v = ly[i];
+            if (mark_[v]) tmp_[a++] = v;
+            else          tmp_[b++] = v;
+        }
+        memcpy(ly.data(), tmp_.data(), sizeof(int32_t) * m);
+        int32_t* out = kd.data();
+        if (m - half >= 2) {
+            if (half >= 2) kd_order(order.data(), ly.data(), half, 1, out);
+            else for (int32_t i = 0; i < half; i++) *out++ = order[i];
+            kd_order(order.data() + half, ly.data() + half, m - half, 1, out);
+            memcpy(order.data(), kd.data(), sizeof(int32_t) * m);
+        }
     }
     nb_.reserve(3 * (2 * (size_t)m + 8));
     vx_.reserve(3 * (2 * (size_t)m + 8));
