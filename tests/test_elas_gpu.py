@@ -195,3 +195,45 @@ def test_full_hd_pairs_batch(svhip, oracle_lib):
         assert (d >= 0).mean() > 0.5 and d.max() <= 255
         # every valid value is a valid disparity or the invalid marker, nothing else
         assert np.all((d >= 0) | (d == -10))
+
+
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
+@pytest.mark.parametrize("seed,w,h,kw", [
+    (31, 1242, 200, {"disp_max": 800}),      # support strips exceed LDS -> global-memory variant
+    (32, 4200, 96, {"disp_max": 127}),       # row wider than the LDS row cache -> global-memory matcher
+    (33, 64, 48, {"disp_max": 40}),          # tiny image: a single block per kernel, few candidates
+])
+def test_fallback_kernels_and_extreme_shapes(seed, w, h, kw, svhip, oracle_lib):
+    l, r = H.synth_pair(w, h, seed, dmax=min(60, kw["disp_max"] - 8, w // 3))
+    prm = H.robotics(**kw)
+    got = product_run(svhip, prm, l, r)
+    want = H.oracle_elas_run(prm, l, r)
+    assert got.status == want.status
+    if got.status == 0:
+        assert_same(want, got)
+
+
+def test_concurrent_objects_from_threads(svhip):
+    """two caller threads, each with its own Elas per frame (stereothread / VO thread overlap,
+    maindialog.cpp:456-465, 514-518): results identical to the serial ones"""
+    import threading
+    pairs = [H.golden_pair("urban3_640x240"), H.golden_pair("urban1_1242x375")]
+    prm = H.robotics()
+    serial = [svhip.Elas(prm).process(l, r) for l, r in pairs]
+    out = {}
+
+    def work(k):
+        res = []
+        for _ in range(6):
+            l, r = pairs[k]
+            res.append(svhip.Elas(prm).process(l, r))
+        out[k] = res
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        for rc, D1, D2 in out[k]:
+            assert rc == 0 and np.array_equal(D1, serial[k][1]) and np.array_equal(D2, serial[k][2])
