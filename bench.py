@@ -315,6 +315,19 @@ def main():
                        "d1_valid_fraction": round(valid, 4)},
             "roofline": roofline,
         }
+        if world == 1:
+            # single-stream latency of the reference-style call: one pair, pageable HOST buffers in
+            # and out (PCIe-inclusive; never part of `value`)
+            e1 = S.Elas(params)
+            D1h = np.zeros((H, W), np.float32)
+            D2h = np.zeros((H, W), np.float32)
+            for _ in range(3):
+                e1.process(I1[0], I2[0], D1h, D2h)
+            t = time.perf_counter()
+            for i in range(20):
+                e1.process(I1[i % B], I2[i % B], D1h, D2h)
+            out["latency_ms_single_pair_host_buffers"] = 1e3 * (time.perf_counter() - t) / 20
+            out["latency_stages_ms"] = {k: round(v, 3) for k, v in e1.last_timing()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(I1, I2, params)
             out["matcher"] = matcher_bench()

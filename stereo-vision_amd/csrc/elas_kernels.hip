@@ -563,8 +563,9 @@ __global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri, int W,
                 if (sub && (v & 1)) continue;
                 int32_t* px = &owner[(size_t)v * W + u];
                 if (kFix) {
-                    if (__hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t)
-                        atomicMax(px, t);
+                    // a plain (possibly L1-stale) read is enough: owners only grow, so a stale
+                    // value can only trigger a redundant atomicMax, never suppress a needed one
+                    if (*px < t) atomicMax(px, t);
                 } else {
                     *px = t;
                 }

@@ -237,3 +237,27 @@ def test_concurrent_objects_from_threads(svhip):
     for k in range(2):
         for rc, D1, D2 in out[k]:
             assert rc == 0 and np.array_equal(D1, serial[k][1]) and np.array_equal(D2, serial[k][2])
+
+
+def test_streamed_sequence_of_430_frames(svhip):
+    """BASELINE.json configs[2] stand-in (the KITTI drive_0029 images are not in the reference):
+    430 KITTI-sized frames, the two golden 1242x375 crops cycled, streamed from host memory through
+    the lanes; every frame must reproduce the reference's output for its pair."""
+    z = {c: np.load(os.path.join(H.GOLDEN, c + ".npz")) for c in ("urban1_robotics",)}
+    l1, r1 = H.golden_pair("urban1_1242x375")
+    l2, r2 = H.golden_pair("urban2_1242x375")
+    prm = H.robotics()
+    rc, A1, A2 = svhip.Elas(prm).process(l2, r2)          # expected output of the second pair
+    assert rc == 0
+    n = 430
+    I1 = np.stack([l1 if i % 2 == 0 else l2 for i in range(n)])
+    I2 = np.stack([r1 if i % 2 == 0 else r2 for i in range(n)])
+    st, D1, D2 = svhip.Elas(prm).process_batch(I1, I2)
+    assert all(s == 0 for s in st)
+    g1 = z["urban1_robotics"]["d1"].reshape(375, 1242)
+    g2 = z["urban1_robotics"]["d2"].reshape(375, 1242)
+    for i in range(n):
+        if i % 2 == 0:
+            assert np.array_equal(D1[i], g1) and np.array_equal(D2[i], g2), i
+        else:
+            assert np.array_equal(D1[i], A1) and np.array_equal(D2[i], A2), i
