@@ -591,9 +591,15 @@ struct MatchParams {
 template <bool kLds>
 __global__ __launch_bounds__(kLds ? 512 : 256) void k_match(GroupDev G, MatchParams P) {
     extern __shared__ uint4 s_row[];
+    __shared__ int s_P[64];
     const int z = blockIdx.z, pair = z >> 1, side = z & 1;
     if (!G.hdr->active[pair]) return;
     const int y = kLds ? blockIdx.y : blockIdx.y * 4 + threadIdx.y;
+    {
+        // prior table: only |d - d_plane| <= plane_radius is ever indexed
+        const int tl = kLds ? (int)threadIdx.x : (int)(threadIdx.y * 64 + threadIdx.x);
+        if (tl < 64) s_P[tl] = tl <= P.disp_max ? G.P[tl] : 0;
+    }
     const size_t N = (size_t)P.W * P.H;
     const int mul = P.sub ? 2 : 1;
     const int v = y * mul;
@@ -602,25 +608,24 @@ __global__ __launch_bounds__(kLds ? 512 : 256) void k_match(GroupDev G, MatchPar
     const uint4* oth_line =
         reinterpret_cast<const uint4*>(G.desc + (size_t)(z ^ 1) * N * 16) + (size_t)line * P.W;
     const int s0 = 0;
-    if (kLds) {
+    if (kLds)
         for (int i = threadIdx.x; i < P.W; i += blockDim.x) s_row[i] = oth_line[i];
-        __syncthreads();
-    }
+    __syncthreads();
     for (int x = kLds ? (int)threadIdx.x : (int)(blockIdx.x * 64 + threadIdx.x); x < P.DW;
          x += kLds ? (int)blockDim.x : P.DW) {
     if (y >= P.DH) return;
     const int u = x * mul;
     float out = -10.f;
+    const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
     const int t = G.owner[(size_t)z * N + (size_t)v * P.W + u];
     if (t >= 0 && u >= 2 && u < P.W - 2) {
         const uint4* own_line =
             reinterpret_cast<const uint4*>(G.desc + (size_t)z * N * 16) + (size_t)line * P.W;
         const uint4 own = own_line[u];
         if ((int)texture16(own) >= P.match_texture) {
-            const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
-            const TriRaster* tr = G.raster + tri0 + t;
-            const float pa = tr->pa, pb = tr->pb, pc = tr->pc;
-            const int valid = tr->valid;
+            const float4 pl = *reinterpret_cast<const float4*>(G.raster + tri0 + t);   // pa pb pc valid
+            const float pa = pl.x, pb = pl.y, pc = pl.z;
+            const int valid = __float_as_int(pl.w);
             const int d_plane = (int)__fadd_rn(
                 __fadd_rn(__fmul_rn(pa, (float)u), __fmul_rn(pb, (float)v)), pc);
             int dlo = d_plane - P.plane_radius;
@@ -630,8 +635,25 @@ __global__ __launch_bounds__(kLds ? 512 : 256) void k_match(GroupDev G, MatchPar
             const int cell = (v / P.grid_size) * P.gw + u / P.grid_size;
             const uint32_t* bits = G.mask + ((size_t)z * P.gw * P.gh + cell) * P.gwords;
             int min_val = 10000, min_d = -1;
+            // candidate disparities of the cell, ascending; the 32-byte bit set of the common
+            // disp_max = 255 case is fetched with two 16-byte loads before the loop starts
+            uint32_t wbuf[8];
+            const bool fast8 = P.gwords == 8;
+            if (fast8) {
+                const uint4 lo4 = reinterpret_cast<const uint4*>(bits)[0];
+                const uint4 hi4 = reinterpret_cast<const uint4*>(bits)[1];
+                wbuf[0] = lo4.x; wbuf[1] = lo4.y; wbuf[2] = lo4.z; wbuf[3] = lo4.w;
+                wbuf[4] = hi4.x; wbuf[5] = hi4.y; wbuf[6] = hi4.z; wbuf[7] = hi4.w;
+            }
             for (int w = 0; w < P.gwords; w++) {
-                uint32_t b = bits[w];
+                uint32_t b;
+                if (fast8) {
+                    b = wbuf[0];
+#pragma unroll
+                    for (int q = 1; q < 8; q++) b = (w == q) ? wbuf[q] : b;
+                } else {
+                    b = bits[w];
+                }
                 while (b) {
                     const int dc = w * 32 + __builtin_ctz(b);
                     b &= b - 1;
@@ -653,7 +675,7 @@ __global__ __launch_bounds__(kLds ? 512 : 256) void k_match(GroupDev G, MatchPar
                 int dd = dc - d_plane;
                 dd = dd < 0 ? -dd : dd;
                 const uint4 o = kLds ? s_row[uw - s0] : oth_line[uw];
-                const int val = (int)sad16(own, o) + (valid ? G.P[dd] : 0);
+                const int val = (int)sad16(own, o) + (valid ? (dd < 64 ? s_P[dd] : G.P[dd]) : 0);
                 if (val < min_val) {
                     min_val = val;
                     min_d = dc;

@@ -40,14 +40,16 @@ struct GroupHdr {
 
 // One rasterisation record per triangle and image side, computed on the device
 // by k_prior with the reference's arithmetic (elas.cpp:605-680, 1026-1072).
-struct TriRaster {
+struct alignas(16) TriRaster {
+    float pa, pb, pc;          // disparity plane of this side   } one 16-byte load in the
+    int32_t valid;             // |plane_a|<0.7 && |plane_d|<0.7 } matcher
     int32_t uA, uB, uC;        // (int32)A_u, (int32)B_u, (int32)C_u
     float ACa, ACb;            // long edge
     float ABa, ABb;            // first part
     float BCa, BCb;            // second part
-    float pa, pb, pc;          // disparity plane of this side
-    int32_t valid;             // |plane_a|<0.7 && |plane_d|<0.7
+    int32_t pad_[3];
 };
+static_assert(sizeof(TriRaster) == 64, "TriRaster is one 64-byte record");
 
 // Host-side result of stages E4(second half)..E7 for one pair.
 struct HostPrior {
