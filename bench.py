@@ -172,6 +172,9 @@ def main():
     ap.add_argument("--profile-in-timed-region", type=int, default=1,
                     help="1: HIP-event kernel timing is on during the timed steps (roofline comes "
                          "from exactly those launches); 0: a separate pass after them")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL, the default) or gloo (CPU collectives: lets several ranks "
+                         "share one GPU when the multi-rank path is smoke-tested on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -183,11 +186,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where collectives run
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import svhip as S
     import helpers as Hh
@@ -249,13 +258,13 @@ def main():
         S.lib().svh_profile_enable(0)
         S.lib().svh_profile_only(None)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the only collective on the path: a tiny per-rank result record over RCCL
         from svhip import shard
         recs = shard.gather_records([float(B * args.steps), float((dD1[0] >= 0).sum().item())],
-                                    dist, dev)
+                                    dist, cdev)
         total_pairs = int(recs[:, 0].sum())
     else:
         total_pairs = B * args.steps
