@@ -31,9 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "stereo-vision_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-W, H = 1242, 375
+W, H = 1242, 375        # --workload kitti (BASELINE.json configs[1]); hd1080 rebinds these
 N_PIX = W * H
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALG_BYTES_PER_PIXEL_PAIR = 174.8   # staged model, whole Elas::process, per pixel
 
 # algorithmic bytes per pair and kernel launch (SURVEY 8d staged model, N = W*H)
 ALG_BYTES_PER_PIXEL = {
@@ -41,10 +42,10 @@ ALG_BYTES_PER_PIXEL = {
     "k_support": 12.8,      # rows v+-2 of a 5-row lattice, both images
     "k_match": 72.0,        # 2 x (16 own + 16 other + 4 out)
     "k_lr": 16.0,
-    "k_seg_runs": 8.0, "k_seg_link": 8.0, "k_seg_count": 8.0, "k_seg_mask": 8.0,
+    "k_seg_tile": 8.0, "k_seg_border": 8.0, "k_seg_sum": 8.0, "k_seg_mask": 8.0,
     "k_gap_rows": 8.0, "k_gap_cols": 8.0,
     "k_mean_h": 8.0, "k_mean_v": 8.0,
-    "k_owner": 8.0,
+    "k_owner": 8.0, "k_owner_fix": 8.0,
 }
 
 
@@ -53,7 +54,7 @@ def make_inputs(batch, seed0=1000):
     I1 = np.empty((batch, H, W), np.uint8)
     I2 = np.empty((batch, H, W), np.uint8)
     for i in range(batch):
-        I1[i], I2[i] = Hh.synth_pair(W, H, seed0 + i, dmax=96, planes=8)
+        I1[i], I2[i] = Hh.synth_pair(W, H, seed0 + i, dmax=96 if W < 1500 else 200, planes=8)
     return I1, I2
 
 
@@ -92,8 +93,8 @@ def cpu_baseline(I1, I2, params, budget_s=15.0):
         i += 1
     return {"value": n_done / t_used, "unit": "pairs/s", "cores": 1, "kind": kind,
             "ms_per_pair": 1e3 * t_used / n_done,
-            "sample": "%d x Elas::process on the bench's own 1242x375 synthetic pairs, 1 thread, "
-                      "%s" % (n_done, "oracle/_ref (reference compiled -O3 -msse3)" if kind == "reference"
+            "sample": "%d x Elas::process on the bench's own %dx%d synthetic pairs, 1 thread, "
+                      "%s" % (n_done, W, H, "oracle/_ref (reference compiled -O3 -msse3)" if kind == "reference"
                               else "oracle/ scalar port"),
             "host": _cpu_model(), "host_cores": os.cpu_count()}
 
@@ -164,7 +165,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="pairs per step and GPU")
+    ap.add_argument("--workload", choices=("kitti", "hd1080"), default="kitti",
+                    help="kitti = BASELINE.json configs[1] (the headline: 1242x375); hd1080 = "
+                         "configs[3] / SURVEY 8(d) config 4 (synthetic 1920x1080, disp_max 255)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="pairs per step and GPU (0 = 128 for kitti, 8 for hd1080)")
     ap.add_argument("--lanes", type=int, default=0, help="pipeline lanes per GPU (0 = auto)")
     ap.add_argument("--group", type=int, default=4, help="pairs per kernel launch (1..16)")
     ap.add_argument("--spinup", type=float, default=1.0,
@@ -177,6 +182,12 @@ def main():
                          "share one GPU when the multi-rank path is smoke-tested on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    global W, H, N_PIX
+    if args.workload == "hd1080":
+        W, H = 1920, 1080
+        N_PIX = W * H
+    if args.batch <= 0:
+        args.batch = 128 if args.workload == "kitti" else 8
 
     import torch
     import torch.distributed as dist
@@ -298,13 +309,31 @@ def main():
                                                  "read = 2*FETCH_SIZE*1024 (gfx950), scaled to pairs per launch"
             except (OSError, IndexError, KeyError, ValueError):
                 pass
+            # whole-path view: staged-model bytes of all pairs / wall time
+            e2e = ALG_BYTES_PER_PIXEL_PAIR * N_PIX * B * args.steps / elapsed / 1e9
+            roofline["end_to_end"] = {"alg_bytes_per_pair": ALG_BYTES_PER_PIXEL_PAIR * N_PIX,
+                                      "achieved": e2e, "frac": e2e / HBM_PEAK_GBS,
+                                      "note": "this rank's pairs; staged model 174.8 B/pixel"}
+            # the box's own copy bandwidth (device-to-device, read + write counted)
+            src = torch.empty(1 << 29, dtype=torch.uint8, device=dev)
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            for _ in range(10):
+                dst.copy_(src)
+            torch.cuda.synchronize()
+            copy_gbs = 10 * 2 * src.numel() / (time.perf_counter() - tc) / 1e9
+            del src, dst
+            roofline["measured_copy_GBps"] = copy_gbs
+            roofline["frac_of_measured_copy"] = achieved / copy_gbs
     if world > 1:
         dist.barrier()
 
     if rank == 0:
         valid = float((dD1 >= 0).float().mean().item())
         out = {
-            "metric": "stereo pairs/sec (ELAS 1242x375, ROBOTICS, D1+D2+LR)",
+            "metric": "stereo pairs/sec (ELAS %dx%d, ROBOTICS, D1+D2+LR)" % (W, H),
             "value": total_pairs / elapsed,
             "unit": "pairs/s",
             "n_gpus": world,
@@ -317,8 +346,10 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: KITTI-size 1242x375 pairs, ELAS ROBOTICS, D1+D2 + "
-                                   "LR-check, subsampling=false, inputs and outputs resident in HBM",
+            "config": {"workload": ("configs[1]: KITTI-size 1242x375 pairs" if args.workload == "kitti"
+                                    else "configs[3]: synthetic 1920x1080 pairs, disp_max 255") +
+                                   ", ELAS ROBOTICS, D1+D2 + LR-check, subsampling=false, inputs "
+                                   "and outputs resident in HBM",
                        "pairs_per_step_per_gpu": B, "lanes_per_gpu": lanes,
                        "pairs_per_launch": group,
                        "d1_valid_fraction": round(valid, 4)},

@@ -29,8 +29,10 @@ constexpr int kWave = 64;
 // instead of six ds_bpermute round trips through the LDS crossbar.
 template <int kCtrl, int kRowMask>
 __device__ __forceinline__ uint32_t dpp_min_step(uint32_t v) {
-    // lanes without a valid source (or masked rows) read back `v` itself
-    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, kCtrl, kRowMask, 0xF, false);
+    // lanes without a valid source (or masked rows) get the identity of min, which lets the
+    // compiler fold the DPP move into the v_min_u32 itself (one VALU op per step)
+    const uint32_t o =
+        (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, kCtrl, kRowMask, 0xF, false);
     return o < v ? o : v;
 }
 
@@ -51,6 +53,24 @@ __device__ __forceinline__ uint32_t sad16(const uint4& a, const uint4& b) {
     s = __builtin_amdgcn_sad_u8(a.z, b.z, s);
     s = __builtin_amdgcn_sad_u8(a.w, b.w, s);
     return s;
+}
+
+// same, continuing a running sum (v_sad_u8 adds its third operand for free)
+__device__ __forceinline__ uint32_t sad16_acc(const uint4& a, const uint4& b, uint32_t s) {
+    s = __builtin_amdgcn_sad_u8(a.x, b.x, s);
+    s = __builtin_amdgcn_sad_u8(a.y, b.y, s);
+    s = __builtin_amdgcn_sad_u8(a.z, b.z, s);
+    s = __builtin_amdgcn_sad_u8(a.w, b.w, s);
+    return s;
+}
+
+// best / second best update: best2 = median(best1, best2, key), best1 = min(best1, key)
+// (the strict-"<" chain of elas.cpp:419-427 on keys E<<16|d, two VALU ops)
+__device__ __forceinline__ void keep_two(uint32_t key, uint32_t& best1, uint32_t& best2) {
+    uint32_t m;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(best1), "v"(best2), "v"(key));
+    best2 = m;
+    best1 = key < best1 ? key : best1;
 }
 
 // descriptor texture: sum |byte - 128| (elas.cpp:358-362, 851-855)
@@ -190,16 +210,10 @@ __device__ __forceinline__ int support_match(const uint8_t* __restrict__ own,
         if (d <= dmax) {
             const ptrdiff_t sh = right ? d : -d;
             uint32_t e = sad16(r0, othq[o0 + sh]);
-            e += sad16(r1, othq[o1 + sh]);
-            e += sad16(r2, othq[o2 + sh]);
-            e += sad16(r3, othq[o3 + sh]);
-            const uint32_t key = (e << 16) | (uint32_t)d;
-            if (key < best1) {
-                best2 = best1;
-                best1 = key;
-            } else if (key < best2) {
-                best2 = key;
-            }
+            e = sad16_acc(r1, othq[o1 + sh], e);
+            e = sad16_acc(r2, othq[o2 + sh], e);
+            e = sad16_acc(r3, othq[o3 + sh], e);
+            keep_two((e << 16) | (uint32_t)d, best1, best2);
         }
     }
     const uint32_t m1 = wave_min_u32(best1);
@@ -266,16 +280,10 @@ __device__ __forceinline__ int support_match_lds(const StripView& own, const Str
         if (d <= dmax) {
             const int uw = right ? u + d : u - d;
             uint32_t e = sad16(r0, oth.at(0, uw - 2));
-            e += sad16(r1, oth.at(0, uw + 2));
-            e += sad16(r2, oth.at(1, uw - 2));
-            e += sad16(r3, oth.at(1, uw + 2));
-            const uint32_t key = (e << 16) | (uint32_t)d;
-            if (key < best1) {
-                best2 = best1;
-                best1 = key;
-            } else if (key < best2) {
-                best2 = key;
-            }
+            e = sad16_acc(r1, oth.at(0, uw + 2), e);
+            e = sad16_acc(r2, oth.at(1, uw - 2), e);
+            e = sad16_acc(r3, oth.at(1, uw + 2), e);
+            keep_two((e << 16) | (uint32_t)d, best1, best2);
         }
     }
     const uint32_t m1 = wave_min_u32(best1);
