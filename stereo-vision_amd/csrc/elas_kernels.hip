@@ -591,6 +591,7 @@ __global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri, int W,
 struct MatchParams {
     int W, H, DW, DH, gw, gh, gwords, grid_size, sub;
     int disp_max, match_texture, plane_radius;
+    uint32_t grid_magic;   // floor(2^32 / grid_size) + 1: u / grid_size == mulhi(u, magic), u < 2^16
 };
 
 // kLds: one block = one row of the disparity map; the OTHER image's descriptor
@@ -693,6 +694,166 @@ __global__ __launch_bounds__(kLds ? 512 : 256) void k_match(GroupDev G, MatchPar
         }
     }
     G.Draw[(size_t)z * P.DW * P.DH + (size_t)y * P.DW + x] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// E11, issue-lean variant (the default).  k_match above is bound by instruction
+// issue (VALU + SALU, rocprofv3 SQ counters), not by memory, so this version
+// spends fewer instructions per candidate:
+//  * the reference's "first minimum wins" scan order (cell candidates outside
+//    the plane band ascending, then the band ascending; elas.cpp:868-953) is
+//    encoded in the key  cost*1024 + rank  with rank = d for cell candidates and
+//    512 + d for band candidates; the winner is then a plain minimum, so the
+//    candidates can be evaluated in any order, two per loop trip (two LDS reads
+//    in flight, one v_min3), without the ordered compare/select chain;
+//  * band bits are cleared from the cell's bit set up front (no per-candidate
+//    band test) and the warp-range test is skipped when the whole wave is far
+//    enough from the image border (wave-uniform branch);
+//  * u / grid_size is one v_mul_hi.
+// Needs |cost| < 2^20 and d < 512; launch_match falls back to k_match otherwise.
+// ---------------------------------------------------------------------------
+template <bool kCheck>
+__device__ __forceinline__ void scan_word(uint32_t b, int base, int u, int sgn, int W, const uint4& own,
+                                          const uint4* row, int& best) {
+    while (b) {
+        const int i0 = __builtin_ctz(b);
+        b &= b - 1;
+        const bool has1 = b != 0;
+        const int i1 = has1 ? __builtin_ctz(b) : i0;   // odd count: evaluate the same one twice
+        b &= b - 1;
+        const int dc0 = base + i0, dc1 = base + i1;
+        int uw0 = u + __mul24(sgn, dc0), uw1 = u + __mul24(sgn, dc1);
+        bool ok0 = true, ok1 = true;
+        if (kCheck) {
+            ok0 = (uint32_t)(uw0 - 2) < (uint32_t)(W - 4);
+            ok1 = (uint32_t)(uw1 - 2) < (uint32_t)(W - 4);
+            uw0 = ok0 ? uw0 : 2;
+            uw1 = ok1 ? uw1 : 2;
+        }
+        const uint4 o0 = row[uw0], o1 = row[uw1];
+        int k0 = (int)(sad16(own, o0) << 10) + dc0;
+        int k1 = (int)(sad16(own, o1) << 10) + dc1;
+        if (kCheck) {
+            k0 = ok0 ? k0 : 0x7FFFFFFF;
+            k1 = ok1 ? k1 : 0x7FFFFFFF;
+        }
+        const int k = k0 < k1 ? k0 : k1;
+        best = k < best ? k : best;
+    }
+}
+
+template <bool kCheck>
+__device__ __forceinline__ float match_pixel_keyed(const uint4& own, const float4& pl, int u, int v, int sgn,
+                                                   const uint4* row, const uint32_t* __restrict__ bits,
+                                                   const int* s_P, const int32_t* __restrict__ gP,
+                                                   const MatchParams& P) {
+    const int valid = __float_as_int(pl.w);
+    const int d_plane =
+        (int)__fadd_rn(__fadd_rn(__fmul_rn(pl.x, (float)u), __fmul_rn(pl.y, (float)v)), pl.z);
+    int dlo = d_plane - P.plane_radius;
+    dlo = dlo > 0 ? dlo : 0;
+    int dhi = d_plane + P.plane_radius;
+    dhi = dhi < P.disp_max ? dhi : P.disp_max;
+    const int len = dhi - dlo + 1;   // <= 2*radius+1 <= 31; <= 0: empty band
+    // clear the band from the bit set: it spans at most two words
+    int wlo = -9;
+    uint32_t m0 = ~0u, m1 = ~0u;
+    if (len > 0) {
+        const uint32_t bm = (1u << len) - 1u;
+        const int sh = dlo & 31;
+        wlo = dlo >> 5;
+        m0 = ~(bm << sh);
+        m1 = sh ? ~(bm >> (32 - sh)) : ~0u;
+    }
+    int best = 0x7FFFFFFF;
+    if (P.gwords == 8) {
+        const uint4 lo4 = reinterpret_cast<const uint4*>(bits)[0];
+        const uint4 hi4 = reinterpret_cast<const uint4*>(bits)[1];
+        const uint32_t wb[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t keep = q == wlo ? m0 : (q == wlo + 1 ? m1 : ~0u);
+            scan_word<kCheck>(wb[q] & keep, q * 32, u, sgn, P.W, own, row, best);
+        }
+    } else {
+        for (int q = 0; q < P.gwords; q++) {
+            const uint32_t keep = q == wlo ? m0 : (q == wlo + 1 ? m1 : ~0u);
+            scan_word<kCheck>(bits[q] & keep, q * 32, u, sgn, P.W, own, row, best);
+        }
+    }
+    // the band, two disparities per trip, with the plane prior
+    for (int dc = dlo; dc <= dhi; dc += 2) {
+        const int dc1 = dc + 1 <= dhi ? dc + 1 : dc;
+        int uw0 = u + __mul24(sgn, dc), uw1 = u + __mul24(sgn, dc1);
+        bool ok0 = true, ok1 = true;
+        if (kCheck) {
+            ok0 = (uint32_t)(uw0 - 2) < (uint32_t)(P.W - 4);
+            ok1 = (uint32_t)(uw1 - 2) < (uint32_t)(P.W - 4);
+            uw0 = ok0 ? uw0 : 2;
+            uw1 = ok1 ? uw1 : 2;
+        }
+        const uint4 o0 = row[uw0], o1 = row[uw1];
+        int dd0 = dc - d_plane, dd1 = dc1 - d_plane;
+        dd0 = dd0 < 0 ? -dd0 : dd0;
+        dd1 = dd1 < 0 ? -dd1 : dd1;
+        const int p0 = valid ? (dd0 < 64 ? s_P[dd0] : gP[dd0]) : 0;
+        const int p1 = valid ? (dd1 < 64 ? s_P[dd1] : gP[dd1]) : 0;
+        int k0 = ((int)sad16(own, o0) + p0) * 1024 + 512 + dc;
+        int k1 = ((int)sad16(own, o1) + p1) * 1024 + 512 + dc1;
+        if (kCheck) {
+            k0 = ok0 ? k0 : 0x7FFFFFFF;
+            k1 = ok1 ? k1 : 0x7FFFFFFF;
+        }
+        const int k = k0 < k1 ? k0 : k1;
+        best = k < best ? k : best;
+    }
+    return best != 0x7FFFFFFF ? (float)(best & 511) : -1.f;
+}
+
+__global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P) {
+    extern __shared__ uint4 s_row[];
+    __shared__ int s_P[64];
+    const int z = blockIdx.z, pair = z >> 1, side = z & 1;
+    if (!G.hdr->active[pair]) return;
+    const int y = blockIdx.y;
+    if (threadIdx.x < 64) s_P[threadIdx.x] = (int)threadIdx.x <= P.disp_max ? G.P[threadIdx.x] : 0;
+    const size_t N = (size_t)P.W * P.H;
+    const int mul = P.sub ? 2 : 1;
+    const int v = y * mul;
+    int line = v < P.H - 3 ? v : P.H - 3;
+    line = line > 2 ? line : 2;
+    const uint4* oth_line =
+        reinterpret_cast<const uint4*>(G.desc + (size_t)(z ^ 1) * N * 16) + (size_t)line * P.W;
+    const uint4* own_line =
+        reinterpret_cast<const uint4*>(G.desc + (size_t)z * N * 16) + (size_t)line * P.W;
+    for (int i = threadIdx.x; i < P.W; i += blockDim.x) s_row[i] = oth_line[i];
+    __syncthreads();
+    const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
+    const int sgn = side ? 1 : -1;
+    const int32_t* own_t = G.owner + (size_t)z * N + (size_t)v * P.W;
+    const uint32_t* row_bits =
+        G.mask + ((size_t)z * P.gw * P.gh + (size_t)(v / P.grid_size) * P.gw) * P.gwords;
+    float* out_row = G.Draw + (size_t)z * P.DW * P.DH + (size_t)y * P.DW;
+    for (int x = threadIdx.x; x < P.DW; x += blockDim.x) {
+        const int u = x * mul;
+        float out = -10.f;
+        const int t = own_t[u];
+        const bool live = t >= 0 && u >= 2 && u < P.W - 2;
+        // every disparity up to disp_max warps inside [2, W-2) for the whole wave?
+        const bool inner = side ? u + P.disp_max < P.W - 2 : u - P.disp_max >= 2;
+        const bool wave_inner = __builtin_amdgcn_ballot_w64(live && !inner) == 0;
+        if (live) {
+            const uint4 own = own_line[u];
+            if ((int)texture16(own) >= P.match_texture) {
+                const float4 pl = *reinterpret_cast<const float4*>(G.raster + tri0 + t);
+                const uint32_t* bits = row_bits + (size_t)__umulhi((uint32_t)u, P.grid_magic) * P.gwords;
+                out = wave_inner
+                          ? match_pixel_keyed<false>(own, pl, u, v, sgn, s_row, bits, s_P, G.P, P)
+                          : match_pixel_keyed<true>(own, pl, u, v, sgn, s_row, bits, s_P, G.P, P);
+            }
+        }
+        out_row[x] = out;
     }
 }
 
@@ -1421,7 +1582,7 @@ void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d
         else if (variant == 1) hipLaunchKernelGGL((k_support_lds<32, 512>), grid, dim3(512), lds, s, desc, dcan, P);
         else if (variant == 2) hipLaunchKernelGGL((k_support_lds<64, 1024>), grid, dim3(1024), lds, s, desc, dcan, P);
         else {
-            static bool once = (hipFuncSetAttribute((const void*)k_support_lds<128, 1024>,
+            static bool once = ((void)hipFuncSetAttribute((const void*)k_support_lds<128, 1024>,
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), true);
             (void)once;
             hipLaunchKernelGGL((k_support_lds<128, 1024>), grid, dim3(1024), lds, s, desc, dcan, P);
@@ -1463,15 +1624,24 @@ void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     P.W = d.W; P.H = d.H; P.DW = d.DW; P.DH = d.DH; P.gw = d.gw; P.gh = d.gh; P.gwords = d.gwords;
     P.grid_size = p.grid_size; P.sub = p.subsampling; P.disp_max = p.disp_max;
     P.match_texture = p.match_texture; P.plane_radius = G.plane_radius;
+    P.grid_magic = (uint32_t)(0x100000000ull / (uint64_t)p.grid_size) + 1u;
     const size_t lds = (size_t)d.W * sizeof(uint4);
+    // the keyed kernel packs cost and scan rank into one int32 (see k_match_keyed)
+    static const bool ordered = getenv("SVH_MATCH_ORDERED") != nullptr;
+    const bool keyed_ok = !ordered && G.prior_absmax < (1 << 19) && p.disp_max < 512 &&
+                          G.plane_radius <= 15 && d.W < 65536 && p.grid_size > 1;
     if (lds <= 64 * 1024) {
         Timed timed_(cx, "k_match");
         // threads per row block: the row is covered in `iters` equal passes with little idle tail
         static const int mt = getenv("SVH_MATCH_THREADS") ? atoi(getenv("SVH_MATCH_THREADS")) : 256;
         const int iters = (d.DW + mt - 1) / mt;
         const int threads = std::min(512, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
-        hipLaunchKernelGGL(k_match<true>, dim3(1, d.DH, 2 * g), dim3(threads), lds,
-                           (hipStream_t)cx.stream, G, P);
+        if (keyed_ok)
+            hipLaunchKernelGGL(k_match_keyed, dim3(1, d.DH, 2 * g), dim3(threads), lds,
+                               (hipStream_t)cx.stream, G, P);
+        else
+            hipLaunchKernelGGL(k_match<true>, dim3(1, d.DH, 2 * g), dim3(threads), lds,
+                               (hipStream_t)cx.stream, G, P);
     } else {
         LAUNCH("k_match", k_match<false>, grid2d(d.DW, d.DH, 2 * g), dim3(64, 4), G, P);
     }

@@ -109,6 +109,7 @@ struct GroupDev {
     int32_t* owner;            // [g][2][N]
     float* Draw;               // [g][2][DN]
     int32_t plane_radius;
+    int32_t prior_absmax;      // max |P[dd]|, dd <= plane_radius (selects the keyed match kernel)
 };
 
 void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t g, int32_t W, int32_t H,
