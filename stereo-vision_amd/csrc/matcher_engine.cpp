@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "matcher_internal.h"
@@ -91,6 +92,7 @@ struct svh_matcher {
     // scratch
     int4* slots = nullptr;
     int32_t* flags = nullptr;
+    int32_t* order = nullptr;
     int32_t slot_cap = 0;
     int32_t* cursor = nullptr;
     int32_t cursor_cap = 0;
@@ -105,13 +107,24 @@ struct svh_matcher {
     size_t h_stage_cap[2] = {0, 0};
     svh_p_match* h_pm = nullptr;                // pinned download staging for match lists
     int32_t* h_cnt = nullptr;                   // pinned: match count
+    int32_t* h_n = nullptr;                     // pinned: feature counts [camera][sparse, dense]
     int32_t h_pm_cap = 0;
     bool taps = false;                          // keep every intermediate stage (parity tests)
     // results
     std::vector<svh_p_match> m1, m2;
     std::vector<float> ranges;    // [bins][16]
     std::vector<svh_p_match> stage[SVH_M_STAGE_COUNT];
+    // SVH_MATCHER_TIMING=1: host wall-clock per step, printed by svh_matcher_destroy
+    double tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double tfine[6] = {0, 0, 0, 0, 0, 0};
+    int64_t tcalls[2] = {0, 0};
 };
+
+static double mnow_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static const bool g_mtiming = getenv("SVH_MATCHER_TIMING") != nullptr;
+enum { T_PACK = 0, T_PUSH_GPU, T_SPARSE, T_OUT1, T_PRIOR, T_DENSE, T_OUT2 };
 
 namespace svh {
 
@@ -154,9 +167,10 @@ static int ensure_view(svh_matcher* m, DevView& V, int32_t w, int32_t h, int32_t
 
 static int ensure_scratch(svh_matcher* m, int32_t slot_need, int32_t pm_need, size_t owner_need) {
     if (slot_need > m->slot_cap) {
-        (void)hipFree(m->slots); (void)hipFree(m->flags);
+        (void)hipFree(m->slots); (void)hipFree(m->flags); (void)hipFree(m->order);
         HIP_TRY(dalloc(&m->slots, (size_t)slot_need));
-        HIP_TRY(dalloc(&m->flags, (size_t)slot_need));
+        HIP_TRY(dalloc(&m->flags, (size_t)slot_need + 4));
+        HIP_TRY(dalloc(&m->order, (size_t)slot_need));
         m->slot_cap = slot_need;
     }
     if (pm_need > m->pm_cap) {
@@ -189,6 +203,9 @@ static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* 
     // rows are packed at the aligned pitch in pinned memory, then one linear DMA;
     // the previous pushBack ended with a stream sync, so the staging buffer is free
     uint8_t* stage = m->h_stage[cam];
+    double tf[6] = {0, 0, 0, 0, 0, 0};
+    auto ftick = [&](int i) { if (g_mtiming) tf[i] = mnow_ms(); };
+    ftick(0);
     V.host.resize(fn);
     for (int32_t v = 0; v < V.h; v++) {
         uint8_t* row = stage + (size_t)v * V.bpl;
@@ -196,7 +213,9 @@ static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* 
         memset(row + V.w, 0, V.bpl - V.w);
     }
     memcpy(V.host.data(), stage, fn);
+    ftick(1);
     HIP_TRY(hipMemcpyAsync(V.I, stage, fn, hipMemcpyHostToDevice, s));
+    ftick(2);
     const uint8_t* Im = V.I;
     if (p.half_resolution) {
         mlaunch_half(s, V.I, V.bpl, V.Ih, V.mw, V.mh, V.mbpl);
@@ -204,6 +223,7 @@ static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* 
         mlaunch_filters(s, V.I, V.w, V.h, V.bpl, V.du_full, V.dv_full, nullptr, nullptr);
     }
     mlaunch_filters(s, Im, V.mw, V.mh, V.mbpl, V.du, V.dv, V.f1, V.f2);
+    ftick(3);
     const int32_t scale = p.half_resolution ? 2 : 1;
     int32_t ns = p.nms_n * 3;
     if (ns > 10) ns = std::max(p.nms_n, 10);
@@ -211,12 +231,18 @@ static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* 
     if (rc) return rc;
     if (p.multi_stage)
         mlaunch_features(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, ns, p.nms_tau, m->margin, scale,
-                         m->slots, m->flags, V.tab[0], V.cnt + 0);
+                         m->slots, m->flags, m->order, V.tab[0], V.cnt + 0);
     else
         HIP_TRY(hipMemsetAsync(V.cnt, 0, sizeof(int32_t), s));
     mlaunch_features(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, p.nms_n, p.nms_tau, m->margin, scale,
-                     m->slots, m->flags, V.tab[1], V.cnt + 1);
-    HIP_TRY(hipMemcpyAsync(V.n, V.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                     m->slots, m->flags, m->order, V.tab[1], V.cnt + 1);
+    ftick(4);
+    // feature counts come back through pinned memory after BOTH cameras are enqueued
+    // (a copy into pageable memory would block here until this camera's kernels finish)
+    HIP_TRY(hipMemcpyAsync(m->h_n + 2 * cam, V.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ftick(5);
+    if (g_mtiming)
+        for (int i = 0; i < 5; i++) m->tfine[i] += tf[i + 1] - tf[i];
     V.nbins = 0;   // bin indices are (re)built by matchFeatures for the current bin grid
     V.valid = true;
     return SVH_OK;   // the caller synchronises once after both cameras
@@ -235,7 +261,7 @@ static int ensure_bins(svh_matcher* m, DevView& V, int32_t ub, int32_t vb) {
         m->cursor_cap = nb;
     }
     for (int k = 0; k < 2; k++)
-        mlaunch_bin_index(m->stream, V.tab[k], V.cnt + k, ub, vb, m->p.match_binsize, V.off[k], V.ids[k],
+        mlaunch_bin_index(m->stream, V.tab[k], V.cnt + k, V.n[k], ub, vb, m->p.match_binsize, V.off[k], V.ids[k],
                           m->cursor);
     V.nbins = nb;
     return SVH_OK;
@@ -449,6 +475,16 @@ svh_matcher* svh_matcher_create(const svh_matcher_params* p) {
 
 void svh_matcher_destroy(svh_matcher* m) {
     if (!m) return;
+    if (g_mtiming && m->tcalls[0] && m->tcalls[1]) {
+        const double a = 1.0 / (double)m->tcalls[0], b = 1.0 / (double)m->tcalls[1];
+        fprintf(stderr, "[svh matcher timing] pushBack: pack+enqueue %.3f ms, gpu wait %.3f ms | matchFeatures: "
+                        "sparse %.3f, outliers %.3f, prior %.3f, dense+refine %.3f, outliers %.3f ms\n",
+                m->tacc[T_PACK] * a, m->tacc[T_PUSH_GPU] * a, m->tacc[T_SPARSE] * b, m->tacc[T_OUT1] * b,
+                m->tacc[T_PRIOR] * b, m->tacc[T_DENSE] * b, m->tacc[T_OUT2] * b);
+        fprintf(stderr, "[svh matcher timing] pushBack per frame: pack %.3f, h2d enqueue %.3f, filters enqueue %.3f, "
+                        "features enqueue %.3f, d2h enqueue %.3f ms\n",
+                m->tfine[0] * a, m->tfine[1] * a, m->tfine[2] * a, m->tfine[3] * a, m->tfine[4] * a);
+    }
     if (m->stream) {
         (void)hipSetDevice(m->device);
         (void)hipStreamSynchronize(m->stream);
@@ -456,10 +492,12 @@ void svh_matcher_destroy(svh_matcher* m) {
             m->prev[k].release();
             m->cur[k].release();
         }
-        (void)hipFree(m->slots); (void)hipFree(m->flags); (void)hipFree(m->cursor); (void)hipFree(m->pm_slots);
+        (void)hipFree(m->slots); (void)hipFree(m->flags); (void)hipFree(m->order); (void)hipFree(m->cursor);
+        (void)hipFree(m->pm_slots);
         (void)hipFree(m->pm_out); (void)hipFree(m->pm_flags); (void)hipFree(m->pm_count);
         (void)hipFree(m->pixel_owner); (void)hipFree(m->ranges_dev); (void)hipHostFree(m->h_stage[0]);
         (void)hipHostFree(m->h_stage[1]); (void)hipHostFree(m->h_pm); (void)hipHostFree(m->h_cnt);
+        (void)hipHostFree(m->h_n);
         (void)hipStreamDestroy(m->stream);
     }
     delete m;
@@ -498,6 +536,8 @@ int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* 
     m->dims_c[1] = h;
     m->dims_c[2] = w + 16 - w % 16;   // +16 even when w % 16 == 0 (matcher.cpp:173)
     const uint8_t* src[2] = {I1, I2};
+    if (!m->h_n) HIP_TRY(hipHostMalloc((void**)&m->h_n, 4 * sizeof(int32_t)));
+    const double t0 = g_mtiming ? mnow_ms() : 0;
     for (int k = 0; k < 2; k++) {
         if (!src[k]) continue;
         int rc = ensure_view(m, m->cur[k], w, h, m->dims_c[2]);
@@ -505,8 +545,19 @@ int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* 
         rc = compute_features(m, m->cur[k], k, src[k], pitch);
         if (rc) return rc;
     }
+    const double t1 = g_mtiming ? mnow_ms() : 0;
     HIP_TRY(hipStreamSynchronize(m->stream));
     HIP_TRY(hipGetLastError());
+    for (int k = 0; k < 2; k++)
+        if (src[k]) {
+            m->cur[k].n[0] = m->h_n[2 * k];
+            m->cur[k].n[1] = m->h_n[2 * k + 1];
+        }
+    if (g_mtiming) {
+        m->tacc[T_PACK] += t1 - t0;
+        m->tacc[T_PUSH_GPU] += mnow_ms() - t1;
+        m->tcalls[0]++;
+    }
     return SVH_OK;
 }
 
@@ -545,23 +596,36 @@ int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double*
         m->ranges_cap = ub * vb;
     }
     int rc;
+    double tm[6] = {0, 0, 0, 0, 0, 0};
+    auto tick = [&](int i) { if (g_mtiming) tm[i] = mnow_ms(); };
+    tick(0);
     if (p.multi_stage) {
         rc = run_matching(m, 0, method, false, Tr, m->m1, false, &m->stage[SVH_M_SPARSE_RAW]);
         if (rc) return rc;
+        tick(1);
         rc = remove_outliers(p, m->m1, method);
         if (rc) return rc;
+        tick(2);
         if (m->taps) m->stage[SVH_M_SPARSE] = m->m1;
         prior_statistics(m, m->m1, method, ub, vb);
         HIP_TRY(hipMemcpyAsync(m->ranges_dev, m->ranges.data(), m->ranges.size() * sizeof(float),
                                hipMemcpyHostToDevice, m->stream));
+        tick(3);
         rc = run_matching(m, 1, method, true, Tr, m->m2, p.refinement > 0, &m->stage[SVH_M_DENSE_RAW]);
     } else {
+        tick(1); tick(2); tick(3);
         rc = run_matching(m, 1, method, false, Tr, m->m2, p.refinement > 0, &m->stage[SVH_M_DENSE_RAW]);
     }
     if (rc) return rc;
+    tick(4);
     if (m->taps) m->stage[SVH_M_DENSE_REFINED] = m->m2;
     rc = remove_outliers(p, m->m2, method);
     if (rc) return rc;
+    tick(5);
+    if (g_mtiming) {
+        for (int i = 0; i < 5; i++) m->tacc[T_SPARSE + i] += tm[i + 1] - tm[i];
+        m->tcalls[1]++;
+    }
     if (m->taps) m->stage[SVH_M_DENSE] = m->m2;
     return SVH_OK;
 }

@@ -10,6 +10,7 @@
 //     walked u outer / v inner, strict "<" keeps the first minimum.
 // Each kernel cites the reference lines whose result it reproduces.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include "matcher_internal.h"
 
@@ -102,58 +103,88 @@ __global__ __launch_bounds__(256) void k_filters(const uint8_t* __restrict__ I, 
 
 // ---------------------------------------------------------------------------
 // M4  Matcher::nonMaximumSuppression   matcher.cpp:395-530
-// One thread per (n+1)x(n+1) block.  Slot = (iblock*nj + jblock)*4 + class.
+// kG lanes per (n+1)x(n+1) block (16 for the dense n = 3 pass: one lane per
+// pixel of the block; 64 for wider blocks).  The reference's scan keeps the
+// FIRST smallest / largest value in (i outer, j inner) order; that is the lane
+// minimum of the key  value<<16 | scan_index  (maximum of value<<16 | ~index).
+// The neighbourhood test is an order-free "any pixel beats it" vote.
+// Slot = (iblock*nj + jblock)*4 + class.
 // ---------------------------------------------------------------------------
+template <int kG>
+__device__ __forceinline__ int group_min(int v) {
+#pragma unroll
+    for (int m = kG / 2; m >= 1; m >>= 1) {
+        const int o = __shfl_xor(v, m, kG);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+template <int kG>
+__device__ __forceinline__ int group_max(int v) {
+#pragma unroll
+    for (int m = kG / 2; m >= 1; m >>= 1) {
+        const int o = __shfl_xor(v, m, kG);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+template <int kG>
+__device__ __forceinline__ bool group_any(bool p) {
+    const unsigned long long b = __ballot(p);
+    if (kG == 64) return b != 0;
+    const int sh = (int)(threadIdx.x & 63) / kG * kG;
+    return ((b >> sh) & ((1ull << kG) - 1ull)) != 0;
+}
+
+template <int kG>
 __global__ __launch_bounds__(256) void k_nms(const int16_t* __restrict__ f1,
                                              const int16_t* __restrict__ f2, int w, int h, int bpl,
                                              int n, int tau, int margin, int ni, int nj,
                                              int4* __restrict__ slots, int32_t* __restrict__ flags) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= ni * nj) return;
+    const int b = (int)(blockIdx.x * 256 + threadIdx.x) / kG;
+    const int lane = (int)threadIdx.x % kG;
+    if (b >= ni * nj) return;   // whole groups leave together
     const int ib = b / nj, jb = b - ib * nj;
     const int i = n + margin + ib * (n + 1), j = n + margin + jb * (n + 1);
+    const int n1 = n + 1, np = n1 * n1;
     const int16_t* F[2] = {f1, f2};
-    int mini[2], minj[2], maxi[2], maxj[2], minv[2], maxv[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        mini[k] = maxi[k] = i;
-        minj[k] = maxj[k] = j;
-        minv[k] = maxv[k] = F[k][(size_t)j * bpl + i];
-    }
-    for (int i2 = i; i2 <= i + n; i2++)
-        for (int j2 = j; j2 <= j + n; j2++)
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int c = F[k][(size_t)j2 * bpl + i2];
-                if (c < minv[k]) {
-                    mini[k] = i2; minj[k] = j2; minv[k] = c;
-                } else if (c > maxv[k]) {
-                    maxi[k] = i2; maxj[k] = j2; maxv[k] = c;
-                }
-            }
-#pragma unroll
-    for (int k = 0; k < 2; k++)
+        int kmin = 0x7FFFFFFF, kmax = (int)0x80000000;
+        for (int l = lane; l < np; l += kG) {
+            const int di = l / n1, dj = l - di * n1;
+            const int c = F[k][(size_t)(j + dj) * bpl + i + di];
+            const int lo = c * 65536 + l, hi = c * 65536 + (0xFFFF - l);
+            kmin = lo < kmin ? lo : kmin;
+            kmax = hi > kmax ? hi : kmax;
+        }
+        kmin = group_min<kG>(kmin);
+        kmax = group_max<kG>(kmax);
 #pragma unroll
         for (int mm = 0; mm < 2; mm++) {
             const bool is_min = mm == 0;
-            const int ci = is_min ? mini[k] : maxi[k], cj = is_min ? minj[k] : maxj[k];
-            const int cv = is_min ? minv[k] : maxv[k];
+            const int key = is_min ? kmin : kmax;
+            const int cv = key >> 16;
+            const int l = is_min ? (key & 0xFFFF) : 0xFFFF - (key & 0xFFFF);
+            const int ci = i + l / n1, cj = j + l % n1;
+            const int i0 = ci - n, j0 = cj - n;
             const int ie = min(ci + n, w - 1 - margin), je = min(cj + n, h - 1 - margin);
-            bool ok = true;
-            for (int i2 = ci - n; ok && i2 <= ie; i2++)
-                for (int j2 = cj - n; j2 <= je; j2++) {
-                    const int c = F[k][(size_t)j2 * bpl + i2];
-                    const bool beats = is_min ? c < cv : c > cv;
-                    if (beats && (i2 < i || i2 > i + n || j2 < j || j2 > j + n)) {
-                        ok = false;
-                        break;
-                    }
-                }
-            ok = ok && (is_min ? cv <= -tau : cv >= tau);
-            const int slot = b * 4 + 2 * k + mm;
-            flags[slot] = ok ? 1 : 0;
-            if (ok) slots[slot] = make_int4(ci, cj, cv, 2 * k + mm);
+            const int nwj = je - j0 + 1, total = (ie - i0 + 1) * nwj;
+            bool bad = false;
+            for (int q = lane; q < total; q += kG) {
+                const int di = q / nwj, i2 = i0 + di, j2 = j0 + (q - di * nwj);
+                const int c = F[k][(size_t)j2 * bpl + i2];
+                const bool beats = is_min ? c < cv : c > cv;
+                bad = bad || (beats && (i2 < i || i2 > i + n || j2 < j || j2 > j + n));
+            }
+            const bool ok = !group_any<kG>(bad) && (is_min ? cv <= -tau : cv >= tau);
+            if (lane == 0) {
+                const int slot = b * 4 + 2 * k + mm;
+                flags[slot] = ok ? 1 : 0;
+                if (ok) slots[slot] = make_int4(ci, cj, cv, 2 * k + mm);
+            }
         }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -175,42 +206,52 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int value, int* total) 
     return s_scan[t] - value;
 }
 
-// M5  descriptor + record packing   matcher.cpp:534-579, 854-877
-__global__ __launch_bounds__(1024) void k_compact_features(const int4* __restrict__ slots,
-                                                           const int32_t* __restrict__ flags,
-                                                           int nslots, const uint8_t* __restrict__ du,
-                                                           const uint8_t* __restrict__ dv, int bpl,
-                                                           int scale, int32_t* __restrict__ table,
-                                                           int32_t* __restrict__ count) {
+// ordered compaction of the surviving slots: order[k] = slot of the k-th feature
+__global__ __launch_bounds__(1024) void k_compact_slots(const int32_t* __restrict__ flags, int nslots,
+                                                        int32_t* __restrict__ order,
+                                                        int32_t* __restrict__ count) {
     const int t = threadIdx.x;
-    const int chunk = (nslots + 1023) / 1024;
-    const int lo = t * chunk, hi = min(lo + chunk, nslots);
+    const int chunk = ((nslots + 1023) / 1024 + 3) & ~3;   // multiple of 4: 16-byte flag loads
+    const int lo = min(t * chunk, nslots), hi = min(lo + chunk, nslots);
     int mine = 0;
-    for (int s = lo; s < hi; s++) mine += flags[s];
-    int total;
-    int base = block_exclusive_scan_1024(mine, &total);
-    for (int s = lo; s < hi; s++) {
-        if (!flags[s]) continue;
-        const int4 m = slots[s];
-        int32_t* rec = table + (size_t)12 * base++;
-        rec[0] = m.x * scale;
-        rec[1] = m.y * scale;
-        rec[2] = 0;
-        rec[3] = m.w;
-        // 16 (du,dv) pairs around (u, v-1): rows -5,-3,-1,+1,+3,+5 relative to v
-        const ptrdiff_t m1 = (ptrdiff_t)(m.y - 1) * bpl + m.x;
-        const ptrdiff_t m3 = m1 - 2 * bpl, m5 = m3 - 2 * bpl, p1 = m1 + 2 * bpl, p3 = p1 + 2 * bpl,
-                        p5 = p3 + 2 * bpl;
-        const ptrdiff_t at[16] = {m1 - 3, p1 - 3, m1 - 1, p1 - 1, m1 + 3, p1 + 3, m1 + 1, p1 + 1,
-                                  m5 - 1, p5 - 1, m5 + 1, p5 + 1, m3 - 5, p3 - 5, m3 + 5, p3 + 5};
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const uint32_t b0 = du[at[2 * q]], b1 = dv[at[2 * q]];
-            const uint32_t b2 = du[at[2 * q + 1]], b3 = dv[at[2 * q + 1]];
-            rec[4 + q] = (int32_t)(b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+    for (int s = lo; s < hi; s += 4) {
+        if (s + 4 <= hi) {
+            const int4 f = *reinterpret_cast<const int4*>(flags + s);
+            mine += f.x + f.y + f.z + f.w;
+        } else {
+            for (int r = s; r < hi; r++) mine += flags[r];
         }
     }
+    int total;
+    int base = block_exclusive_scan_1024(mine, &total);
+    if (mine)
+        for (int s = lo; s < hi; s++)
+            if (flags[s]) order[base++] = s;
     if (t == 0) *count = total;
+}
+
+// M5  descriptor + record packing   matcher.cpp:534-579, 854-877
+// one thread per (feature, descriptor word): 16 (du,dv) pairs around (u, v-1),
+// rows -5,-3,-1,+1,+3,+5 relative to v
+__global__ __launch_bounds__(256) void k_feature_records(const int4* __restrict__ slots,
+                                                         const int32_t* __restrict__ order,
+                                                         const int32_t* __restrict__ count,
+                                                         const uint8_t* __restrict__ du,
+                                                         const uint8_t* __restrict__ dv, int bpl,
+                                                         int scale, int32_t* __restrict__ table) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int feat = g >> 3, q = g & 7;
+    if (feat >= *count) return;
+    const int4 m = slots[order[feat]];
+    int32_t* rec = table + (size_t)12 * feat;
+    if (q < 4) rec[q] = q == 0 ? m.x * scale : q == 1 ? m.y * scale : q == 2 ? 0 : m.w;
+    // word q packs (du,dv) at (row -r, dx) and (row +r, dx), rows relative to v
+    const int dx[8] = {-3, -1, 3, 1, -1, 1, -5, 5};
+    const int rr[8] = {1, 1, 1, 1, 5, 5, 3, 3};
+    const ptrdiff_t base = (ptrdiff_t)m.y * bpl + m.x + dx[q];
+    const ptrdiff_t a0 = base - (ptrdiff_t)rr[q] * bpl, b0 = base + (ptrdiff_t)rr[q] * bpl;
+    const uint32_t w0 = du[a0], w1 = dv[a0], w2 = du[b0], w3 = dv[b0];
+    rec[4 + q] = (int32_t)(w0 | (w1 << 8) | (w2 << 16) | (w3 << 24));
 }
 
 // ---------------------------------------------------------------------------
@@ -218,6 +259,66 @@ __global__ __launch_bounds__(1024) void k_compact_features(const int4* __restric
 // CSR over class x v_bin x u_bin; every list ends up in ascending feature index
 // (the reference's push_back order).  One workgroup per table.
 // ---------------------------------------------------------------------------
+// LDS build: histogram, scan, scatter and the per-bin ascending sort all stay on chip;
+// used when 2*nb + 1 + n ints fit the LDS budget (launcher), else k_bin_index below.
+__global__ __launch_bounds__(1024) void k_bin_index_lds(const int32_t* __restrict__ table,
+                                                        const int32_t* __restrict__ count, int ub,
+                                                        int vb, int binsize, int32_t* __restrict__ off,
+                                                        int32_t* __restrict__ ids) {
+    extern __shared__ int s_bin[];
+    const int n = *count, nb = 4 * ub * vb, t = threadIdx.x;
+    int* s_off = s_bin;            // nb + 1
+    int* s_cur = s_bin + nb + 1;   // nb
+    int* s_ids = s_cur + nb;       // n
+    for (int b = t; b <= nb; b += 1024) s_off[b] = 0;
+    for (int b = t; b < nb; b += 1024) s_cur[b] = 0;
+    __syncthreads();
+    auto bin_of = [&](int i) {
+        const int32_t* r = table + (size_t)12 * i;
+        int u_bin = (int)floorf(__fdiv_rn((float)r[0], (float)binsize));
+        int v_bin = (int)floorf(__fdiv_rn((float)r[1], (float)binsize));
+        u_bin = u_bin < ub - 1 ? u_bin : ub - 1;
+        v_bin = v_bin < vb - 1 ? v_bin : vb - 1;
+        return (r[3] * vb + v_bin) * ub + u_bin;
+    };
+    for (int i = t; i < n; i += 1024) atomicAdd(&s_off[bin_of(i) + 1], 1);
+    __syncthreads();
+    // inclusive scan of s_off[1..nb]: thread t owns a contiguous chunk
+    {
+        const int chunk = (nb + 1023) / 1024;
+        const int lo = min(1 + t * chunk, nb + 1), hi = min(lo + chunk, nb + 1);
+        int mine = 0;
+        for (int b = lo; b < hi; b++) mine += s_off[b];
+        int total;
+        int run = block_exclusive_scan_1024(mine, &total);
+        for (int b = lo; b < hi; b++) {
+            run += s_off[b];
+            s_off[b] = run;
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {
+        const int b = bin_of(i);
+        s_ids[s_off[b] + atomicAdd(&s_cur[b], 1)] = i;
+    }
+    __syncthreads();
+    for (int b = t; b < nb; b += 1024) {   // short lists: insertion sort to ascending index
+        const int lo = s_off[b], hi = s_off[b + 1];
+        for (int a = lo + 1; a < hi; a++) {
+            const int key = s_ids[a];
+            int q = a - 1;
+            while (q >= lo && s_ids[q] > key) {
+                s_ids[q + 1] = s_ids[q];
+                q--;
+            }
+            s_ids[q + 1] = key;
+        }
+    }
+    __syncthreads();
+    for (int b = t; b <= nb; b += 1024) off[b] = s_off[b];
+    for (int i = t; i < n; i += 1024) ids[i] = s_ids[i];
+}
+
 __global__ __launch_bounds__(1024) void k_bin_index(const int32_t* __restrict__ table,
                                                     const int32_t* __restrict__ count, int ub, int vb,
                                                     int binsize, int32_t* __restrict__ off,
@@ -272,10 +373,16 @@ __device__ __forceinline__ uint32_t sad32(const int32_t* a, const int32_t* b) {
     return s;
 }
 
+// kQ lanes work on one query: bins are walked in the reference's order by the whole
+// group, the lanes stride over a bin's list.  Every lane keeps its first minimum
+// (strict "<" on its ascending subsequence); the group winner is the smallest
+// (cost, traversal position) pair, i.e. the first minimum of the sequential walk.
+constexpr int kQ = 16;
+
 __device__ int find_match(const MatchParams& P, const FeatView& t1, int i1, const FeatView& t2,
                           const float* __restrict__ ranges, int stat_bin, int stage, bool flow,
-                          bool use_prior, double u_, double v_) {
-    int min_ind = 0;
+                          bool use_prior, double u_, double v_, int lane) {
+    int min_ind = 0, min_seq = 0x7FFFFFFF;
     double min_cost = 10000000;
     const int32_t* r1 = t1.rec + (size_t)12 * i1;
     const int u1 = r1[0], v1 = r1[1], c = r1[3];
@@ -308,11 +415,12 @@ __device__ int find_match(const MatchParams& P, const FeatView& t1, int i1, cons
     const int ub0 = bin(u_min, P.ub), ub1 = bin(u_max, P.ub);
     const int vb0 = bin(v_min, P.vb), vb1 = bin(v_max, P.vb);
     const bool predicted = u_ >= 0 && v_ >= 0;
+    int seq0 = 0;   // traversal position of the current bin's first entry
     for (int u_bin = ub0; u_bin <= ub1; u_bin++)
         for (int v_bin = vb0; v_bin <= vb1; v_bin++) {
             const int b = (c * P.vb + v_bin) * P.ub + u_bin;
             const int lo = t2.off[b], hi = t2.off[b + 1];
-            for (int q = lo; q < hi; q++) {
+            for (int q = lo + lane; q < hi; q += kQ) {
                 const int i2 = t2.ids[q];
                 const int32_t* r2 = t2.rec + (size_t)12 * i2;
                 const float u2 = (float)r2[0], v2 = (float)r2[1];
@@ -326,10 +434,24 @@ __device__ int find_match(const MatchParams& P, const FeatView& t1, int i1, cons
                     if (cost < min_cost) {
                         min_ind = i2;
                         min_cost = cost;
+                        min_seq = seq0 + (q - lo);
                     }
                 }
             }
+            seq0 += hi - lo;
         }
+    // group winner: smallest cost, ties to the earlier traversal position
+#pragma unroll
+    for (int m = kQ / 2; m >= 1; m >>= 1) {
+        const double oc = __shfl_xor(min_cost, m, kQ);
+        const int os = __shfl_xor(min_seq, m, kQ);
+        const int oi = __shfl_xor(min_ind, m, kQ);
+        if (oc < min_cost || (oc == min_cost && os < min_seq)) {
+            min_cost = oc;
+            min_seq = os;
+            min_ind = oi;
+        }
+    }
     return min_ind;
 }
 
@@ -357,25 +479,26 @@ __global__ __launch_bounds__(128) void k_match(MatchParams P, FeatView m1p, Feat
                                                int use_prior, svh_p_match* __restrict__ out,
                                                int32_t* __restrict__ flags,
                                                int32_t* __restrict__ pixel_owner) {
-    const int i = blockIdx.x * 128 + threadIdx.x;
+    const int i = (int)(blockIdx.x * 128 + threadIdx.x) / kQ;
+    const int lane = (int)threadIdx.x % kQ;
     const FeatView& q = P.method == 2 ? m1p : m1c;
-    if (i >= *q.count) return;
+    if (i >= *q.count) return;   // whole groups leave together
     int ok = 0;
     svh_p_match m = mk(-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
     const int32_t* r = q.rec + (size_t)12 * i;
     const int uq = r[0], vq = r[1];
     const int sb = stat_bin_of(P, uq, vq);
     if (P.method == 0) {
-        const int i1p = find_match(P, m1c, i, m1p, ranges, sb, 0, true, use_prior, -1, -1);
-        const int i1c2 = find_match(P, m1p, i1p, m1c, ranges, sb, 1, true, use_prior, -1, -1);
+        const int i1p = find_match(P, m1c, i, m1p, ranges, sb, 0, true, use_prior, -1, -1, lane);
+        const int i1c2 = find_match(P, m1p, i1p, m1c, ranges, sb, 1, true, use_prior, -1, -1, lane);
         if (i1c2 == i) {
             const int32_t* rp = m1p.rec + (size_t)12 * i1p;
             m = mk((float)rp[0], (float)rp[1], i1p, -1, -1, -1, (float)uq, (float)vq, i, -1, -1, -1);
             ok = 1;
         }
     } else if (P.method == 1) {
-        const int i2c = find_match(P, m1c, i, m2c, ranges, sb, 0, false, use_prior, -1, -1);
-        const int i1c2 = find_match(P, m2c, i2c, m1c, ranges, sb, 1, false, use_prior, -1, -1);
+        const int i2c = find_match(P, m1c, i, m2c, ranges, sb, 0, false, use_prior, -1, -1, lane);
+        const int i1c2 = find_match(P, m2c, i2c, m1c, ranges, sb, 1, false, use_prior, -1, -1, lane);
         if (i1c2 == i) {
             const int32_t* r2 = m2c.rec + (size_t)12 * i2c;
             if (uq >= r2[0]) {
@@ -384,7 +507,7 @@ __global__ __launch_bounds__(128) void k_match(MatchParams P, FeatView m1p, Feat
             }
         }
     } else {
-        const int i2p = find_match(P, m1p, i, m2p, ranges, sb, 0, false, use_prior, -1, -1);
+        const int i2p = find_match(P, m1p, i, m2p, ranges, sb, 0, false, use_prior, -1, -1, lane);
         const int32_t* r2p = m2p.rec + (size_t)12 * i2p;
         const int u2p = r2p[0], v2p = r2p[1];
         double pu = -1, pv = -1, bu = -1, bv = -1;
@@ -407,9 +530,9 @@ __global__ __launch_bounds__(128) void k_match(MatchParams P, FeatView m1p, Feat
             bu = (double)uq;
             bv = (double)vq;
         }
-        const int i2c = find_match(P, m2p, i2p, m2c, ranges, sb, 1, true, use_prior, pu, pv);
-        const int i1c = find_match(P, m2c, i2c, m1c, ranges, sb, 2, false, use_prior, -1, -1);
-        const int i1p2 = find_match(P, m1c, i1c, m1p, ranges, sb, 3, true, use_prior, bu, bv);
+        const int i2c = find_match(P, m2p, i2p, m2c, ranges, sb, 1, true, use_prior, pu, pv, lane);
+        const int i1c = find_match(P, m2c, i2c, m1c, ranges, sb, 2, false, use_prior, -1, -1, lane);
+        const int i1p2 = find_match(P, m1c, i1c, m1p, ranges, sb, 3, true, use_prior, bu, bv, lane);
         if (i1p2 == i) {
             const int32_t* r2c = m2c.rec + (size_t)12 * i2c;
             const int32_t* r1c = m1c.rec + (size_t)12 * i1c;
@@ -420,6 +543,7 @@ __global__ __launch_bounds__(128) void k_match(MatchParams P, FeatView m1p, Feat
             }
         }
     }
+    if (lane != 0) return;
     if (ok && P.method < 2) atomicMin(&pixel_owner[(size_t)vq * P.width + uq], i);
     flags[i] = ok;
     if (ok) out[i] = m;
@@ -633,21 +757,34 @@ int mnms_blocks(int extent, int n, int margin) {
 
 void mlaunch_features(void* stream, const int16_t* f1, const int16_t* f2, const uint8_t* du,
                       const uint8_t* dv, int w, int h, int bpl, int n, int tau, int margin, int scale,
-                      int4* slots, int32_t* flags, int32_t* table, int32_t* count) {
+                      int4* slots, int32_t* flags, int32_t* order, int32_t* table, int32_t* count) {
     hipStream_t s = (hipStream_t)stream;
     const int ni = mnms_blocks(w, n, margin), nj = mnms_blocks(h, n, margin);
     const int nb = ni * nj;
+    if (nb > 0) {
+        if ((n + 1) * (n + 1) <= 16)
+            hipLaunchKernelGGL(k_nms<16>, dim3((nb + 15) / 16), dim3(256), 0, s, f1, f2, w, h, bpl, n, tau,
+                               margin, ni, nj, slots, flags);
+        else
+            hipLaunchKernelGGL(k_nms<64>, dim3((nb + 3) / 4), dim3(256), 0, s, f1, f2, w, h, bpl, n, tau,
+                               margin, ni, nj, slots, flags);
+    }
+    hipLaunchKernelGGL(k_compact_slots, dim3(1), dim3(1024), 0, s, flags, nb * 4, order, count);
     if (nb > 0)
-        hipLaunchKernelGGL(k_nms, dim3((nb + 255) / 256), dim3(256), 0, s, f1, f2, w, h, bpl, n, tau, margin,
-                           ni, nj, slots, flags);
-    hipLaunchKernelGGL(k_compact_features, dim3(1), dim3(1024), 0, s, slots, flags, nb * 4, du, dv, bpl, scale,
-                       table, count);
+        hipLaunchKernelGGL(k_feature_records, dim3((nb * 4 * 8 + 255) / 256), dim3(256), 0, s, slots, order,
+                           count, du, dv, bpl, scale, table);
 }
 
-void mlaunch_bin_index(void* stream, const int32_t* table, const int32_t* count, int ub, int vb,
-                       int binsize, int32_t* off, int32_t* ids, int32_t* cursor) {
-    hipLaunchKernelGGL(k_bin_index, dim3(1), dim3(1024), 0, (hipStream_t)stream, table, count, ub, vb, binsize,
-                       off, ids, cursor);
+void mlaunch_bin_index(void* stream, const int32_t* table, const int32_t* count, int n_host, int ub,
+                       int vb, int binsize, int32_t* off, int32_t* ids, int32_t* cursor) {
+    const int nb = 4 * ub * vb;
+    const size_t lds = ((size_t)2 * nb + 1 + (size_t)std::max(n_host, 0)) * sizeof(int32_t);
+    if (lds <= 56 * 1024)
+        hipLaunchKernelGGL(k_bin_index_lds, dim3(1), dim3(1024), lds, (hipStream_t)stream, table, count, ub, vb,
+                           binsize, off, ids);
+    else
+        hipLaunchKernelGGL(k_bin_index, dim3(1), dim3(1024), 0, (hipStream_t)stream, table, count, ub, vb,
+                           binsize, off, ids, cursor);
 }
 
 void mlaunch_match(void* stream, const MatchParams& P, const FeatView& m1p, const FeatView& m2p,
@@ -659,8 +796,8 @@ void mlaunch_match(void* stream, const MatchParams& P, const FeatView& m1p, cons
     if (P.method < 2)
         (void)hipMemsetAsync(pixel_owner, 0x7F, (size_t)P.width * P.height * sizeof(int32_t), s);
     if (nquery_cap > 0) {
-        hipLaunchKernelGGL(k_match, dim3((nquery_cap + 127) / 128), dim3(128), 0, s, P, m1p, m2p, m1c, m2c,
-                           ranges, use_prior, slots, flags, pixel_owner);
+        hipLaunchKernelGGL(k_match, dim3((nquery_cap * kQ + 127) / 128), dim3(128), 0, s, P, m1p, m2p, m1c,
+                           m2c, ranges, use_prior, slots, flags, pixel_owner);
         if (P.method < 2)
             hipLaunchKernelGGL(k_match_dedupe, dim3((nquery_cap + 255) / 256), dim3(256), 0, s, q.count,
                                P.width, slots, flags, pixel_owner);
