@@ -40,6 +40,10 @@
 
 #include "../../include/svh.h"
 
+#ifndef TICK
+#define TICK(i)
+#endif
+
 namespace svh {
 
 namespace {
@@ -63,39 +67,42 @@ private:
     int32_t n_;
     uint64_t seed_;
     std::vector<int64_t> ix_, iy_;   // exact scaled integer coordinates
-    std::vector<int32_t> nb_;        // 3 neighbour handles per record, encoded t*4+o
-    std::vector<int32_t> vx_;        // 3 vertex ids per record, -1 = the ghost apex
-    std::vector<uint8_t> dead_;
+    // one 32-byte record per triangle: vertices [0..2] (-1 = the ghost apex), neighbour
+    // handles [3..5] encoded t*4+o, dead flag [6]
+    std::vector<int32_t> rec_;
+    int32_t nrec_ = 0;
 
     float X(int32_t v) const { return pts_[2 * v]; }
     float Y(int32_t v) const { return pts_[2 * v + 1]; }
     float C(int32_t v, int axis) const { return pts_[2 * v + axis]; }
 
     // ---- handle algebra -------------------------------------------------
-    static Handle next(Handle h) { h.o = (h.o + 1) % 3; return h; }
-    static Handle prev(Handle h) { h.o = (h.o + 2) % 3; return h; }
+    static int p1(int o) { return (0x09 >> (2 * o)) & 3; }   // (o + 1) % 3: 0->1, 1->2, 2->0
+    static int p2(int o) { return (0x12 >> (2 * o)) & 3; }   // (o + 2) % 3: 0->2, 1->0, 2->1
+    static Handle next(Handle h) { h.o = p1(h.o); return h; }
+    static Handle prev(Handle h) { h.o = p2(h.o); return h; }
     Handle sym(Handle h) const {
-        int32_t e = nb_[3 * h.t + h.o];
+        int32_t e = rec_[8 * h.t + 3 + h.o];
         Handle r = {e >> 2, e & 3};
         return r;
     }
-    int32_t org(Handle h) const { return vx_[3 * h.t + (h.o + 1) % 3]; }
-    int32_t dest(Handle h) const { return vx_[3 * h.t + (h.o + 2) % 3]; }
-    int32_t apex(Handle h) const { return vx_[3 * h.t + h.o]; }
-    void set_org(Handle h, int32_t v) { vx_[3 * h.t + (h.o + 1) % 3] = v; }
-    void set_dest(Handle h, int32_t v) { vx_[3 * h.t + (h.o + 2) % 3] = v; }
-    void set_apex(Handle h, int32_t v) { vx_[3 * h.t + h.o] = v; }
+    int32_t org(Handle h) const { return rec_[8 * h.t + p1(h.o)]; }
+    int32_t dest(Handle h) const { return rec_[8 * h.t + p2(h.o)]; }
+    int32_t apex(Handle h) const { return rec_[8 * h.t + h.o]; }
+    void set_org(Handle h, int32_t v) { rec_[8 * h.t + p1(h.o)] = v; }
+    void set_dest(Handle h, int32_t v) { rec_[8 * h.t + p2(h.o)] = v; }
+    void set_apex(Handle h, int32_t v) { rec_[8 * h.t + h.o] = v; }
     void bond(Handle a, Handle b) {
-        nb_[3 * a.t + a.o] = b.t * 4 + b.o;
-        nb_[3 * b.t + b.o] = a.t * 4 + a.o;
+        rec_[8 * a.t + 3 + a.o] = b.t * 4 + b.o;
+        rec_[8 * b.t + 3 + b.o] = a.t * 4 + a.o;
     }
     Handle make() {
-        Handle h = {(int32_t)(vx_.size() / 3), 0};
-        for (int k = 0; k < 3; k++) {
-            nb_.push_back(0);  // outer space, orientation 0
-            vx_.push_back(-1);
-        }
-        dead_.push_back(0);
+        if ((size_t)8 * (nrec_ + 1) > rec_.size()) rec_.resize(rec_.size() * 2 + 64);
+        int32_t* r = &rec_[8 * (size_t)nrec_];
+        r[0] = r[1] = r[2] = -1;
+        r[3] = r[4] = r[5] = 0;   // outer space, orientation 0
+        r[6] = r[7] = 0;
+        Handle h = {nrec_++, 0};
         return h;
     }
 
@@ -187,6 +194,50 @@ private:
         }
     }
 
+    // ---- packed keys ---------------------------------------------------------
+    // When every scaled coordinate fits 15 bits (after an offset) a point is one
+    // uint64: (major << 15 | minor) << 24 | index.  Sorting then needs no float
+    // look-ups; comparisons of the reference's quicksort use the 30 key bits only.
+    static constexpr int kIdxBits = 24;
+    uint64_t pack(int32_t v, int axis) const {
+        const uint64_t a = (uint64_t)((axis == 0 ? ix_[v] : iy_[v]) + (1 << 14));
+        const uint64_t b = (uint64_t)((axis == 0 ? iy_[v] : ix_[v]) + (1 << 14));
+        return ((a << 15 | b) << kIdxBits) | (uint64_t)v;
+    }
+    // LSD radix sort on the 30 key bits (three 10-bit digits); stable
+    void radix30(std::vector<uint64_t>& a, std::vector<uint64_t>& tmp) {
+        const size_t n = a.size();
+        tmp.resize(n);
+        uint64_t* src = a.data();
+        uint64_t* dst = tmp.data();
+        for (int pass = 0; pass < 3; pass++) {
+            const int sh = kIdxBits + 10 * pass;
+            uint32_t cnt[1025];
+            memset(cnt, 0, sizeof(cnt));
+            for (size_t i = 0; i < n; i++) cnt[((src[i] >> sh) & 1023) + 1]++;
+            for (int d = 0; d < 1024; d++) cnt[d + 1] += cnt[d];
+            for (size_t i = 0; i < n; i++) dst[cnt[(src[i] >> sh) & 1023]++] = src[i];
+            std::swap(src, dst);
+        }
+        if (src != a.data()) memcpy(a.data(), src, n * sizeof(uint64_t));
+    }
+    // the reference's quicksort (vertexsort, triangle.cpp:5418-5476) on packed keys
+    void sort_xy_packed(uint64_t* a, int32_t n) {
+        if (n == 2) {
+            if ((a[0] >> kIdxBits) > (a[1] >> kIdxBits)) std::swap(a[0], a[1]);
+            return;
+        }
+        const uint64_t pv = a[pick((uint32_t)n)] >> kIdxBits;
+        int32_t l = -1, r = n;
+        while (l < r) {
+            do { l++; } while (l <= r && (a[l] >> kIdxBits) < pv);
+            do { r--; } while (l <= r && (a[r] >> kIdxBits) > pv);
+            if (l < r) std::swap(a[l], a[r]);
+        }
+        if (l > 1) sort_xy_packed(a, l);
+        if (r < n - 2) sort_xy_packed(a + r + 1, n - r - 1);
+    }
+
     // The alternating-cut order is a pure function of a set of DISTINCT points (every
     // cut takes the n/2 smallest by the lexicographic key of its axis, leaves of <= 3
     // points are x-sorted), so it can be produced without the pivot stream: a
@@ -225,11 +276,13 @@ private:
 bool DivConq::scale_coordinates() {
     int min_exp = 0;  // most negative exponent of a set low bit
     float maxabs = 0.f;
+    bool integral = true;
     for (int32_t i = 0; i < 2 * n_; i++) {
         float f = pts_[i];
         if (!(f == f) || std::fabs(f) > 1e9f) return false;
         maxabs = std::fabs(f) > maxabs ? std::fabs(f) : maxabs;
-        if (f != 0.f && f != std::floor(f)) {
+        if (f != (float)(int32_t)f) {
+            integral = false;
             int e;
             float m = std::frexp(f, &e);  // f = m * 2^e, 0.5 <= |m| < 1
             int32_t mi = (int32_t)std::ldexp(m, 24);
@@ -245,10 +298,18 @@ bool DivConq::scale_coordinates() {
     ix_.resize(n_);
     iy_.resize(n_);
     int64_t big = 0;
-    for (int32_t i = 0; i < n_; i++) {
-        ix_[i] = (int64_t)std::ldexp((double)pts_[2 * i], -min_exp);
-        iy_[i] = (int64_t)std::ldexp((double)pts_[2 * i + 1], -min_exp);
-        big = std::max(big, std::max(ix_[i] < 0 ? -ix_[i] : ix_[i], iy_[i] < 0 ? -iy_[i] : iy_[i]));
+    if (integral) {   // the usual case (pixel coordinates): no scaling at all
+        for (int32_t i = 0; i < n_; i++) {
+            ix_[i] = (int64_t)pts_[2 * i];
+            iy_[i] = (int64_t)pts_[2 * i + 1];
+        }
+        big = (int64_t)maxabs;
+    } else {
+        for (int32_t i = 0; i < n_; i++) {
+            ix_[i] = (int64_t)std::ldexp((double)pts_[2 * i], -min_exp);
+            iy_[i] = (int64_t)std::ldexp((double)pts_[2 * i + 1], -min_exp);
+            big = std::max(big, std::max(ix_[i] < 0 ? -ix_[i] : ix_[i], iy_[i] < 0 ? -iy_[i] : iy_[i]));
+        }
     }
     narrow_ = big < (1 << 14);
     return true;
@@ -506,23 +567,40 @@ void DivConq::merge(Handle* farleft, Handle* innerleft, Handle* innerright, Hand
 
 int32_t DivConq::run(int32_t* out, int32_t cap) {
     if (n_ < 2) return 0;
+    TICK(0)
     if (!scale_coordinates()) return SVH_ERR_UNSUPPORTED;
     // x-sort.  For distinct points the sorted order is unique, so a plain sort is
     // used; only when coincident points exist does the survivor depend on the
     // reference's pivot stream, and the mirrored quicksort is run instead.
     std::vector<int32_t> order(n_);
-    for (int32_t i = 0; i < n_; i++) order[i] = i;
-    auto less_xy = [&](int32_t a, int32_t b) {
-        return X(a) < X(b) || (X(a) == X(b) && Y(a) < Y(b));
-    };
-    std::sort(order.begin(), order.end(), less_xy);
+    const bool packed = narrow_ && n_ < (1 << kIdxBits);
+    std::vector<uint64_t> keys, ktmp;
     bool dup = false;
-    for (int32_t j = 1; j < n_ && !dup; j++)
-        dup = X(order[j - 1]) == X(order[j]) && Y(order[j - 1]) == Y(order[j]);
+    if (packed) {
+        keys.resize(n_);
+        for (int32_t i = 0; i < n_; i++) keys[i] = pack(i, 0);
+        radix30(keys, ktmp);
+        for (int32_t j = 1; j < n_ && !dup; j++) dup = (keys[j - 1] >> kIdxBits) == (keys[j] >> kIdxBits);
+        if (dup) {
+            for (int32_t i = 0; i < n_; i++) keys[i] = pack(i, 0);
+            sort_xy_packed(keys.data(), n_);
+        }
+        for (int32_t i = 0; i < n_; i++) order[i] = (int32_t)(keys[i] & ((1u << kIdxBits) - 1));
+    } else {
+        for (int32_t i = 0; i < n_; i++) order[i] = i;
+        auto less_xy = [&](int32_t a, int32_t b) {
+            return X(a) < X(b) || (X(a) == X(b) && Y(a) < Y(b));
+        };
+        std::sort(order.begin(), order.end(), less_xy);
+        for (int32_t j = 1; j < n_ && !dup; j++)
+            dup = X(order[j - 1]) == X(order[j]) && Y(order[j - 1]) == Y(order[j]);
+        if (dup) {
+            for (int32_t i = 0; i < n_; i++) order[i] = i;
+            sort_xy(order.data(), n_);
+        }
+    }
     int32_t m = n_;
     if (dup) {
-        for (int32_t i = 0; i < n_; i++) order[i] = i;
-        sort_xy(order.data(), n_);
         // drop coincident vertices: the first in sorted order survives
         m = 0;
         for (int32_t j = 1; j < n_; j++) {
@@ -532,13 +610,21 @@ int32_t DivConq::run(int32_t* out, int32_t cap) {
         m++;
     }
     if (m < 2) return 0;
+    TICK(1)
     {
         // alternating-cut order (triangle.cpp:5582-5604, 6198-6206): top cut by x at m/2,
         // then each half starts with a y cut
         std::vector<int32_t> ly(order.begin(), order.begin() + m), kd(m);
-        std::sort(ly.begin(), ly.end(), [&](int32_t a, int32_t b) {
-            return Y(a) < Y(b) || (Y(a) == Y(b) && X(a) < X(b));
-        });
+        if (packed) {
+            keys.resize(m);
+            for (int32_t i = 0; i < m; i++) keys[i] = pack(order[i], 1);
+            radix30(keys, ktmp);
+            for (int32_t i = 0; i < m; i++) ly[i] = (int32_t)(keys[i] & ((1u << kIdxBits) - 1));
+        } else {
+            std::sort(ly.begin(), ly.end(), [&](int32_t a, int32_t b) {
+                return Y(a) < Y(b) || (Y(a) == Y(b) && X(a) < X(b));
+            });
+        }
         mark_.assign(n_, 0);
         tmp_.resize(m);
         const int32_t half = m >> 1;
@@ -559,33 +645,38 @@ int32_t DivConq::run(int32_t* out, int32_t cap) {
             memcpy(order.data(), kd.data(), sizeof(int32_t) * m);
         }
     }
-    nb_.reserve(3 * (2 * (size_t)m + 8));
-    vx_.reserve(3 * (2 * (size_t)m + 8));
+    TICK(2)
+    rec_.assign(8 * (2 * (size_t)m + 16), 0);
+    nrec_ = 0;
     make();  // record 0 = outer space
     Handle hullleft, hullright;
     recurse(order.data(), m, 0, &hullleft, &hullright);
 
     // peel the ghost fan off the hull
+    TICK(3)
     Handle g = hullleft;
     do {
         Handle dying = next(g);
         g = sym(prev(g));
-        nb_[3 * g.t + g.o] = 0;  // hull triangle now faces outer space
+        rec_[8 * g.t + 3 + g.o] = 0;  // hull triangle now faces outer space
         g = sym(dying);
-        dead_[dying.t] = 1;
+        rec_[8 * dying.t + 6] = 1;
     } while (!(g.t == hullleft.t && g.o == hullleft.o));
 
+    TICK(4)
     int32_t count = 0;
-    const int32_t nrec = (int32_t)(vx_.size() / 3);
+    const int32_t nrec = nrec_;
     for (int32_t t = 1; t < nrec; t++) {
-        if (dead_[t]) continue;
+        const int32_t* r = &rec_[8 * (size_t)t];
+        if (r[6]) continue;
         if (count < cap) {
-            out[3 * count + 0] = vx_[3 * t + 1];
-            out[3 * count + 1] = vx_[3 * t + 2];
-            out[3 * count + 2] = vx_[3 * t + 0];
+            out[3 * count + 0] = r[1];
+            out[3 * count + 1] = r[2];
+            out[3 * count + 2] = r[0];
         }
         count++;
     }
+    TICK(5)
     return count;
 }
 

@@ -51,9 +51,9 @@ def test_delaunay_matches_golden_triangle_lists(case, S):
 @pytest.mark.skipif(not H.have_ref_elas(), reason="needs the real Triangle in oracle/_ref")
 def test_delaunay_matches_triangle_fuzz(S):
     rng = np.random.default_rng(5)
-    for trial in range(120):
-        n = int(rng.integers(3, 300))
-        kind = trial % 5
+    for trial in range(140):
+        n = int(rng.integers(3, 300)) if trial < 120 else int(rng.integers(1500, 3200))
+        kind = trial % 7
         if kind == 0:      # 5-px lattice: many co-circular ties
             pts = np.unique(rng.integers(1, 50, (n, 2)) * 5, axis=0)
             rng.shuffle(pts)
@@ -64,8 +64,12 @@ def test_delaunay_matches_triangle_fuzz(S):
         elif kind == 3:    # collinear runs
             x = rng.integers(0, 100, n)
             pts = np.stack([x, x * 0 + 7], 1)
-        else:              # half-pixel coordinates
+        elif kind == 4:    # half-pixel coordinates
             pts = rng.integers(0, 2000, (n, 2)) / 2.0
+        elif kind == 5:    # large / negative coordinates with duplicates: the 128-bit predicate path
+            pts = rng.integers(-300, 300, (n, 2)) * 64.0 + 0.25
+        else:              # a dense small lattice: most points are duplicates
+            pts = rng.integers(0, 40, (n, 2)) * 2
         pts = pts.astype(np.float32)
         if len(np.unique(pts, axis=0)) < 3:
             continue
