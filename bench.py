@@ -303,7 +303,7 @@ def main():
                 import glob
                 pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))
                 kk = pmc["kernels"].get(dom)
-                if kk:
+                if kk and args.workload == "kitti":   # the PMC passes were taken on the KITTI workload
                     roofline["traffic"] = kk["hbm_bytes"] * min(group, B) / pmc["pairs_per_launch"]
                     roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), " \
                                                  "read = 2*FETCH_SIZE*1024 (gfx950), scaled to pairs per launch"

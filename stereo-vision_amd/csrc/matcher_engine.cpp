@@ -90,10 +90,11 @@ struct svh_matcher {
     DevView prev[2], cur[2];
     int32_t dims_p[3], dims_c[3];
     // scratch
-    int4* slots = nullptr;
-    int32_t* flags = nullptr;
-    int32_t* order = nullptr;
+    int4* slots[2] = {nullptr, nullptr};      // NMS scratch, one set per camera (the cameras'
+    int32_t* flags[2] = {nullptr, nullptr};   // feature extraction runs on two streams)
+    int32_t* order[2] = {nullptr, nullptr};
     int32_t slot_cap = 0;
+    hipStream_t stream2 = nullptr;            // camera 1 during pushBack
     int32_t* cursor = nullptr;
     int32_t cursor_cap = 0;
     svh_p_match *pm_slots = nullptr, *pm_out = nullptr;
@@ -154,6 +155,7 @@ static int ensure_view(svh_matcher* m, DevView& V, int32_t w, int32_t h, int32_t
     }
     HIP_TRY(dalloc(&V.cnt, 2));
     HIP_TRY(hipMemsetAsync(V.cnt, 0, 2 * sizeof(int32_t), m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));   // (re)allocation path only; the cameras use two streams
     int32_t ns = p.nms_n * 3;
     if (ns > 10) ns = std::max(p.nms_n, 10);           // matcher.cpp:824-828
     const int32_t nn[2] = {ns, p.nms_n};
@@ -167,10 +169,12 @@ static int ensure_view(svh_matcher* m, DevView& V, int32_t w, int32_t h, int32_t
 
 static int ensure_scratch(svh_matcher* m, int32_t slot_need, int32_t pm_need, size_t owner_need) {
     if (slot_need > m->slot_cap) {
-        (void)hipFree(m->slots); (void)hipFree(m->flags); (void)hipFree(m->order);
-        HIP_TRY(dalloc(&m->slots, (size_t)slot_need));
-        HIP_TRY(dalloc(&m->flags, (size_t)slot_need + 4));
-        HIP_TRY(dalloc(&m->order, (size_t)slot_need));
+        for (int c = 0; c < 2; c++) {
+            (void)hipFree(m->slots[c]); (void)hipFree(m->flags[c]); (void)hipFree(m->order[c]);
+            HIP_TRY(dalloc(&m->slots[c], (size_t)slot_need));
+            HIP_TRY(dalloc(&m->flags[c], (size_t)slot_need + 4));
+            HIP_TRY(dalloc(&m->order[c], (size_t)slot_need));
+        }
         m->slot_cap = slot_need;
     }
     if (pm_need > m->pm_cap) {
@@ -192,7 +196,7 @@ static int ensure_scratch(svh_matcher* m, int32_t slot_need, int32_t pm_need, si
 // M1..M5  Matcher::computeFeatures   matcher.cpp:780-878
 static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* src, int32_t pitch) {
     const svh_matcher_params& p = m->p;
-    hipStream_t s = m->stream;
+    hipStream_t s = cam == 1 ? m->stream2 : m->stream;
     const size_t fn = (size_t)V.bpl * V.h;
     if (fn > m->h_stage_cap[cam]) {
         HIP_TRY(hipStreamSynchronize(s));
@@ -214,7 +218,10 @@ static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* 
     }
     memcpy(V.host.data(), stage, fn);
     ftick(1);
-    HIP_TRY(hipMemcpyAsync(V.I, stage, fn, hipMemcpyHostToDevice, s));
+    if (fn % 16 == 0)
+        mlaunch_upload(s, stage, V.I, fn);
+    else
+        HIP_TRY(hipMemcpyAsync(V.I, stage, fn, hipMemcpyHostToDevice, s));
     ftick(2);
     const uint8_t* Im = V.I;
     if (p.half_resolution) {
@@ -231,11 +238,11 @@ static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* 
     if (rc) return rc;
     if (p.multi_stage)
         mlaunch_features(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, ns, p.nms_tau, m->margin, scale,
-                         m->slots, m->flags, m->order, V.tab[0], V.cnt + 0);
+                         m->slots[cam], m->flags[cam], m->order[cam], V.tab[0], V.cnt + 0);
     else
         HIP_TRY(hipMemsetAsync(V.cnt, 0, sizeof(int32_t), s));
     mlaunch_features(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, p.nms_n, p.nms_tau, m->margin, scale,
-                     m->slots, m->flags, m->order, V.tab[1], V.cnt + 1);
+                     m->slots[cam], m->flags[cam], m->order[cam], V.tab[1], V.cnt + 1);
     ftick(4);
     // feature counts come back through pinned memory after BOTH cameras are enqueued
     // (a copy into pageable memory would block here until this camera's kernels finish)
@@ -492,13 +499,17 @@ void svh_matcher_destroy(svh_matcher* m) {
             m->prev[k].release();
             m->cur[k].release();
         }
-        (void)hipFree(m->slots); (void)hipFree(m->flags); (void)hipFree(m->order); (void)hipFree(m->cursor);
+        for (int c = 0; c < 2; c++) {
+            (void)hipFree(m->slots[c]); (void)hipFree(m->flags[c]); (void)hipFree(m->order[c]);
+        }
+        (void)hipFree(m->cursor);
         (void)hipFree(m->pm_slots);
         (void)hipFree(m->pm_out); (void)hipFree(m->pm_flags); (void)hipFree(m->pm_count);
         (void)hipFree(m->pixel_owner); (void)hipFree(m->ranges_dev); (void)hipHostFree(m->h_stage[0]);
         (void)hipHostFree(m->h_stage[1]); (void)hipHostFree(m->h_pm); (void)hipHostFree(m->h_cnt);
         (void)hipHostFree(m->h_n);
         (void)hipStreamDestroy(m->stream);
+        if (m->stream2) (void)hipStreamDestroy(m->stream2);
     }
     delete m;
 }
@@ -522,6 +533,7 @@ int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* 
         return mfail(SVH_ERR_NO_DEVICE, "no HIP device visible: libsvhip has no CPU fallback");
     HIP_TRY(hipSetDevice(m->device));
     if (!m->stream) HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    if (!m->stream2) HIP_TRY(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
     if (!replace) {
         // ring buffer: current -> previous; the old previous buffers are recycled
         for (int k = 0; k < 2; k++) {
@@ -547,6 +559,7 @@ int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* 
     }
     const double t1 = g_mtiming ? mnow_ms() : 0;
     HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream2));
     HIP_TRY(hipGetLastError());
     for (int k = 0; k < 2; k++)
         if (src[k]) {

@@ -35,6 +35,7 @@ struct MatchParams {
     double tr[12];                // rows 0..2 of Tr_delta
 };
 
+void mlaunch_upload(void* stream, const uint8_t* pinned, uint8_t* dev, size_t bytes);
 void mlaunch_half(void* stream, const uint8_t* I, int bpl, uint8_t* out, int hw, int hh, int hbpl);
 // f1 == nullptr: Sobel only
 void mlaunch_filters(void* stream, const uint8_t* I, int w, int h, int bpl, uint8_t* du, uint8_t* dv,

@@ -733,8 +733,25 @@ __global__ __launch_bounds__(128) void k_refine(svh_p_match* __restrict__ m,
 }  // namespace
 
 // ---------------------------------------------------------------------------
+// Image upload: the rows were packed into PINNED host memory; the device reads
+// them over PCIe with 16-byte loads and writes its HBM copy.  One kernel launch
+// instead of a hipMemcpyAsync (whose submission alone costs ~90 us per image).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ host, uint4* __restrict__ dev,
+                                                size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dev[i] = host[i];
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+void mlaunch_upload(void* stream, const uint8_t* pinned, uint8_t* dev, size_t bytes) {
+    const size_t n16 = bytes / 16;   // bpl is a multiple of 16
+    hipLaunchKernelGGL(k_upload, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(pinned), reinterpret_cast<uint4*>(dev), n16);
+}
+
 void mlaunch_half(void* stream, const uint8_t* I, int bpl, uint8_t* out, int hw, int hh, int hbpl) {
     hipLaunchKernelGGL(k_half, dim3((hw + 63) / 64, (hh + 3) / 4), dim3(64, 4), 0, (hipStream_t)stream, I, bpl,
                        out, hw, hh, hbpl);
