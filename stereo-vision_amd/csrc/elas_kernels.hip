@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_descriptor(DevImages img, int W, int H,
 // "<": that is the smallest and second smallest of the keys (E<<16 | d).
 // ---------------------------------------------------------------------------
 struct SupportParams {
-    int W, H, Wc, Hc, step;
+    int W, H, Wc, Hc, step, npairs;
     int disp_min, disp_max, support_texture, lr_threshold;
     float support_threshold;
 };
@@ -299,8 +299,16 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
                                                      int16_t* __restrict__ dcan_all,
                                                      SupportParams P) {
     extern __shared__ uint4 s_strip[];
-    const int pair = blockIdx.z, vc = blockIdx.y;
-    const int uc0 = blockIdx.x * kSB;
+    // XCD-aware block order.  Workgroups go to the 8 XCDs round-robin by linear id, and the
+    // chunks of one lattice row re-read each other's strips (every strip is 2*disp_max wider
+    // than its candidates).  Ids are therefore taken in super-groups of 8*chunks: XCD k gets
+    // all chunks of lattice row q*8+k, so the overlap is served by that XCD's L2, not HBM.
+    const int chunks = (P.Wc + kSB - 1) / kSB;
+    const int bid = blockIdx.x;
+    const int row_id = (bid / (8 * chunks)) * 8 + (bid & 7);   // (pair, lattice row) pair index
+    if (row_id >= P.Hc * P.npairs) return;
+    const int pair = row_id / P.Hc, vc = row_id - pair * P.Hc;
+    const int uc0 = ((bid >> 3) % chunks) * kSB;
     const int ncand = (P.Wc - uc0) < kSB ? (P.Wc - uc0) : kSB;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
@@ -1563,7 +1571,7 @@ void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t g, int
 void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                     const uint8_t* desc, int16_t* dcan) {
     SupportParams P;
-    P.W = d.W; P.H = d.H; P.Wc = d.Wc; P.Hc = d.Hc; P.step = d.step;
+    P.W = d.W; P.H = d.H; P.Wc = d.Wc; P.Hc = d.Hc; P.step = d.step; P.npairs = g;
     P.disp_min = p.disp_min; P.disp_max = p.disp_max;
     P.support_texture = p.support_texture; P.lr_threshold = p.lr_threshold;
     P.support_threshold = p.support_threshold;
@@ -1576,7 +1584,9 @@ void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d
     const size_t lds = 2 * (wl + wr) * sizeof(uint4);
     if (lds <= 64 * 1024 || (variant == 3 && lds <= 80 * 1024)) {
         Timed timed_(cx, "k_support");
-        const dim3 grid((d.Wc + sb - 1) / sb, d.Hc, g);
+        // (pairs * lattice rows rounded up to 8) * chunks blocks: XCD-aware order, see the kernel
+        const int chunks = (d.Wc + sb - 1) / sb;
+        const dim3 grid((unsigned)(((d.Hc * g + 7) / 8) * 8 * chunks), 1, 1);
         hipStream_t s = (hipStream_t)cx.stream;
         if (variant == 0) hipLaunchKernelGGL((k_support_lds<16, 256>), grid, dim3(256), lds, s, desc, dcan, P);
         else if (variant == 1) hipLaunchKernelGGL((k_support_lds<32, 512>), grid, dim3(512), lds, s, desc, dcan, P);

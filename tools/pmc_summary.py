@@ -15,15 +15,28 @@ import sqlite3
 import sys
 
 
+ALIAS = {"k_support_lds": "k_support", "k_match_keyed": "k_match"}   # symbol -> bench.py profile name
+
+
 def per_kernel(path, counter):
+    """average per launch over the launches with the largest grid of each kernel (the full
+    G-pair groups; bench.py's single-pair latency calls are excluded)"""
     db = sqlite3.connect(path)
-    out = {}
-    for name, n, avg in db.execute(
-            "select name, count(*), avg(counter_value) from pmc_events where counter_name=? group by name",
-            (counter,)):
+    grid = {did: gx * gy * gz for did, gx, gy, gz in
+            db.execute("select dispatch_id, grid_x, grid_y, grid_z from kernels")}
+    rows = {}
+    for name, did, tot in db.execute(
+            "select name, dispatch_id, sum(counter_value) from pmc_events where counter_name=? "
+            "group by name, dispatch_id", (counter,)):
         m = re.search(r"(k_\w+)", name)
         if m:
-            out[m.group(1).replace("k_support_lds", "k_support")] = (n, avg)
+            k = ALIAS.get(m.group(1), m.group(1))
+            rows.setdefault(k, []).append((grid.get(did, 0), tot))
+    out = {}
+    for k, v in rows.items():
+        gmax = max(g for g, _ in v)
+        sel = [x for g, x in v if g == gmax]
+        out[k] = (len(sel), sum(sel) / len(sel))
     return out
 
 
