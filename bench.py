@@ -137,6 +137,42 @@ def matcher_bench(iters=40):
     return out
 
 
+def vo_bench(iters=40):
+    """SURVEY 8(f) rank 1: VisualOdometryStereo::process (pushBack + quad match + bucketing +
+    RANSAC/Gauss-Newton motion estimate) per stereo frame on the reference's quad, device vs the
+    reference on one host core; plus estimateMotion alone on the bucketed matches"""
+    import helpers as Hh
+    im = [Hh.read_pgm(os.path.join(Hh.GOLDEN, "viso_%s.pgm" % k)) for k in ("I1p", "I2p", "I1c", "I2c")]
+    prm = Hh.vo_defaults()
+
+    def run(vo, n):
+        vo.process(im[0], im[1])
+        t = time.perf_counter()
+        ok = 0
+        for i in range(n):
+            a, b = (im[2], im[3]) if i % 2 == 0 else (im[0], im[1])
+            ok += vo.process(a, b) == 1
+        frame = 1e3 * (time.perf_counter() - t) / n
+        m = vo.matches()
+        t = time.perf_counter()
+        for _ in range(n):
+            vo.estimate_motion(m)
+        est = 1e3 * (time.perf_counter() - t) / n
+        return frame, est, ok, len(m), len(vo.inliers())
+
+    dev = Hh.ProductVo(prm)
+    run(dev, 5)
+    frame, est, ok, nm, ni = run(Hh.ProductVo(prm), iters)
+    out = {"workload": "VisualOdometryStereo::process on libviso2/img quad 1344x391, default parameters, "
+                       "calibration of demo.cpp", "frame_ms": frame, "estimateMotion_ms": est,
+           "frames_ok": ok, "matches": nm, "inliers": ni}
+    if Hh.have_ref_viso():
+        rf, re_, rok, rnm, rni = run(Hh.RefVo(prm), 10)
+        out["cpu_reference"] = {"frame_ms": rf, "estimateMotion_ms": re_, "frames_ok": rok, "matches": rnm,
+                                "inliers": rni, "cores": 1, "kind": "reference"}
+    return out
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -379,6 +415,7 @@ def main():
             out["latency_stages_ms"] = {k: round(v, 3) for k, v in e1.last_timing()}
         if world == 1 and not args.no_cpu_baseline:
             out["matcher"] = matcher_bench()     # before the CPU leg: the GPU is still at its clocks
+            out["visual_odometry"] = vo_bench()
             out["cpu_baseline"] = cpu_baseline(I1, I2, params)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -252,6 +252,46 @@ int32_t svh_matcher_get_stage(svh_matcher* m, int32_t stage, void* buf, size_t c
 int32_t svh_matcher_get_filter(svh_matcher* m, int32_t which, void* buf, size_t cap, size_t* size,
                                int32_t* dims3);
 
+/* ===========================================================================
+ * libviso2 VisualOdometryStereo (the caller of the Matcher)
+ *   VisualOdometryStereo::parameters        libviso2/src/viso_stereo.h:30-44
+ *   VisualOdometry::parameters/bucketing/calibration  libviso2/src/viso.h:30-66
+ * =========================================================================== */
+typedef struct svh_vo_params {
+    svh_matcher_params match;      /* parameters::match                                       */
+    int32_t bucket_max_features;   /* bucketing::max_features   (2)                           */
+    double  bucket_width;          /* bucketing::bucket_width   (50)                          */
+    double  bucket_height;         /* bucketing::bucket_height  (50)                          */
+    double  f, cu, cv;             /* calibration               (1, 0, 0)                     */
+    double  base;                  /* baseline in metres        (1.0)                         */
+    int32_t ransac_iters;          /* (200)                                                   */
+    double  inlier_threshold;      /* (2.0)                                                   */
+    int32_t reweighting;           /* (1)                                                     */
+} svh_vo_params;
+typedef struct svh_vo svh_vo;
+
+void    svh_vo_params_default(svh_vo_params* p);
+/* VisualOdometryStereo(param): creates the Matcher, sets its intrinsics, Tr_delta = I and
+ * calls srand(0) like the reference (viso.cpp:28-37, viso_stereo.cpp:26-31) */
+svh_vo* svh_vo_create(const svh_vo_params* p);
+void    svh_vo_destroy(svh_vo* v);
+/* bool VisualOdometryStereo::process(I1,I2,dims,replace) -- viso_stereo.cpp:41-68.
+ * returns 1 (true), 0 (false: motion estimate failed) or a negative SVH_ERR_* */
+int32_t svh_vo_process(svh_vo* v, const uint8_t* I1, const uint8_t* I2, const int32_t* dims,
+                       int32_t replace);
+/* bool VisualOdometry::process(p_matched) -- viso.h:87-91: motion from given matches */
+int32_t svh_vo_process_matches(svh_vo* v, const svh_p_match* matches, int32_t n);
+/* vector<double> estimateMotion(p_matched) -- viso_stereo.cpp:72-228 (RANSAC + Gauss-Newton on
+ * the device).  returns 1 and tr_delta[6] = rx,ry,rz,tx,ty,tz, or 0 (empty vector).  Consumes
+ * 3 libc rand() values per RANSAC iteration exactly like getRandomSample (viso.cpp:130-153). */
+int32_t svh_vo_estimate_motion(svh_vo* v, const svh_p_match* matches, int32_t n, double* tr_delta6);
+void    svh_vo_get_motion(svh_vo* v, double* Tr16);              /* getDeltaMotion, row major  */
+int32_t svh_vo_get_matches(svh_vo* v, svh_p_match* out, int32_t cap);   /* _matcher->getMatches() */
+int32_t svh_vo_num_matches(svh_vo* v);                           /* getNumberOfMatches         */
+int32_t svh_vo_get_inliers(svh_vo* v, int32_t* out, int32_t cap);/* getInlierIndices           */
+float   svh_vo_get_gain(svh_vo* v, const int32_t* inliers, int32_t n);
+svh_matcher* svh_vo_matcher(svh_vo* v);                          /* the owned Matcher (taps)   */
+
 #ifdef __cplusplus
 }
 #endif

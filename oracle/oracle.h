@@ -93,6 +93,22 @@ int64_t      orc_matcher_get_stage(orc_matcher* m, int32_t stage, void* buf, int
 int64_t      orc_matcher_get_filter(orc_matcher* m, int32_t which, void* buf, int64_t cap,
                                     int32_t* dims3);
 
+/* ---- libviso2 VisualOdometryStereo (oracle/viso_oracle.cpp) ------------------ */
+/* Same call surface as the svh_vo_* C-ABI (include/svh.h). */
+typedef struct orc_vo orc_vo;
+void    orc_vo_params_default(svh_vo_params* p);
+orc_vo* orc_vo_create(const svh_vo_params* p);
+void    orc_vo_destroy(orc_vo* v);
+void    orc_vo_set_triangulator(orc_vo* v, orc_triangulate_fn fn);
+int32_t orc_vo_process(orc_vo* v, const uint8_t* I1, const uint8_t* I2, const int32_t* dims, int32_t replace);
+int32_t orc_vo_process_matches(orc_vo* v, const svh_p_match* m, int32_t n);
+int32_t orc_vo_estimate_motion(orc_vo* v, const svh_p_match* m, int32_t n, double* tr6);
+void    orc_vo_get_motion(orc_vo* v, double* Tr16);
+int32_t orc_vo_get_inliers(orc_vo* v, int32_t* out, int32_t cap);
+int32_t orc_vo_num_matches(orc_vo* v);
+int32_t orc_vo_get_matches(orc_vo* v, svh_p_match* out, int32_t cap);
+float   orc_vo_get_gain(orc_vo* v, const int32_t* inliers, int32_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,10 @@
 #include <vector>
 
 #define private public   // reach the private stage functions
+#define protected public
 #include "matcher.h"
+#include "viso_stereo.h"
+#undef protected
 #undef private
 #include "filter.h"
 #include "triangle.h"
@@ -281,5 +284,84 @@ int32_t ref_viso_triangulate(const float* pts, int32_t n, int32_t* tri, int32_t 
     free(out.trianglelist);
     return nt;
 }
+
+
+// ---- VisualOdometryStereo (viso_stereo.cpp, viso.cpp) ------------------------------------
+struct ref_vo { VisualOdometryStereo* vo; };
+
+static VisualOdometryStereo::parameters to_ref_vo(const svh_vo_params* p) {
+    VisualOdometryStereo::parameters r;
+    r.match = to_ref(&p->match);
+    r.bucket.max_features = p->bucket_max_features;
+    r.bucket.bucket_width = p->bucket_width;
+    r.bucket.bucket_height = p->bucket_height;
+    r.calib.f = p->f; r.calib.cu = p->cu; r.calib.cv = p->cv;
+    r.base = p->base;
+    r.ransac_iters = p->ransac_iters;
+    r.inlier_threshold = p->inlier_threshold;
+    r.reweighting = p->reweighting != 0;
+    return r;
+}
+void ref_vo_params_default(svh_vo_params* p) {
+    VisualOdometryStereo::parameters r;
+    ref_matcher_params_default(&p->match);
+    p->bucket_max_features = r.bucket.max_features;
+    p->bucket_width = r.bucket.bucket_width;
+    p->bucket_height = r.bucket.bucket_height;
+    p->f = r.calib.f; p->cu = r.calib.cu; p->cv = r.calib.cv;
+    p->base = r.base;
+    p->ransac_iters = r.ransac_iters;
+    p->inlier_threshold = r.inlier_threshold;
+    p->reweighting = r.reweighting ? 1 : 0;
+}
+ref_vo* ref_vo_create(const svh_vo_params* p) {
+    ref_vo* h = new ref_vo();
+    h->vo = new VisualOdometryStereo(to_ref_vo(p));   // calls srand(0)
+    return h;
+}
+void ref_vo_destroy(ref_vo* h) { delete h->vo; delete h; }
+int32_t ref_vo_process(ref_vo* h, const uint8_t* I1, const uint8_t* I2, const int32_t* dims, int32_t replace) {
+    int32_t d[3] = {dims[0], dims[1], dims[2]};
+    return h->vo->process(const_cast<uint8_t*>(I1), const_cast<uint8_t*>(I2), d, replace != 0) ? 1 : 0;
+}
+static std::vector<Matcher::p_match> from_abi(const svh_p_match* m, int32_t n) {
+    std::vector<Matcher::p_match> v(n);
+    for (int32_t i = 0; i < n; i++) {
+        v[i].u1p = m[i].u1p; v[i].v1p = m[i].v1p; v[i].i1p = m[i].i1p;
+        v[i].u2p = m[i].u2p; v[i].v2p = m[i].v2p; v[i].i2p = m[i].i2p;
+        v[i].u1c = m[i].u1c; v[i].v1c = m[i].v1c; v[i].i1c = m[i].i1c;
+        v[i].u2c = m[i].u2c; v[i].v2c = m[i].v2c; v[i].i2c = m[i].i2c;
+    }
+    return v;
+}
+int32_t ref_vo_estimate_motion(ref_vo* h, const svh_p_match* m, int32_t n, double* tr6) {
+    std::vector<double> tr = h->vo->estimateMotion(from_abi(m, n));
+    if (tr.size() != 6) return 0;
+    for (int i = 0; i < 6; i++) tr6[i] = tr[i];
+    return 1;
+}
+int32_t ref_vo_process_matches(ref_vo* h, const svh_p_match* m, int32_t n) {
+    return h->vo->VisualOdometry::process(from_abi(m, n)) ? 1 : 0;
+}
+void ref_vo_get_motion(ref_vo* h, double* Tr16) {
+    Matrix T = h->vo->getDeltaMotion();
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) Tr16[4 * i + j] = T._val[i][j];
+}
+int32_t ref_vo_get_inliers(ref_vo* h, int32_t* out, int32_t cap) {
+    std::vector<int32_t> v = h->vo->getInlierIndices();
+    for (int32_t i = 0; i < (int32_t)v.size() && i < cap; i++) out[i] = v[i];
+    return (int32_t)v.size();
+}
+int32_t ref_vo_num_matches(ref_vo* h) { return h->vo->getNumberOfMatches(); }
+int32_t ref_vo_get_matches(ref_vo* h, svh_p_match* out, int32_t cap) {
+    ref_matcher tmp;
+    tmp.m = h->vo->_matcher;
+    return ref_matcher_get_matches(&tmp, out, cap);
+}
+float ref_vo_get_gain(ref_vo* h, const int32_t* inl, int32_t n) {
+    return h->vo->getGain(std::vector<int32_t>(inl, inl + n));
+}
+void ref_srand(uint32_t s) { srand(s); }
 
 }  // extern "C"

@@ -852,3 +852,274 @@ int64_t orc_matcher_get_filter(orc_matcher* m, int32_t which, void* buf, int64_t
 }
 
 }  // extern "C"
+
+// ===========================================================================
+// VisualOdometryStereo -- restated from
+//   libviso2/src/viso_stereo.cpp:41-68 (process), :72-228 (estimateMotion),
+//   :232-255 (getInlier), :259-323 (updateParameters), :327-337
+//   (computeObservations), :341-485 (computeResidualsAndJacobian) and
+//   libviso2/src/viso.cpp:28-37, 47-64, 68-96, 130-153.
+// Plain doubles, the reference's operation order (sums run over the rows in
+// ascending order, no FMA: the file is built -ffp-contract=off), libm sin/cos.
+// ===========================================================================
+struct orc_vo {
+    svh_vo_params p;
+    orc_matcher* matcher;
+    double Tr[16];
+    bool Tr_valid;
+    std::vector<int32_t> inliers;
+    std::vector<PM> matched;
+};
+
+namespace {
+
+typedef orc_vo VoState;
+
+enum VoResult { VO_UPDATED, VO_FAILED, VO_CONVERGED };
+
+struct VoWork {
+    const PM* pm;
+    int32_t n;
+    std::vector<double> X, Y, Z, J, predict, observe, residual;
+};
+
+// viso_stereo.cpp:327-337 + :341-485: observations, predictions, residuals and Jacobian rows
+// of the `active` matches for the motion tr = (rx,ry,rz,tx,ty,tz)
+void vo_linearise(const svh_vo_params& P, VoWork& w, const double* tr, const std::vector<int32_t>& active) {
+    const double rx = tr[0], ry = tr[1], rz = tr[2], tx = tr[3], ty = tr[4], tz = tr[5];
+    const double sx = sin(rx), cx = cos(rx), sy = sin(ry), cy = cos(ry), sz = sin(rz), cz = cos(rz);
+    // R = Rx * Ry * Rz and its partial derivatives
+    const double r00 = +cy * cz, r01 = -cy * sz, r02 = +sy;
+    const double r10 = +sx * sy * cz + cx * sz, r11 = -sx * sy * sz + cx * cz, r12 = -sx * cy;
+    const double r20 = -cx * sy * cz + sx * sz, r21 = +cx * sy * sz + sx * cz, r22 = +cx * cy;
+    const double ax10 = +cx * sy * cz - sx * sz, ax11 = -cx * sy * sz - sx * cz, ax12 = -cx * cy;
+    const double ax20 = +sx * sy * cz + cx * sz, ax21 = -sx * sy * sz + cx * cz, ax22 = -sx * cy;
+    const double ay00 = -sy * cz, ay01 = +sy * sz, ay02 = +cy;
+    const double ay10 = +sx * cy * cz, ay11 = -sx * cy * sz, ay12 = +sx * sy;
+    const double ay20 = -cx * cy * cz, ay21 = +cx * cy * sz, ay22 = -cx * sy;
+    const double az00 = -cy * sz, az01 = -cy * cz;
+    const double az10 = -sx * sy * sz + cx * cz, az11 = -sx * sy * cz - cx * sz;
+    const double az20 = +cx * sy * sz + sx * cz, az21 = +cx * sy * cz - sx * sz;
+    const double f = P.f, cu = P.cu, cv = P.cv;
+    for (size_t i = 0; i < active.size(); i++) {
+        const PM& m = w.pm[active[i]];
+        double* ob = &w.observe[4 * i];
+        ob[0] = m.u1c; ob[1] = m.v1c; ob[2] = m.u2c; ob[3] = m.v2c;
+        const double X1p = w.X[active[i]], Y1p = w.Y[active[i]], Z1p = w.Z[active[i]];
+        const double X1c = r00 * X1p + r01 * Y1p + r02 * Z1p + tx;
+        const double Y1c = r10 * X1p + r11 * Y1p + r12 * Z1p + ty;
+        const double Z1c = r20 * X1p + r21 * Y1p + r22 * Z1p + tz;
+        double weight = 1.0;
+        if (P.reweighting) weight = 1.0 / (fabs(ob[0] - cu) / fabs(cu) + 0.05);
+        const double X2c = X1c - P.base;
+        for (int j = 0; j < 6; j++) {
+            double dX = 0, dY = 0, dZ = 0;
+            switch (j) {
+                case 0: dX = 0;
+                        dY = ax10 * X1p + ax11 * Y1p + ax12 * Z1p;
+                        dZ = ax20 * X1p + ax21 * Y1p + ax22 * Z1p; break;
+                case 1: dX = ay00 * X1p + ay01 * Y1p + ay02 * Z1p;
+                        dY = ay10 * X1p + ay11 * Y1p + ay12 * Z1p;
+                        dZ = ay20 * X1p + ay21 * Y1p + ay22 * Z1p; break;
+                case 2: dX = az00 * X1p + az01 * Y1p;
+                        dY = az10 * X1p + az11 * Y1p;
+                        dZ = az20 * X1p + az21 * Y1p; break;
+                case 3: dX = 1; break;
+                case 4: dY = 1; break;
+                case 5: dZ = 1; break;
+            }
+            double* Jr = &w.J[(4 * i) * 6 + j];
+            Jr[0]  = weight * f * (dX * Z1c - X1c * dZ) / (Z1c * Z1c);
+            Jr[6]  = weight * f * (dY * Z1c - Y1c * dZ) / (Z1c * Z1c);
+            Jr[12] = weight * f * (dX * Z1c - X2c * dZ) / (Z1c * Z1c);
+            Jr[18] = Jr[6];
+        }
+        double* pr = &w.predict[4 * i];
+        pr[0] = f * X1c / Z1c + cu;
+        pr[1] = f * Y1c / Z1c + cv;
+        pr[2] = f * X2c / Z1c + cu;
+        pr[3] = pr[1];
+        for (int k = 0; k < 4; k++) w.residual[4 * i + k] = weight * (ob[k] - pr[k]);
+    }
+}
+
+// viso_stereo.cpp:259-323: one Gauss-Newton step, normal equations by ascending-row sums
+VoResult vo_update(const svh_vo_params& P, VoWork& w, const std::vector<int32_t>& active, double* tr,
+                   double step, double eps) {
+    if (active.size() < 3) return VO_FAILED;
+    vo_linearise(P, w, tr, active);
+    double A[36], B[6];
+    const int32_t rows = 4 * (int32_t)active.size();
+    for (int m = 0; m < 6; m++) {
+        for (int n = 0; n < 6; n++) {
+            double a = 0;
+            for (int32_t i = 0; i < rows; i++) a += w.J[i * 6 + m] * w.J[i * 6 + n];
+            A[m * 6 + n] = a;
+        }
+        double b = 0;
+        for (int32_t i = 0; i < rows; i++) b += w.J[i * 6 + m] * w.residual[i];
+        B[m] = b;
+    }
+    if (!gauss_jordan(A, B, 6)) return VO_FAILED;
+    bool converged = true;
+    for (int m = 0; m < 6; m++) {
+        tr[m] += step * B[m];
+        if (fabs(B[m]) > eps) converged = false;
+    }
+    return converged ? VO_CONVERGED : VO_UPDATED;
+}
+
+// viso_stereo.cpp:72-228.  Returns true and tr[6] on success (the reference's 6-vector), false
+// for its empty vector; `inliers` is left as the reference leaves _inliers.
+bool vo_estimate(VoState* s, const PM* pm, int32_t N, double* tr_out) {
+    const svh_vo_params& P = s->p;
+    if (N < 6) return false;               // _inliers is NOT cleared on this path (:91-94)
+    VoWork w;
+    w.pm = pm; w.n = N;
+    w.X.resize(N); w.Y.resize(N); w.Z.resize(N);
+    w.J.assign((size_t)4 * N * 6, 0.0);
+    w.predict.assign((size_t)4 * N, 0.0);
+    w.observe.assign((size_t)4 * N, 0.0);
+    w.residual.assign((size_t)4 * N, 0.0);
+    for (int32_t i = 0; i < N; i++) {
+        const double d = std::max(pm[i].u1p - pm[i].u2p, 0.0001f);   // float max, then widened
+        w.X[i] = (pm[i].u1p - P.cu) * P.base / d;
+        w.Y[i] = (pm[i].v1p - P.cv) * P.base / d;
+        w.Z[i] = P.f * P.base / d;
+    }
+    std::vector<double> best;     // empty until a hypothesis wins
+    double cur[6];
+    s->inliers.clear();
+    std::vector<int32_t> all(N);
+    for (int32_t i = 0; i < N; i++) all[i] = i;
+    for (int32_t k = 0; k < P.ransac_iters; k++) {
+        // getRandomSample(N, 3), viso.cpp:130-153: draw without replacement through libc rand()
+        std::vector<int32_t> pool(all), active;
+        for (int q = 0; q < 3; q++) {
+            const int32_t j = rand() % (int32_t)pool.size();
+            active.push_back(pool[j]);
+            pool.erase(pool.begin() + j);
+        }
+        for (int i = 0; i < 6; i++) cur[i] = 0;
+        VoResult res = VO_UPDATED;
+        int32_t iter = 0;
+        while (res == VO_UPDATED) {
+            res = vo_update(P, w, active, cur, 1, 1e-6);
+            if (iter++ > 20 || res == VO_CONVERGED) break;
+        }
+        if (res != VO_FAILED) {
+            // getInlier, :232-255
+            vo_linearise(P, w, cur, all);
+            std::vector<int32_t> in;
+            const double thr = P.inlier_threshold * P.inlier_threshold;
+            for (int32_t i = 0; i < N; i++) {
+                const double e0 = w.observe[4 * i + 0] - w.predict[4 * i + 0];
+                const double e1 = w.observe[4 * i + 1] - w.predict[4 * i + 1];
+                const double e2 = w.observe[4 * i + 2] - w.predict[4 * i + 2];
+                const double e3 = w.observe[4 * i + 3] - w.predict[4 * i + 3];
+                if (e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3 < thr) in.push_back(i);
+            }
+            if (in.size() > s->inliers.size()) {
+                s->inliers = in;
+                best.assign(cur, cur + 6);
+            }
+        }
+    }
+    bool success = true;
+    if (s->inliers.size() >= 6) {
+        int32_t iter = 0;
+        VoResult res = VO_UPDATED;
+        while (res == VO_UPDATED) {
+            res = vo_update(P, w, s->inliers, best.data(), 1, 1e-8);
+            if (iter++ > 100 || res == VO_CONVERGED) break;
+        }
+        if (res != VO_CONVERGED) success = false;
+    } else {
+        success = false;
+    }
+    if (!success) return false;
+    for (int i = 0; i < 6; i++) tr_out[i] = best[i];
+    return true;
+}
+
+// viso.cpp:68-96
+void vo_vector_to_matrix(const double* tr, double* T) {
+    const double sx = sin(tr[0]), cx = cos(tr[0]), sy = sin(tr[1]), cy = cos(tr[1]);
+    const double sz = sin(tr[2]), cz = cos(tr[2]);
+    T[0] = +cy * cz;                T[1] = -cy * sz;                T[2] = +sy;       T[3] = tr[3];
+    T[4] = +sx * sy * cz + cx * sz; T[5] = -sx * sy * sz + cx * cz; T[6] = -sx * cy;  T[7] = tr[4];
+    T[8] = -cx * sy * cz + sx * sz; T[9] = +cx * sy * sz + sx * cz; T[10] = +cx * cy; T[11] = tr[5];
+    T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+}
+
+// viso.cpp:47-64
+bool vo_update_motion(VoState* s) {
+    double tr[6];
+    if (!vo_estimate(s, s->matched.data(), (int32_t)s->matched.size(), tr)) return false;
+    vo_vector_to_matrix(tr, s->Tr);
+    s->Tr_valid = true;
+    return true;
+}
+
+void vo_fetch_matches(VoState* s) {
+    const int32_t n = orc_matcher_get_matches(s->matcher, 0, 0);
+    s->matched.resize(n);
+    if (n) orc_matcher_get_matches(s->matcher, s->matched.data(), n);
+}
+
+}  // namespace
+
+extern "C" {
+
+void orc_vo_params_default(svh_vo_params* p) {
+    orc_matcher_params_default(&p->match);
+    p->bucket_max_features = 2; p->bucket_width = 50; p->bucket_height = 50;   // viso.h:50-55
+    p->f = 1; p->cu = 0; p->cv = 0;                                            // viso.h:38-43
+    p->base = 1.0; p->ransac_iters = 200; p->inlier_threshold = 2.0; p->reweighting = 1;
+}
+
+orc_vo* orc_vo_create(const svh_vo_params* p) {
+    VoState* s = new VoState();
+    s->p = *p;
+    s->matcher = orc_matcher_create(&p->match);
+    orc_matcher_set_intrinsics(s->matcher, p->f, p->cu, p->cv, p->base);
+    for (int i = 0; i < 16; i++) s->Tr[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    s->Tr_valid = false;
+    srand(0);                                                                  // viso.cpp:36
+    return s;
+}
+void orc_vo_destroy(orc_vo* s) { orc_matcher_destroy(s->matcher); delete s; }
+void orc_vo_set_triangulator(orc_vo* s, orc_triangulate_fn fn) { orc_matcher_set_triangulator(s->matcher, fn); }
+
+// viso_stereo.cpp:41-68
+int32_t orc_vo_process(orc_vo* s, const uint8_t* I1, const uint8_t* I2, const int32_t* dims, int32_t replace) {
+    const svh_vo_params& P = s->p;
+    orc_matcher_push_back(s->matcher, I1, I2, dims, replace);
+    if (!s->Tr_valid) {
+        orc_matcher_match_features(s->matcher, 2, 0);
+        orc_matcher_bucket_features(s->matcher, P.bucket_max_features, (float)P.bucket_width, (float)P.bucket_height);
+        vo_fetch_matches(s);
+        vo_update_motion(s);
+    }
+    orc_matcher_match_features(s->matcher, 2, s->Tr_valid ? s->Tr : 0);
+    orc_matcher_bucket_features(s->matcher, P.bucket_max_features, (float)P.bucket_width, (float)P.bucket_height);
+    vo_fetch_matches(s);
+    return vo_update_motion(s) ? 1 : 0;
+}
+int32_t orc_vo_process_matches(orc_vo* s, const svh_p_match* m, int32_t n) {
+    s->matched.assign(m, m + n);
+    return vo_update_motion(s) ? 1 : 0;
+}
+int32_t orc_vo_estimate_motion(orc_vo* s, const svh_p_match* m, int32_t n, double* tr6) {
+    return vo_estimate(s, m, n, tr6) ? 1 : 0;
+}
+void orc_vo_get_motion(orc_vo* s, double* Tr16) { memcpy(Tr16, s->Tr, sizeof(s->Tr)); }
+int32_t orc_vo_get_inliers(orc_vo* s, int32_t* out, int32_t cap) {
+    for (int32_t i = 0; i < (int32_t)s->inliers.size() && i < cap && out; i++) out[i] = s->inliers[i];
+    return (int32_t)s->inliers.size();
+}
+int32_t orc_vo_num_matches(orc_vo* s) { return (int32_t)s->matched.size(); }
+int32_t orc_vo_get_matches(orc_vo* s, svh_p_match* out, int32_t cap) { return orc_matcher_get_matches(s->matcher, out, cap); }
+float orc_vo_get_gain(orc_vo* s, const int32_t* inl, int32_t n) { return orc_matcher_get_gain(s->matcher, inl, n); }
+
+}  // extern "C"

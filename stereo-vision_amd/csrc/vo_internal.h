@@ -1,0 +1,30 @@
+// internal interface between vo_engine.cpp (host) and vo_kernels.hip (device)
+#ifndef SVH_VO_INTERNAL_H
+#define SVH_VO_INTERNAL_H
+#include <stdint.h>
+
+#include "../../include/svh.h"
+
+namespace svh {
+
+struct VoCalib {
+    double f, cu, cv, base, inlier_threshold;
+    int32_t reweighting;
+};
+
+struct VoResult {          // written by k_vo_refine into pinned host memory
+    double tr[6];
+    int32_t success;       // final Gauss-Newton converged on >= 6 inliers
+    int32_t n_inliers;     // size of the winning hypothesis' inlier set (may be < 6)
+    int32_t best;          // winning hypothesis, -1 = none
+    int32_t pad_;
+};
+
+// pinned host -> device copy by a kernel (bytes is a multiple of 16)
+void vlaunch_upload(void* stream, const uint8_t* pinned, uint8_t* dev, size_t bytes);
+void vlaunch_estimate(void* stream, const svh_p_match* pm, int N, const int32_t* samples, int iters,
+                      const VoCalib& c, double* hyp_tr, int32_t* hyp_count, uint8_t* hyp_flags, double* Jg,
+                      double* resg, VoResult* out, int32_t* out_inliers);
+
+}  // namespace svh
+#endif

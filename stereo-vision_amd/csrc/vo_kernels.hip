@@ -1,0 +1,384 @@
+// VisualOdometryStereo::estimateMotion on the device
+//   libviso2/src/viso_stereo.cpp:72-228 (RANSAC + iterated Gauss-Newton),
+//   :232-255 getInlier, :259-323 updateParameters, :341-485 residuals / Jacobian.
+//
+// k_vo_ransac   one wave per RANSAC hypothesis (the 200 hypotheses are independent):
+//               Gauss-Newton on its 3 sampled matches, then the inlier vote over all N.
+// k_vo_refine   one workgroup: first hypothesis with the most inliers, its inlier list
+//               in index order, final Gauss-Newton over the inliers.
+//
+// Arithmetic is fp64 in the reference's operation order: the normal equations are
+// summed over the Jacobian rows in ascending order by one lane per matrix entry, no
+// FMA contraction (library flag -ffp-contract=off plus explicit *_rn intrinsics in
+// the sums).  sin/cos are the device libm's; they can differ from glibc's in the
+// last bit, which is the only source of (<= 1e-12) deviations from the CPU result.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/svh.h"
+#include "vo_internal.h"
+
+namespace svh {
+
+namespace {
+
+struct Rot {   // R = Rx*Ry*Rz and its partial derivatives (viso_stereo.cpp:352-377)
+    double r00, r01, r02, r10, r11, r12, r20, r21, r22;
+    double ax10, ax11, ax12, ax20, ax21, ax22;
+    double ay00, ay01, ay02, ay10, ay11, ay12, ay20, ay21, ay22;
+    double az00, az01, az10, az11, az20, az21;
+};
+
+__device__ __forceinline__ Rot make_rot(const double* tr) {
+    const double sx = sin(tr[0]), cx = cos(tr[0]), sy = sin(tr[1]), cy = cos(tr[1]);
+    const double sz = sin(tr[2]), cz = cos(tr[2]);
+    Rot R;
+    R.r00 = +cy * cz;                R.r01 = -cy * sz;                R.r02 = +sy;
+    R.r10 = +sx * sy * cz + cx * sz; R.r11 = -sx * sy * sz + cx * cz; R.r12 = -sx * cy;
+    R.r20 = -cx * sy * cz + sx * sz; R.r21 = +cx * sy * sz + sx * cz; R.r22 = +cx * cy;
+    R.ax10 = +cx * sy * cz - sx * sz; R.ax11 = -cx * sy * sz - sx * cz; R.ax12 = -cx * cy;
+    R.ax20 = +sx * sy * cz + cx * sz; R.ax21 = -sx * sy * sz + cx * cz; R.ax22 = -sx * cy;
+    R.ay00 = -sy * cz;      R.ay01 = +sy * sz;      R.ay02 = +cy;
+    R.ay10 = +sx * cy * cz; R.ay11 = -sx * cy * sz; R.ay12 = +sx * sy;
+    R.ay20 = -cx * cy * cz; R.ay21 = +cx * cy * sz; R.ay22 = -cx * sy;
+    R.az00 = -cy * sz;                R.az01 = -cy * cz;
+    R.az10 = -sx * sy * sz + cx * cz; R.az11 = -sx * sy * cz - cx * sz;
+    R.az20 = +cx * sy * sz + sx * cz; R.az21 = +cx * sy * cz - sx * sz;
+    return R;
+}
+
+struct Point3 { double X, Y, Z; };
+
+// back-projection of the previous-frame match (viso_stereo.cpp:113-131)
+__device__ __forceinline__ Point3 back_project(const svh_p_match& m, const VoCalib& c) {
+    const float df = m.u1p - m.u2p;
+    const double d = (double)(df > 0.0001f ? df : 0.0001f);
+    Point3 p;
+    p.X = ((double)m.u1p - c.cu) * c.base / d;
+    p.Y = ((double)m.v1p - c.cv) * c.base / d;
+    p.Z = c.f * c.base / d;
+    return p;
+}
+
+// prediction of one match under (R, t): p[0..3] = u1c, v1c, u2c, v2c; also X1c.., weight
+struct Pred { double X1c, Y1c, Z1c, X2c, p[4]; };
+__device__ __forceinline__ Pred predict(const Rot& R, const double* tr, const Point3& P, const VoCalib& c) {
+    Pred q;
+    q.X1c = R.r00 * P.X + R.r01 * P.Y + R.r02 * P.Z + tr[3];
+    q.Y1c = R.r10 * P.X + R.r11 * P.Y + R.r12 * P.Z + tr[4];
+    q.Z1c = R.r20 * P.X + R.r21 * P.Y + R.r22 * P.Z + tr[5];
+    q.X2c = q.X1c - c.base;
+    q.p[0] = c.f * q.X1c / q.Z1c + c.cu;
+    q.p[1] = c.f * q.Y1c / q.Z1c + c.cv;
+    q.p[2] = c.f * q.X2c / q.Z1c + c.cu;
+    q.p[3] = q.p[1];
+    return q;
+}
+
+// column j of the four Jacobian rows of one match (viso_stereo.cpp:431-466)
+__device__ __forceinline__ void jacobian_col(const Rot& R, const Point3& P, const Pred& q, double weight,
+                                             const VoCalib& c, int j, double* J0, double* J1, double* J2) {
+    double dX = 0, dY = 0, dZ = 0;
+    switch (j) {
+        case 0: dY = R.ax10 * P.X + R.ax11 * P.Y + R.ax12 * P.Z;
+                dZ = R.ax20 * P.X + R.ax21 * P.Y + R.ax22 * P.Z; break;
+        case 1: dX = R.ay00 * P.X + R.ay01 * P.Y + R.ay02 * P.Z;
+                dY = R.ay10 * P.X + R.ay11 * P.Y + R.ay12 * P.Z;
+                dZ = R.ay20 * P.X + R.ay21 * P.Y + R.ay22 * P.Z; break;
+        case 2: dX = R.az00 * P.X + R.az01 * P.Y;
+                dY = R.az10 * P.X + R.az11 * P.Y;
+                dZ = R.az20 * P.X + R.az21 * P.Y; break;
+        case 3: dX = 1; break;
+        case 4: dY = 1; break;
+        default: dZ = 1; break;
+    }
+    const double zz = q.Z1c * q.Z1c;
+    *J0 = weight * c.f * (dX * q.Z1c - q.X1c * dZ) / zz;
+    *J1 = weight * c.f * (dY * q.Z1c - q.Y1c * dZ) / zz;
+    *J2 = weight * c.f * (dX * q.Z1c - q.X2c * dZ) / zz;
+}
+
+__device__ __forceinline__ double obs_weight(double u1c, const VoCalib& c) {
+    return c.reweighting ? 1.0 / (fabs(u1c - c.cu) / fabs(c.cu) + 0.05) : 1.0;
+}
+
+// Matrix::solve (6x6, one right-hand side)   libviso2/src/matrix.cpp:648-760
+// Gauss-Jordan with full pivoting, run by ONE WAVE: lane e < 42 owns element (e/7, e%7) of the
+// augmented matrix [A | B].  The reference scans rows then columns and takes ">=": the LAST
+// maximum wins, i.e. the largest (|a|, scan position) pair; rows are swapped, the pivot row is
+// scaled by 1/pivot (after the pivot itself was set to 1) and eliminated from the others with
+// the same expressions, so every element sees the reference's operation sequence.
+// All 64 lanes must call this.  Returns false (uniformly) for a pivot below 1e-20.
+__device__ __forceinline__ bool wave_solve6(double& a, int lane) {
+    const int r = lane / 7, cidx = lane - 7 * r;
+    const bool elem = lane < 42;
+    uint32_t used = 0;   // ipiv as a bit set
+    for (int it = 0; it < 6; it++) {
+        double v = -1.0;
+        int pos = -1;
+        if (elem && cidx < 6 && !((used >> r) & 1) && !((used >> cidx) & 1)) {
+            v = fabs(a);
+            pos = r * 6 + cidx;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double ov = __shfl_xor(v, m, 64);
+            const int op = __shfl_xor(pos, m, 64);
+            if (ov > v || (ov == v && op > pos)) {
+                v = ov;
+                pos = op;
+            }
+        }
+        const int irow = pos / 6, icol = pos - 6 * irow;
+        used |= 1u << icol;
+        if (irow != icol) {   // swap rows irow and icol (uniform branch)
+            const int src = r == irow ? icol * 7 + cidx : (r == icol ? irow * 7 + cidx : lane);
+            a = __shfl(a, elem ? src : lane, 64);
+        }
+        const double pivot = __shfl(a, icol * 7 + icol, 64);
+        if (fabs(pivot) < 1e-20) return false;
+        const double pivinv = __ddiv_rn(1.0, pivot);
+        if (elem && r == icol) a = __dmul_rn(cidx == icol ? 1.0 : a, pivinv);
+        const double rowval = __shfl(a, icol * 7 + (elem ? cidx : 0), 64);   // A[icol][l] after scaling
+        const double dum = __shfl(a, (elem ? r : 0) * 7 + icol, 64);         // A[ll][icol] before zeroing
+        if (elem && r != icol) a = __dsub_rn(cidx == icol ? 0.0 : a, __dmul_rn(rowval, dum));
+    }
+    return true;
+}
+
+enum { VO_UPDATED = 0, VO_FAILED = 1, VO_CONVERGED = 2 };
+
+// One Gauss-Newton step by one wave (viso_stereo.cpp:281-322).  J is [rows][6] row major and
+// res [rows] (LDS or global).  Lane e < 42 sums its entry of [JtJ | Jt r] over the rows in
+// ascending order (the reference's loop order; loads are batched, the add chain is not
+// reordered), the wave solves, lanes 0..5 update tr (LDS).  Returns the status uniformly.
+__device__ __forceinline__ int wave_gn_step(const double* J, const double* res, int rows, int lane,
+                                            double* s_tr, double eps) {
+    const int m = lane / 7, n = lane - 7 * m;
+    double acc = 0.0;
+    if (lane < 42) {
+        for (int i0 = 0; i0 < rows; i0 += 8) {
+            double x[8], y[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i = i0 + q < rows ? i0 + q : rows - 1;
+                x[q] = J[i * 6 + m];
+                y[q] = n < 6 ? J[i * 6 + n] : res[i];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (i0 + q < rows) acc = __dadd_rn(acc, __dmul_rn(x[q], y[q]));
+        }
+    }
+    if (!wave_solve6(acc, lane)) return VO_FAILED;
+    // solution = column 6
+    bool big = false;
+    if (lane < 42 && n == 6) {
+        s_tr[m] = __dadd_rn(s_tr[m], acc);   // step_size = 1
+        big = fabs(acc) > eps;
+    }
+    return __ballot(big) ? VO_UPDATED : VO_CONVERGED;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_vo_ransac(const svh_p_match* __restrict__ pm, int N,
+                                                  const int32_t* __restrict__ samples, VoCalib c,
+                                                  double* __restrict__ hyp_tr,       // [iters][6]
+                                                  int32_t* __restrict__ hyp_count,   // [iters], -1 = failed
+                                                  uint8_t* __restrict__ hyp_flags) { // [iters][N]
+    __shared__ double s_tr[6], s_J[12 * 6], s_res[12];
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (lane < 6) s_tr[lane] = 0.0;
+    const int pt = lane / 6, col = lane - 6 * pt;      // lanes 0..17: (sampled match, parameter)
+    svh_p_match m = pm[0];
+    Point3 P = {0, 0, 0};
+    if (lane < 18) {
+        m = pm[samples[3 * k + pt]];
+        P = back_project(m, c);
+    }
+    __syncthreads();
+    int status = VO_UPDATED, iter = 0;
+    while (status == VO_UPDATED) {
+        double tr[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) tr[i] = s_tr[i];
+        __syncthreads();   // everyone has read s_tr before the step updates it
+        if (lane < 18) {
+            const Rot R = make_rot(tr);
+            const Pred q = predict(R, tr, P, c);
+            const double w = obs_weight((double)m.u1c, c);
+            double j0, j1, j2;
+            jacobian_col(R, P, q, w, c, col, &j0, &j1, &j2);
+            s_J[(4 * pt + 0) * 6 + col] = j0;
+            s_J[(4 * pt + 1) * 6 + col] = j1;
+            s_J[(4 * pt + 2) * 6 + col] = j2;
+            s_J[(4 * pt + 3) * 6 + col] = j1;
+            if (col == 0) {
+                s_res[4 * pt + 0] = w * ((double)m.u1c - q.p[0]);
+                s_res[4 * pt + 1] = w * ((double)m.v1c - q.p[1]);
+                s_res[4 * pt + 2] = w * ((double)m.u2c - q.p[2]);
+                s_res[4 * pt + 3] = w * ((double)m.v2c - q.p[3]);
+            }
+        }
+        __syncthreads();
+        status = wave_gn_step(s_J, s_res, 12, lane, s_tr, 1e-6);
+        __syncthreads();
+        if (iter++ > 20 || status == VO_CONVERGED) break;
+    }
+    // inlier vote over all matches (getInlier, viso_stereo.cpp:232-255)
+    int count = -1;
+    if (status != VO_FAILED) {
+        double tr[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) tr[i] = s_tr[i];
+        const Rot R = make_rot(tr);
+        const double thr = c.inlier_threshold * c.inlier_threshold;
+        count = 0;
+        for (int base = 0; base < N; base += 64) {
+            const int i = base + lane;
+            bool in = false;
+            if (i < N) {
+                const svh_p_match mi = pm[i];
+                const Pred q = predict(R, tr, back_project(mi, c), c);
+                const double e0 = (double)mi.u1c - q.p[0], e1 = (double)mi.v1c - q.p[1];
+                const double e2 = (double)mi.u2c - q.p[2], e3 = (double)mi.v2c - q.p[3];
+                const double ss = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(e0, e0), __dmul_rn(e1, e1)),
+                                                      __dmul_rn(e2, e2)), __dmul_rn(e3, e3));
+                in = ss < thr;
+                hyp_flags[(size_t)k * N + i] = in ? 1 : 0;
+            }
+            count += __popcll(__ballot(in));
+        }
+    }
+    if (lane < 6) hyp_tr[6 * k + lane] = s_tr[lane];
+    if (lane == 0) hyp_count[k] = count;
+}
+
+// One workgroup of 256.  The Jacobian / residual rows of the inliers live in LDS when they fit
+// (lds_rows >= 4 * inliers; the launcher sizes the dynamic LDS from N), else in global scratch.
+__global__ __launch_bounds__(256) void k_vo_refine(const svh_p_match* __restrict__ pm, int N, int iters,
+                                                   VoCalib c, const double* __restrict__ hyp_tr,
+                                                   const int32_t* __restrict__ hyp_count,
+                                                   const uint8_t* __restrict__ hyp_flags,
+                                                   double* __restrict__ Jg, double* __restrict__ resg,
+                                                   int lds_rows, VoResult* __restrict__ out,
+                                                   int32_t* __restrict__ out_inliers) {
+    extern __shared__ double s_rows[];   // [lds_rows][6] J then [lds_rows] residuals
+    __shared__ double s_tr[6];
+    __shared__ int s_best, s_status, s_scan[256];
+    const int t = threadIdx.x;
+    if (t == 0) {
+        int best = -1, bc = 0;   // "more inliers than the current set" starting from the empty set
+        for (int k = 0; k < iters; k++)
+            if (hyp_count[k] > bc) {
+                bc = hyp_count[k];
+                best = k;
+            }
+        s_best = best;
+    }
+    __syncthreads();
+    const int best = s_best;
+    // inlier list of the winner, ascending index: ordered compaction, chunk per thread
+    int nin = 0;
+    if (best >= 0) {
+        const uint8_t* fl = hyp_flags + (size_t)best * N;
+        const int chunk = (N + 255) / 256;
+        const int lo = min(t * chunk, N), hi = min(lo + chunk, N);
+        int mine = 0;
+        for (int i = lo; i < hi; i++) mine += fl[i];
+        s_scan[t] = mine;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int add = t >= off ? s_scan[t - off] : 0;
+            __syncthreads();
+            s_scan[t] += add;
+            __syncthreads();
+        }
+        int pos = s_scan[t] - mine;
+        for (int i = lo; i < hi; i++)
+            if (fl[i]) out_inliers[pos++] = i;
+        nin = s_scan[255];
+        if (t < 6) s_tr[t] = hyp_tr[6 * best + t];
+    }
+    __syncthreads();
+    const bool in_lds = 4 * nin <= lds_rows;
+    double* J = in_lds ? s_rows : Jg;
+    double* res = in_lds ? s_rows + (size_t)6 * lds_rows : resg;
+    int success = 0;
+    if (nin >= 6) {
+        int status = VO_UPDATED, iter = 0;
+        while (status == VO_UPDATED) {
+            double tr[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) tr[i] = s_tr[i];
+            const Rot R = make_rot(tr);
+            for (int a = t; a < nin; a += 256) {
+                const svh_p_match m = pm[out_inliers[a]];
+                const Point3 P = back_project(m, c);
+                const Pred q = predict(R, tr, P, c);
+                const double w = obs_weight((double)m.u1c, c);
+#pragma unroll
+                for (int col = 0; col < 6; col++) {
+                    double j0, j1, j2;
+                    jacobian_col(R, P, q, w, c, col, &j0, &j1, &j2);
+                    J[(size_t)(4 * a + 0) * 6 + col] = j0;
+                    J[(size_t)(4 * a + 1) * 6 + col] = j1;
+                    J[(size_t)(4 * a + 2) * 6 + col] = j2;
+                    J[(size_t)(4 * a + 3) * 6 + col] = j1;
+                }
+                res[4 * a + 0] = w * ((double)m.u1c - q.p[0]);
+                res[4 * a + 1] = w * ((double)m.v1c - q.p[1]);
+                res[4 * a + 2] = w * ((double)m.u2c - q.p[2]);
+                res[4 * a + 3] = w * ((double)m.v2c - q.p[3]);
+            }
+            __syncthreads();
+            if (t < 64) {   // wave 0 forms and solves the normal equations
+                const int st = wave_gn_step(J, res, 4 * nin, t, s_tr, 1e-8);
+                if (t == 0) s_status = st;
+            }
+            __syncthreads();
+            status = s_status;
+            if (iter++ > 100 || status == VO_CONVERGED) break;
+        }
+        success = status == VO_CONVERGED;
+    }
+    if (t == 0) {
+        out->success = success;
+        out->n_inliers = nin;
+        out->best = best;
+        for (int i = 0; i < 6; i++) out->tr[i] = best >= 0 ? s_tr[i] : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_vo_upload(const uint4* __restrict__ host, uint4* __restrict__ dev,
+                                                   size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dev[i] = host[i];
+}
+
+void vlaunch_upload(void* stream, const uint8_t* pinned, uint8_t* dev, size_t bytes) {
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(k_vo_upload, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(pinned), reinterpret_cast<uint4*>(dev), n16);
+}
+
+void vlaunch_estimate(void* stream, const svh_p_match* pm, int N, const int32_t* samples, int iters,
+                      const VoCalib& c, double* hyp_tr, int32_t* hyp_count, uint8_t* hyp_flags, double* Jg,
+                      double* resg, VoResult* out, int32_t* out_inliers) {
+    hipStream_t s = (hipStream_t)stream;
+    if (iters > 0)
+        hipLaunchKernelGGL(k_vo_ransac, dim3(iters), dim3(64), 0, s, pm, N, samples, c, hyp_tr, hyp_count,
+                           hyp_flags);
+    // dynamic LDS for the refinement rows: 4 rows per match, 7 doubles per row, up to 144 KB
+    static bool attr_once = ((void)hipFuncSetAttribute((const void*)k_vo_refine,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       144 * 1024), true);
+    (void)attr_once;
+    int lds_rows = 4 * N;
+    if ((size_t)lds_rows * 7 * sizeof(double) > 144 * 1024) lds_rows = 0;
+    hipLaunchKernelGGL(k_vo_refine, dim3(1), dim3(256), (size_t)lds_rows * 7 * sizeof(double), s, pm, N, iters,
+                       c, hyp_tr, hyp_count, hyp_flags, Jg, resg, lds_rows, out, out_inliers);
+}
+
+}  // namespace svh

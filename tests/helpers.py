@@ -602,3 +602,156 @@ class ProductMatcher(MatcherBase):
     def gain(self, inliers):
         a = np.ascontiguousarray(inliers, np.int32)
         return self.lib.svh_matcher_get_gain(self.h, _p(a), len(a))
+
+# ---------------------------------------------------------------------------
+# VisualOdometryStereo drivers (reference / oracle / product share one C-ABI shape)
+# ---------------------------------------------------------------------------
+class VoParams(C.Structure):
+    """svh_vo_params (include/svh.h) == VisualOdometryStereo::parameters (viso_stereo.h:30-44)."""
+    _fields_ = [
+        ("match", MatcherParams), ("bucket_max_features", C.c_int32), ("bucket_width", C.c_double),
+        ("bucket_height", C.c_double), ("f", C.c_double), ("cu", C.c_double), ("cv", C.c_double),
+        ("base", C.c_double), ("ransac_iters", C.c_int32), ("inlier_threshold", C.c_double),
+        ("reweighting", C.c_int32),
+    ]
+
+    def copy(self, **kw):
+        q = VoParams.from_buffer_copy(bytes(self))
+        for k, v in kw.items():
+            setattr(q, k, v)
+        return q
+
+
+def vo_defaults(**kw):
+    """VisualOdometryStereo::parameters() with the calibration of libviso2/src/demo.cpp:54-58"""
+    p = VoParams()
+    p.match = matcher_defaults()
+    p.bucket_max_features, p.bucket_width, p.bucket_height = 2, 50.0, 50.0
+    p.f, p.cu, p.cv, p.base = 645.24, 635.96, 194.13, 0.5707
+    p.ransac_iters, p.inlier_threshold, p.reweighting = 200, 2.0, 1
+    return p.copy(**kw)
+
+
+class VoBase:
+    """shared driver over the three VisualOdometryStereo implementations (ref_/orc_/svh_)"""
+
+    def __init__(self, lib, prefix, params):
+        self.lib, self.px, self.params = lib, prefix, params
+        g = lambda n: getattr(lib, prefix + "vo_" + n)
+        g("create").restype = C.c_void_p
+        g("create").argtypes = [C.POINTER(VoParams)]
+        g("destroy").argtypes = [C.c_void_p]
+        g("process").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        g("process_matches").argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        g("estimate_motion").argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        g("get_motion").argtypes = [C.c_void_p, C.c_void_p]
+        g("get_inliers").argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        g("get_matches").argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        g("num_matches").argtypes = [C.c_void_p]
+        g("get_gain").restype = C.c_float
+        g("get_gain").argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        self.h = g("create")(C.byref(params))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(self.lib, self.px + "vo_destroy")(self.h)
+            self.h = None
+
+    def _f(self, name):
+        return getattr(self.lib, self.px + "vo_" + name)
+
+    def process(self, I1, I2, replace=False):
+        I1 = np.ascontiguousarray(I1, np.uint8)
+        I2 = np.ascontiguousarray(I2, np.uint8)
+        dims = (C.c_int32 * 3)(I1.shape[1], I1.shape[0], I1.shape[1])
+        return self._f("process")(self.h, _p(I1), _p(I2), dims, int(replace))
+
+    def process_matches(self, matches):
+        m = np.ascontiguousarray(matches, P_MATCH)
+        return self._f("process_matches")(self.h, _p(m), len(m))
+
+    def estimate_motion(self, matches):
+        m = np.ascontiguousarray(matches, P_MATCH)
+        tr = np.zeros(6, np.float64)
+        ok = self._f("estimate_motion")(self.h, _p(m), len(m), _p(tr))
+        return ok, tr
+
+    def motion(self):
+        T = np.zeros((4, 4), np.float64)
+        self._f("get_motion")(self.h, _p(T))
+        return T
+
+    def inliers(self):
+        n = self._f("get_inliers")(self.h, None, 0)
+        out = np.zeros(max(n, 1), np.int32)
+        self._f("get_inliers")(self.h, _p(out), n)
+        return out[:n]
+
+    def matches(self):
+        n = self._f("get_matches")(self.h, None, 0)
+        out = np.zeros(max(n, 1), P_MATCH)
+        self._f("get_matches")(self.h, _p(out), n)
+        return out[:n]
+
+    def num_matches(self):
+        return self._f("num_matches")(self.h)
+
+    def gain(self, inliers):
+        inl = np.ascontiguousarray(inliers, np.int32)
+        return float(self._f("get_gain")(self.h, _p(inl), len(inl)))
+
+
+class RefVo(VoBase):
+    def __init__(self, params):
+        lib = ref_viso()
+        lib.ref_init(1)
+        VoBase.__init__(self, lib, "ref_", params)
+
+
+class OracleVo(VoBase):
+    def __init__(self, params, tri_fn=None):
+        lib = oracle()
+        VoBase.__init__(self, lib, "orc_", params)
+        if tri_fn is None:
+            tri_fn = C.cast(ref_viso().ref_viso_triangulate, C.c_void_p)
+        self._tri = tri_fn
+        lib.orc_vo_set_triangulator.argtypes = [C.c_void_p, C.c_void_p]
+        lib.orc_vo_set_triangulator(self.h, tri_fn if isinstance(tri_fn, C.c_void_p)
+                                    else C.cast(tri_fn, C.c_void_p))
+
+
+class ProductVo(VoBase):
+    def __init__(self, params):
+        import svhip as S
+        VoBase.__init__(self, S.lib(), "svh_", params)
+
+def synth_vo_matches(n, seed=0, motion=(0.004, -0.01, 0.002, 0.03, -0.01, -0.8), outliers=0.25,
+                     noise=0.3, calib=(645.24, 635.96, 194.13, 0.5707), size=(1344, 391)):
+    """quad matches of random 3-D points seen before / after a known rigid motion (the model of
+    viso_stereo.cpp:113-131, 379-475), with pixel noise and a fraction of gross outliers"""
+    rng = np.random.default_rng(seed)
+    f, cu, cv, base = calib
+    rx, ry, rz, tx, ty, tz = motion
+    sx, cx, sy, cy, sz, cz = np.sin(rx), np.cos(rx), np.sin(ry), np.cos(ry), np.sin(rz), np.cos(rz)
+    R = np.array([[cy * cz, -cy * sz, sy],
+                  [sx * sy * cz + cx * sz, -sx * sy * sz + cx * cz, -sx * cy],
+                  [-cx * sy * cz + sx * sz, cx * sy * sz + sx * cz, cx * cy]])
+    out = np.zeros(n, P_MATCH)
+    k = 0
+    while k < n:
+        Z = rng.uniform(4, 60)
+        u1p, v1p = rng.uniform(20, size[0] - 20), rng.uniform(20, size[1] - 20)
+        X, Y = (u1p - cu) * Z / f, (v1p - cv) * Z / f
+        Xc = R @ np.array([X, Y, Z]) + np.array([tx, ty, tz])
+        if Xc[2] < 1:
+            continue
+        u1c, v1c = f * Xc[0] / Xc[2] + cu, f * Xc[1] / Xc[2] + cv
+        u2p, u2c = u1p - f * base / Z, u1c - f * base / Xc[2]
+        m = np.array([u1p, v1p, u2p, v1p, u1c, v1c, u2c, v1c]) + rng.normal(0, noise, 8)
+        if rng.uniform() < outliers:
+            m[4:] += rng.uniform(-40, 40, 4)
+        if not (0 < m[4] < size[0] and 0 < m[5] < size[1]):
+            continue
+        out[k] = (m[0], m[1], k, m[2], m[3], k, m[4], m[5], k, m[6], m[7], k)
+        k += 1
+    return out
