@@ -210,7 +210,7 @@ def main():
                     help="different synthetic pairs generated per rank; the batch tiles them")
     ap.add_argument("--lanes", type=int, default=0, help="pipeline lanes per GPU (0 = auto)")
     ap.add_argument("--group", type=int, default=0,
-                    help="pairs per kernel launch, 1..16 (0 = 6 for kitti, 4 for hd1080)")
+                    help="pairs per kernel launch, 1..16 (0 = 6 for kitti, 1 for hd1080)")
     ap.add_argument("--spinup", type=float, default=1.0,
                     help="seconds of untimed steps before the warmup (GPU clocks, lane buffers)")
     ap.add_argument("--profile-in-timed-region", type=int, default=1,
@@ -228,7 +228,7 @@ def main():
     if args.batch <= 0:
         args.batch = 768 if args.workload == "kitti" else 8
     if args.group <= 0:
-        args.group = 6 if args.workload == "kitti" else 4
+        args.group = 6 if args.workload == "kitti" else 1   # 8 pairs per step: one pair per lane
 
     import torch
     import torch.distributed as dist
