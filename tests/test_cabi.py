@@ -133,3 +133,15 @@ def test_matcher_refuses_to_run_without_a_gpu(S):
         m.push_back(I, I)
     assert ei.value.code == S.ERR_NO_DEVICE
     assert len(m.matches()) == 0
+
+
+def test_visual_odometry_refuses_to_run_without_a_gpu(S):
+    """svh_vo_* has no CPU path either: construction works, compute entries report NO_DEVICE"""
+    if S.device_count() > 0:
+        pytest.skip("a GPU is present")
+    vo = H.ProductVo(H.vo_defaults())
+    I = H.read_pgm(os.path.join(H.GOLDEN, "viso_I1p.pgm"))
+    assert vo.process(I, I) == S.ERR_NO_DEVICE
+    ok, _ = vo.estimate_motion(H.synth_vo_matches(50, seed=1))
+    assert ok == S.ERR_NO_DEVICE
+    assert np.array_equal(vo.motion(), np.eye(4)) and len(vo.inliers()) == 0
