@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri, int W,
 // ---------------------------------------------------------------------------
 struct MatchParams {
     int W, H, DW, DH, gw, gh, gwords, grid_size, sub;
-    int disp_max, match_texture, plane_radius;
+    int disp_max, match_texture, plane_radius, npairs;
     uint32_t grid_magic;   // floor(2^32 / grid_size) + 1: u / grid_size == mulhi(u, magic), u < 2^16
 };
 
@@ -822,9 +822,17 @@ __device__ __forceinline__ float match_pixel_keyed(const uint4& own, const float
 __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P) {
     extern __shared__ uint4 s_row[];
     __shared__ int s_P[64];
-    const int z = blockIdx.z, pair = z >> 1, side = z & 1;
+    // XCD-aware block order: the left-map and the right-map block of one image row read the
+    // same two descriptor rows (own / other swapped).  Workgroups go to the 8 XCDs round-robin
+    // by linear id, so ids k and k+8 of every group of 16 are the two sides of row q*8+k: the
+    // second one finds both rows in that XCD's L2 instead of fetching them from HBM again.
+    const int bid = blockIdx.x;
+    const int row_id = (bid >> 4) * 8 + (bid & 7);   // (pair, image row)
+    const int side = (bid >> 3) & 1;
+    if (row_id >= P.DH * P.npairs) return;
+    const int pair = row_id / P.DH, y = row_id - pair * P.DH;
+    const int z = 2 * pair + side;
     if (!G.hdr->active[pair]) return;
-    const int y = blockIdx.y;
     if (threadIdx.x < 64) s_P[threadIdx.x] = (int)threadIdx.x <= P.disp_max ? G.P[threadIdx.x] : 0;
     const size_t N = (size_t)P.W * P.H;
     const int mul = P.sub ? 2 : 1;
@@ -1635,6 +1643,7 @@ void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     P.grid_size = p.grid_size; P.sub = p.subsampling; P.disp_max = p.disp_max;
     P.match_texture = p.match_texture; P.plane_radius = G.plane_radius;
     P.grid_magic = (uint32_t)(0x100000000ull / (uint64_t)p.grid_size) + 1u;
+    P.npairs = g;
     const size_t lds = (size_t)d.W * sizeof(uint4);
     // the keyed kernel packs cost and scan rank into one int32 (see k_match_keyed)
     static const bool ordered = getenv("SVH_MATCH_ORDERED") != nullptr;
@@ -1647,7 +1656,7 @@ void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
         const int iters = (d.DW + mt - 1) / mt;
         const int threads = std::min(512, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
         if (keyed_ok)
-            hipLaunchKernelGGL(k_match_keyed, dim3(1, d.DH, 2 * g), dim3(threads), lds,
+            hipLaunchKernelGGL(k_match_keyed, dim3((unsigned)(((d.DH * g + 7) / 8) * 16)), dim3(threads), lds,
                                (hipStream_t)cx.stream, G, P);
         else
             hipLaunchKernelGGL(k_match<true>, dim3(1, d.DH, 2 * g), dim3(threads), lds,
