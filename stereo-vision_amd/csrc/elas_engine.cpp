@@ -120,6 +120,8 @@ struct Lane {
     EventProfiler prof;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t wait_ev = nullptr;   // completion marker polled by lane_wait
+    bool poll_wait = false;         // batch workers sleep-poll; single calls spin (lowest latency)
     // geometry the buffers were sized for
     int32_t W = 0, H = 0, disp_max = -1, step = 0, grid_size = 0, sub = -1, gcap = 0;
     Dims d{};
@@ -209,6 +211,28 @@ struct Lane {
     }
 };
 
+// Wait for everything enqueued on the lane's stream.  A single svh_elas_process call spins in
+// hipStreamSynchronize (lowest latency).  Batch workers must NOT spin: a batch keeps as many
+// workers as cores busy, containers often cap the CPU time of the whole process, and the
+// Delaunay / lattice-filter work of the other workers needs those cycles (measured on the
+// 16-core-quota MI355X box: same throughput at 10 instead of 16 cores).  They poll a completion
+// event and sleep in between (SVH_WAIT_US, default 40; 0 = spin).
+static int g_wait_us = getenv("SVH_WAIT_US") ? atoi(getenv("SVH_WAIT_US")) : 40;
+static hipError_t lane_wait(Lane& L) {
+    if (!L.poll_wait || g_wait_us <= 0) return hipStreamSynchronize(L.stream);
+    if (!L.wait_ev) {
+        hipError_t e = hipEventCreateWithFlags(&L.wait_ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipEventRecord(L.wait_ev, L.stream);
+    if (e != hipSuccess) return e;
+    for (;;) {
+        e = hipEventQuery(L.wait_ev);
+        if (e != hipErrorNotReady) return e;
+        std::this_thread::sleep_for(std::chrono::microseconds(g_wait_us));
+    }
+}
+
 // ---------------------------------------------------------------------------
 // per-device lane pool
 // ---------------------------------------------------------------------------
@@ -235,24 +259,37 @@ static Pool* pool_for(int device) {
     return p;
 }
 
-static Lane* acquire_lane(int device) {
+// takes `count` (1 or 2) lanes at once -- all or nothing, so two callers can never hold one
+// lane each while waiting for a second.  A batch worker is double-buffered (2 lanes), hence
+// the pool may grow to twice the configured number of workers.
+static void acquire_lanes(int device, int count, Lane** out) {
     Pool* p = pool_for(device);
     std::unique_lock<std::mutex> lk(p->mu);
-    p->max_lanes = g_lanes.load();
+    p->max_lanes = 2 * g_lanes.load();
     for (;;) {
-        if (!p->free_list.empty()) {
-            Lane* l = p->free_list.back();
-            p->free_list.pop_back();
-            return l;
-        }
-        if ((int)p->lanes.size() < p->max_lanes) {
-            Lane* l = new Lane();
-            l->device = device;
-            p->lanes.push_back(l);
-            return l;
+        const int can_make = p->max_lanes - (int)p->lanes.size();
+        if ((int)p->free_list.size() + std::max(can_make, 0) >= count) {
+            for (int i = 0; i < count; i++) {
+                if (!p->free_list.empty()) {
+                    out[i] = p->free_list.back();
+                    p->free_list.pop_back();
+                } else {
+                    Lane* l = new Lane();
+                    l->device = device;
+                    p->lanes.push_back(l);
+                    out[i] = l;
+                }
+            }
+            return;
         }
         p->cv.wait(lk);
     }
+}
+
+static Lane* acquire_lane(int device) {
+    Lane* l = nullptr;
+    acquire_lanes(device, 1, &l);
+    return l;
 }
 
 static void release_lane(Lane* l) {
@@ -261,7 +298,7 @@ static void release_lane(Lane* l) {
         std::lock_guard<std::mutex> lk(p->mu);
         p->free_list.push_back(l);
     }
-    p->cv.notify_one();
+    p->cv.notify_all();
 }
 
 // ---------------------------------------------------------------------------
@@ -324,8 +361,15 @@ static void tap_host(Taps* taps, int stage, const T* src, size_t count) {
 }
 
 // one group of pairs through one lane; status[j] per pair
+// A group runs in three steps that may be issued separately (the batch workers overlap the
+// host step of one group with the device steps of the next, see batch_impl):
+//   RG_A       enqueue descriptor + support matching + the candidate download
+//   RG_HOST_B  wait for A, lattice filters + Delaunay on the host, enqueue everything else
+//   RG_FINISH  wait for the stream, collect errors and kernel timings
+enum { RG_A = 1, RG_HOST_B = 2, RG_FINISH = 4, RG_ALL = 7 };
+
 static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, const GroupIO& io,
-                     int32_t* status, Taps* taps, svh_elas* timing) {
+                     int32_t* status, Taps* taps, svh_elas* timing, int mode = RG_ALL) {
     const int32_t W = dims[0], H = dims[1], g = io.g;
     int rc = check_params(p, W, H);
     if (rc) return rc;
@@ -341,8 +385,15 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     const size_t N = (size_t)W * H, DN = (size_t)d.DW * d.DH;
     const size_t nc = (size_t)d.Wc * d.Hc;
     double t0 = now_ms();
+    if (mode == RG_FINISH) {
+        HIP_TRY(lane_wait(L));
+        HIP_TRY(hipGetLastError());
+        L.prof.collect();
+        return SVH_OK;
+    }
 
     // ---- phase A ---------------------------------------------------------
+    if (mode & RG_A) {
     DevImages img;
     if (io.in_device) {
         img.I[0] = io.dI[0]; img.I[1] = io.dI[1];
@@ -365,7 +416,9 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     launch_descriptor(cx, img, g, W, H, p.subsampling, L.desc);
     launch_support(cx, p, d, g, L.desc, L.dcan);
     HIP_TRY(hipMemcpyAsync(L.h_dcan, L.dcan, g * nc * sizeof(int16_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (!(mode & RG_HOST_B)) return SVH_OK;
+    HIP_TRY(lane_wait(L));
     HIP_TRY(hipGetLastError());
     L.prof.collect();
     double t1 = now_ms();
@@ -466,7 +519,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         const size_t words = (size_t)d.gw * d.gh * d.gwords;
         std::vector<uint32_t> m(2 * words);
         HIP_TRY(hipMemcpyAsync(m.data(), L.mask, m.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(lane_wait(L));
         for (int k = 0; k < 2; k++) {
             std::vector<int32_t> gr;
             expand_grid(p, d, m.data() + k * words, gr);
@@ -528,7 +581,8 @@ copy_out:
                 HIP_TRY(hipMemcpyAsync(io.hD[k][j], L.D + ((size_t)2 * j + k) * DN, DN * sizeof(float),
                                        hipMemcpyDeviceToHost, s));
         }
-    HIP_TRY(hipStreamSynchronize(s));
+    if (!(mode & RG_FINISH)) return SVH_OK;
+    HIP_TRY(lane_wait(L));
     HIP_TRY(hipGetLastError());
     L.prof.collect();
     double t3 = now_ms();
@@ -705,24 +759,80 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
     const int32_t G = std::max(1, std::min(g_group.load(), kMaxGroup));
     const int32_t ngroups = (n + G - 1) / G;
     const int lanes = std::min<int>(g_lanes.load(), ngroups);
-    std::atomic<int32_t> next{0};
     std::vector<int32_t> st(n, SVH_OK);
     std::vector<int32_t> grc(ngroups, SVH_OK);
     std::vector<std::string> errs(std::max(lanes, 1));
+    // Each worker owns TWO lanes (stream + buffers) and software-pipelines its groups: while it
+    // filters and triangulates group i on the host, the device already runs descriptor + support
+    // matching of group i+1 on the other lane, and the tail kernels of group i-1 behind that.
     auto worker = [&](int w) {
-        Lane* L = acquire_lane(e->device);
-        // size the lane's buffers before taking work: allocation synchronises the
+        Lane* slot[2] = {nullptr, nullptr};
+        acquire_lanes(e->device, ngroups > 1 ? 2 : 1, slot);
+        // size the lanes' buffers before taking work: allocation synchronises the
         // device and must not land in the middle of other lanes' launches later
-        if (hipSetDevice(L->device) == hipSuccess) (void)L->ensure(e->p, dims[0], dims[1], G);
-        for (;;) {
-            int32_t gi = next.fetch_add(1);
-            if (gi >= ngroups) break;
-            const int32_t first = gi * G, cnt = std::min(G, n - first);
-            GroupIO io = io_of(first, cnt);
-            grc[gi] = run_group(*L, e->p, dims, io, &st[first], nullptr, nullptr);
-            if (grc[gi] < 0) errs[w] = t_error;
+        for (Lane* L : slot)
+            if (L) {
+                L->poll_wait = true;
+                if (hipSetDevice(L->device) == hipSuccess) (void)L->ensure(e->p, dims[0], dims[1], G);
+            }
+        struct Job { int32_t gi = -1; GroupIO io{}; int32_t first = 0; };
+        // static round-robin shares (groups cost the same): a worker that prefetches its next
+        // group never takes one away from a worker that has nothing to do yet
+        int32_t my_next = w;
+        auto take = [&]() {
+            Job j;
+            const int32_t gi = my_next;
+            my_next += lanes;
+            if (gi < ngroups) {
+                j.gi = gi;
+                j.first = gi * G;
+                j.io = io_of(j.first, std::min(G, n - j.first));
+            }
+            return j;
+        };
+        auto note = [&](const Job& j, int rcj) {
+            if (rcj != SVH_OK && grc[j.gi] == SVH_OK) {
+                grc[j.gi] = rcj;
+                if (rcj < 0) errs[w] = t_error;
+            }
+        };
+        Job pending[2];   // group whose tail is still on slot k's stream
+        Job cur = take();
+        int k = 0;
+        if (cur.gi >= 0) note(cur, run_group(*slot[0], e->p, dims, cur.io, &st[cur.first], nullptr, nullptr, RG_A));
+        while (cur.gi >= 0) {
+            Job nxt = slot[1] ? take() : Job();
+            if (nxt.gi >= 0) {
+                const int o = 1 - k;
+                if (pending[o].gi >= 0) {
+                    note(pending[o], run_group(*slot[o], e->p, dims, pending[o].io, &st[pending[o].first], nullptr,
+                                               nullptr, RG_FINISH));
+                    pending[o].gi = -1;
+                }
+                note(nxt, run_group(*slot[o], e->p, dims, nxt.io, &st[nxt.first], nullptr, nullptr, RG_A));
+            }
+            if (grc[cur.gi] == SVH_OK)
+                note(cur, run_group(*slot[k], e->p, dims, cur.io, &st[cur.first], nullptr, nullptr, RG_HOST_B));
+            pending[k] = cur;
+            if (!slot[1]) {   // single lane: finish right away and take the next group on it
+                note(cur, run_group(*slot[0], e->p, dims, cur.io, &st[cur.first], nullptr, nullptr, RG_FINISH));
+                pending[0].gi = -1;
+                nxt = take();
+                if (nxt.gi >= 0)
+                    note(nxt, run_group(*slot[0], e->p, dims, nxt.io, &st[nxt.first], nullptr, nullptr, RG_A));
+            } else {
+                k = 1 - k;
+            }
+            cur = nxt;
         }
-        release_lane(L);
+        for (int q = 0; q < 2; q++)
+            if (slot[q]) {
+                if (pending[q].gi >= 0)
+                    note(pending[q], run_group(*slot[q], e->p, dims, pending[q].io, &st[pending[q].first], nullptr,
+                                               nullptr, RG_FINISH));
+                slot[q]->poll_wait = false;
+                release_lane(slot[q]);
+            }
     };
     if (lanes <= 1) {
         worker(0);
