@@ -398,6 +398,19 @@ def main():
             roofline["end_to_end"] = {"alg_bytes_per_pair": ALG_BYTES_PER_PIXEL_PAIR * N_PIX,
                                       "achieved": e2e, "frac": e2e / HBM_PEAK_GBS,
                                       "note": "this rank's pairs; staged model 174.8 B/pixel"}
+            # measured HBM traffic of the whole pipeline (sum over the kernels of the PMC passes)
+            try:
+                import glob
+                pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))
+                twice = ("k_adaptive_mean", "k_gap_local", "k_owner")   # two launches per group share a symbol
+                per_pair = sum(v["hbm_bytes"] * (2 if k in twice else 1)
+                               for k, v in pmc["kernels"].items()) / pmc["pairs_per_launch"]
+                if args.workload != "hd1080":
+                    mt = per_pair * B * args.steps / elapsed / 1e9
+                    roofline["end_to_end"].update(measured_hbm_bytes_per_pair=per_pair, measured_achieved=mt,
+                                                  measured_frac=mt / HBM_PEAK_GBS)
+            except (OSError, IndexError, KeyError, ValueError):
+                pass
             # the box's own copy bandwidth (device-to-device, read + write counted)
             src = torch.empty(1 << 29, dtype=torch.uint8, device=dev)
             dst = torch.empty_like(src)

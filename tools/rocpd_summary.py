@@ -21,11 +21,24 @@ def main(path):
         import re as _re; m = _re.search(r"(k_\w+)(<[^>]*>)?", name); short = (m.group(0) if m else name)[:58]
         print("%-58s %7d %11.1f %9.2f %9.2f %9.2f %6.2f %5s %5s %6s %9s" % (
             short, n, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total, vg, sg, lds, grid))
+    # fraction of the span during which at least one kernel was running (sweep over intervals)
+    iv = db.execute("select start, end from kernels order by start").fetchall()
+    busy, cur_s, cur_e = 0, None, None
+    for s, e in iv:
+        if cur_e is None or s > cur_e:
+            if cur_e is not None:
+                busy += cur_e - cur_s
+            cur_s, cur_e = s, e
+        elif e > cur_e:
+            cur_e = e
+    if cur_e is not None:
+        busy += cur_e - cur_s
     span = db.execute("select min(start), max(end) from kernels").fetchone()
     if span and span[0] is not None:
         print("\nkernel time %.3f ms over a %.3f ms span (sum/span = %.2f: >1 means kernels from "
-              "different lanes overlap)" % (total / 1e6, (span[1] - span[0]) / 1e6,
-                                            total / max(span[1] - span[0], 1)))
+              "different lanes overlap); some kernel running during %.1f %% of the span"
+              % (total / 1e6, (span[1] - span[0]) / 1e6, total / max(span[1] - span[0], 1),
+                 100.0 * busy / max(span[1] - span[0], 1)))
 
 
 if __name__ == "__main__":
