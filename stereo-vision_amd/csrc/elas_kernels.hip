@@ -820,18 +820,14 @@ __device__ __forceinline__ float match_pixel_keyed(const uint4& own, const float
 }
 
 __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P) {
-    extern __shared__ uint4 s_row[];
+    // One block = one image row of one pair, BOTH disparity maps: the left-map pass compares
+    // L[row] with R[row], the right-map pass R[row] with L[row], so the two descriptor rows
+    // (2 x 19.9 KB at W = 1242) are staged in LDS once and serve as "own" and "other" row of
+    // both passes; the first half of the block matches the left map, the second half the right.
+    extern __shared__ uint4 s_rows[];   // [2][W]: row of image 1, row of image 2
     __shared__ int s_P[64];
-    // XCD-aware block order: the left-map and the right-map block of one image row read the
-    // same two descriptor rows (own / other swapped).  Workgroups go to the 8 XCDs round-robin
-    // by linear id, so ids k and k+8 of every group of 16 are the two sides of row q*8+k: the
-    // second one finds both rows in that XCD's L2 instead of fetching them from HBM again.
-    const int bid = blockIdx.x;
-    const int row_id = (bid >> 4) * 8 + (bid & 7);   // (pair, image row)
-    const int side = (bid >> 3) & 1;
-    if (row_id >= P.DH * P.npairs) return;
+    const int row_id = blockIdx.x;      // (pair, image row)
     const int pair = row_id / P.DH, y = row_id - pair * P.DH;
-    const int z = 2 * pair + side;
     if (!G.hdr->active[pair]) return;
     if (threadIdx.x < 64) s_P[threadIdx.x] = (int)threadIdx.x <= P.disp_max ? G.P[threadIdx.x] : 0;
     const size_t N = (size_t)P.W * P.H;
@@ -839,19 +835,25 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P) 
     const int v = y * mul;
     int line = v < P.H - 3 ? v : P.H - 3;
     line = line > 2 ? line : 2;
-    const uint4* oth_line =
-        reinterpret_cast<const uint4*>(G.desc + (size_t)(z ^ 1) * N * 16) + (size_t)line * P.W;
-    const uint4* own_line =
-        reinterpret_cast<const uint4*>(G.desc + (size_t)z * N * 16) + (size_t)line * P.W;
-    for (int i = threadIdx.x; i < P.W; i += blockDim.x) s_row[i] = oth_line[i];
+    {
+        const uint4* l1 = reinterpret_cast<const uint4*>(G.desc + (size_t)(2 * pair) * N * 16) + (size_t)line * P.W;
+        const uint4* l2 = l1 + N;
+        for (int i = threadIdx.x; i < 2 * P.W; i += blockDim.x)
+            s_rows[i] = i < P.W ? l1[i] : l2[i - P.W];
+    }
     __syncthreads();
+    const int half = blockDim.x >> 1;
+    const int side = (int)threadIdx.x >= half;        // wave-uniform: half is a multiple of 64
+    const int z = 2 * pair + side;
+    const uint4* own_row = s_rows + side * P.W;
+    const uint4* oth_row = s_rows + (1 - side) * P.W;
     const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
     const int sgn = side ? 1 : -1;
     const int32_t* own_t = G.owner + (size_t)z * N + (size_t)v * P.W;
     const uint32_t* row_bits =
         G.mask + ((size_t)z * P.gw * P.gh + (size_t)(v / P.grid_size) * P.gw) * P.gwords;
     float* out_row = G.Draw + (size_t)z * P.DW * P.DH + (size_t)y * P.DW;
-    for (int x = threadIdx.x; x < P.DW; x += blockDim.x) {
+    for (int x = (int)threadIdx.x - side * half; x < P.DW; x += half) {
         const int u = x * mul;
         float out = -10.f;
         const int t = own_t[u];
@@ -860,13 +862,13 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P) 
         const bool inner = side ? u + P.disp_max < P.W - 2 : u - P.disp_max >= 2;
         const bool wave_inner = __builtin_amdgcn_ballot_w64(live && !inner) == 0;
         if (live) {
-            const uint4 own = own_line[u];
+            const uint4 own = own_row[u];
             if ((int)texture16(own) >= P.match_texture) {
                 const float4 pl = *reinterpret_cast<const float4*>(G.raster + tri0 + t);
                 const uint32_t* bits = row_bits + (size_t)__umulhi((uint32_t)u, P.grid_magic) * P.gwords;
                 out = wave_inner
-                          ? match_pixel_keyed<false>(own, pl, u, v, sgn, s_row, bits, s_P, G.P, P)
-                          : match_pixel_keyed<true>(own, pl, u, v, sgn, s_row, bits, s_P, G.P, P);
+                          ? match_pixel_keyed<false>(own, pl, u, v, sgn, oth_row, bits, s_P, G.P, P)
+                          : match_pixel_keyed<true>(own, pl, u, v, sgn, oth_row, bits, s_P, G.P, P);
             }
         }
         out_row[x] = out;
@@ -1649,18 +1651,21 @@ void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     static const bool ordered = getenv("SVH_MATCH_ORDERED") != nullptr;
     const bool keyed_ok = !ordered && G.prior_absmax < (1 << 19) && p.disp_max < 512 &&
                           G.plane_radius <= 15 && d.W < 65536 && p.grid_size > 1;
-    if (lds <= 64 * 1024) {
+    if (keyed_ok && 2 * lds <= 64 * 1024) {
         Timed timed_(cx, "k_match");
-        // threads per row block: the row is covered in `iters` equal passes with little idle tail
+        // threads per map and row block: the row is covered in `iters` equal passes with little idle tail
+        static const int mt = getenv("SVH_MATCH_THREADS") ? atoi(getenv("SVH_MATCH_THREADS")) : 256;
+        const int iters = (d.DW + mt - 1) / mt;
+        const int half = std::min(256, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
+        hipLaunchKernelGGL(k_match_keyed, dim3((unsigned)(d.DH * g)), dim3(2 * half), 2 * lds,
+                           (hipStream_t)cx.stream, G, P);
+    } else if (lds <= 64 * 1024) {
+        Timed timed_(cx, "k_match");
         static const int mt = getenv("SVH_MATCH_THREADS") ? atoi(getenv("SVH_MATCH_THREADS")) : 256;
         const int iters = (d.DW + mt - 1) / mt;
         const int threads = std::min(512, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
-        if (keyed_ok)
-            hipLaunchKernelGGL(k_match_keyed, dim3((unsigned)(((d.DH * g + 7) / 8) * 16)), dim3(threads), lds,
-                               (hipStream_t)cx.stream, G, P);
-        else
-            hipLaunchKernelGGL(k_match<true>, dim3(1, d.DH, 2 * g), dim3(threads), lds,
-                               (hipStream_t)cx.stream, G, P);
+        hipLaunchKernelGGL(k_match<true>, dim3(1, d.DH, 2 * g), dim3(threads), lds,
+                           (hipStream_t)cx.stream, G, P);
     } else {
         LAUNCH("k_match", k_match<false>, grid2d(d.DW, d.DH, 2 * g), dim3(64, 4), G, P);
     }
