@@ -676,9 +676,12 @@ static inline bool am_filter(const float* ring, int taps, float centre, float* o
 void orc_adaptive_mean(const svh_elas_params* p, float* D, int32_t dw, int32_t dh) {
     const size_t n = (size_t)dw * dh;
     std::vector<float> copy(D, D + n);
-    // D_tmp is malloc'ed and only partly written by the reference (elas.cpp:1548);
-    // the never-written part is defined here as the input value.
-    std::vector<float> tmp(D, D + n);
+    // D_tmp is malloc'ed, set to -10 where D is invalid and otherwise only written by the
+    // horizontal pass (elas.cpp:1548-1560, 1683-1701).  It is a fresh multi-MB block (zero
+    // pages) and the pinned reference (oracle/_ref, ref_init(1)) zero-fills its allocations, so
+    // the never-written valid pixels -- the 3 border rows / columns, reachable only with
+    // add_corners -- read as 0 in the vertical pass.
+    std::vector<float> tmp(n, 0.0f);
     for (size_t i = 0; i < n; i++)
         if (D[i] < 0) {
             copy[i] = -10;

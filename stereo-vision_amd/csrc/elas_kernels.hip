@@ -1293,7 +1293,12 @@ __global__ __launch_bounds__(256) void k_adaptive_mean(GroupDev G, DevMaps m, Po
     const int pos = kCols ? y : x, len = kCols ? DH : DW;
     const int other = kCols ? x : y, olen = kCols ? DW : DH;
     float res = D[i];
-    if (!kCols && res < 0) res = -10.f;  // D_copy/D_tmp initialisation (elas.cpp:1553-1560)
+    // D_tmp (elas.cpp:1548-1560) is malloc'ed, set to -10 where D is invalid and otherwise left
+    // UNINITIALISED until the horizontal pass writes it.  Both allocations are fresh multi-MB
+    // blocks (zero pages), and the pinned reference runs with zero-filled allocations: a valid
+    // pixel the horizontal pass does not write reads back as 0 in the vertical pass.  That only
+    // matters when valid pixels reach the 3 border rows/columns (add_corners).
+    if (!kCols) res = res < 0 ? -10.f : 0.f;
     // lines 3..olen-4; centres lead-back .. len-1-back
     if (other >= 3 && other < olen - 3 && pos >= lead - back && pos <= len - 1 - back) {
         const int first = pos + back - lead;  // oldest tap position

@@ -755,3 +755,33 @@ def synth_vo_matches(n, seed=0, motion=(0.004, -0.01, 0.002, 0.03, -0.01, -0.8),
         out[k] = (m[0], m[1], k, m[2], m[3], k, m[4], m[5], k, m[6], m[7], k)
         k += 1
     return out
+
+def fuzz_elas_params(seed):
+    """a seeded random point of Elas::parameters inside the ranges the reference handles
+    (elas.h:59-148): every field moves, both filters / corner points / subsampling toggle"""
+    rng = np.random.default_rng(seed)
+    base = robotics() if rng.uniform() < 0.5 else middlebury()
+    return base.copy(
+        disp_max=int(rng.integers(24, 200)),
+        support_threshold=float(rng.uniform(0.7, 0.98)),
+        support_texture=int(rng.integers(0, 40)),
+        candidate_stepsize=int(rng.integers(3, 8)),
+        incon_window_size=int(rng.integers(3, 8)),
+        incon_threshold=int(rng.integers(2, 8)),
+        incon_min_support=int(rng.integers(2, 8)),
+        add_corners=int(rng.integers(0, 2)),
+        grid_size=int(rng.integers(10, 32)),
+        beta=float(rng.uniform(0.01, 0.05)),
+        gamma=float(rng.uniform(1.0, 8.0)),
+        sigma=float(rng.uniform(0.6, 2.0)),
+        sradius=float(rng.uniform(1.5, 3.5)),
+        match_texture=int(rng.integers(0, 4)),
+        lr_threshold=int(rng.integers(1, 4)),
+        speckle_sim_threshold=float(rng.uniform(0.5, 2.5)),
+        speckle_size=int(rng.integers(20, 400)),
+        ipol_gap_width=int(rng.integers(2, 12)),
+        filter_median=int(rng.integers(0, 2)),
+        filter_adaptive_mean=int(rng.integers(0, 2)),
+        postprocess_only_left=int(rng.integers(0, 2)),
+        subsampling=int(rng.uniform() < 0.25),
+    )

@@ -261,3 +261,17 @@ def test_streamed_sequence_of_430_frames(svhip):
             assert np.array_equal(D1[i], g1) and np.array_equal(D2[i], g2), i
         else:
             assert np.array_equal(D1[i], A1) and np.array_equal(D2[i], A2), i
+
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
+@pytest.mark.parametrize("seed", range(40, 56))
+def test_param_fuzz_matches_oracle(seed, svhip, oracle_lib):
+    """random points of Elas::parameters (every field moves, see helpers.fuzz_elas_params):
+    all stages and the final maps bit-exact against the oracle"""
+    prm = H.fuzz_elas_params(seed)
+    w, h = [(320, 200), (401, 177), (512, 160), (288, 240)][seed % 4]
+    l, r = H.synth_pair(w, h, seed, dmax=min(48, prm.disp_max - 8))
+    got = product_run(svhip, prm, l, r)
+    want = H.oracle_elas_run(prm, l, r)
+    assert got.status == want.status
+    if got.status == 0:
+        assert_same(want, got)

@@ -103,3 +103,22 @@ def test_too_few_support_points(oracle_lib, capsys):
                                      H.dims_of(I), C.cast(cb, C.c_void_p))
     assert st == 1
     assert np.all(D1 == -7.0) and np.all(D2 == -7.0)
+
+FUZZ_SHAPES = [(320, 200), (401, 177), (512, 160), (288, 240)]
+
+
+@pytest.mark.skipif(not H.have_ref_elas(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed", range(40, 60))
+def test_oracle_matches_reference_param_fuzz(seed, oracle_lib):
+    """every field of Elas::parameters moves (helpers.fuzz_elas_params): both presets as the
+    base, median / adaptive mean / corner points / subsampling in every combination.  Found the
+    one place where the reference reads uninitialised memory with an effect (D_tmp border rows
+    under add_corners + adaptive mean, see orc_adaptive_mean)."""
+    prm = H.fuzz_elas_params(seed)
+    w, h = FUZZ_SHAPES[seed % 4]
+    l, r = H.synth_pair(w, h, seed, dmax=min(48, prm.disp_max - 8))
+    a = H.ref_elas_run(prm, l, r)
+    b = H.oracle_elas_run(prm, l, r)
+    assert a.status == b.status
+    bad = [(n, c) for n, c in H.compare_runs(a, b) if c != 0]
+    assert not bad, bad
