@@ -785,3 +785,24 @@ def fuzz_elas_params(seed):
         postprocess_only_left=int(rng.integers(0, 2)),
         subsampling=int(rng.uniform() < 0.25),
     )
+
+def fuzz_matcher_case(seed):
+    """a seeded random point of Matcher::parameters (matcher.h:41-69), a matching method, a crop of
+    the quad (ragged widths) and optionally a predicted motion + intrinsics"""
+    rng = np.random.default_rng(seed)
+    prm = matcher_defaults(
+        nms_n=int(rng.integers(2, 7)), nms_tau=int(rng.integers(20, 90)),
+        match_binsize=int(rng.integers(25, 90)), match_radius=int(rng.integers(60, 260)),
+        match_disp_tolerance=int(rng.integers(1, 4)), outlier_disp_tolerance=int(rng.integers(2, 9)),
+        outlier_flow_tolerance=int(rng.integers(2, 9)), multi_stage=int(rng.integers(0, 2)),
+        half_resolution=int(rng.integers(0, 2)), refinement=int(rng.integers(0, 3)))
+    method = int(rng.integers(0, 3))
+    x0, y0 = int(rng.integers(0, 200)), int(rng.integers(0, 40))
+    w, h = int(rng.integers(600, 1100)), int(rng.integers(220, 340))
+    tr = None
+    if method == 2 and rng.uniform() < 0.5:
+        prm = prm.copy(f=645.24, cu=635.96 - x0, cv=194.13 - y0, base=0.5707)
+        tr = np.eye(4)
+        tr[:3, 3] = rng.uniform(-0.05, 0.05, 3)
+        tr[2, 3] -= 0.7
+    return prm, method, (slice(y0, y0 + h), slice(x0, x0 + w)), tr

@@ -142,3 +142,18 @@ def test_cxx_dropin_visual_odometry_call_sequence(predict, tmp_path, oracle_lib)
     g = a.gain(np.arange(0, nb, 3))
     assert "matches %d" % nb in txt
     assert "gain %.6f" % g in txt
+
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_param_fuzz_matches_oracle(seed, oracle_lib):
+    """random points of Matcher::parameters x method x crop x predicted motion
+    (helpers.fuzz_matcher_case): tables, every stage and the match indices bit-exact"""
+    if not H.have_ref_viso():
+        pytest.skip("oracle needs the real Triangle (oracle/_ref) for removeOutliers")
+    prm, method, crop, tr = H.fuzz_matcher_case(seed)
+    im = {k: v[crop] for k, v in quad().items()}
+    a, b = H.OracleMatcher(prm), H.ProductMatcher(prm)
+    for m in (a, b):
+        push_quad(m, im)
+        assert m.match(method, tr) == 0
+    bad = [x for x in H.compare_matchers(a, b, method) if x[1] != 0]
+    assert not bad, bad

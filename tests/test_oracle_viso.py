@@ -105,3 +105,19 @@ def test_ring_buffer_bucketing_and_gain(oracle_lib):
     assert a.n_bucket == b.n_bucket and len(a.after) == a.n_bucket
     assert (a.after == b.after).all()
     assert a.g == b.g
+
+@pytest.mark.skipif(not H.have_ref_viso(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_oracle_matches_reference_param_fuzz(seed, oracle_lib):
+    """every field of Matcher::parameters moves, all three methods, random ragged crops of the
+    quad, optional predicted motion (helpers.fuzz_matcher_case)"""
+    prm, method, crop, tr = H.fuzz_matcher_case(seed)
+    im = {k: v[crop] for k, v in quad().items()}
+    a, b = H.RefMatcher(prm), H.OracleMatcher(prm)
+    for m in (a, b):
+        m.push_back(im["I1p"], im["I2p"])
+        m.push_back(im["I1c"], im["I2c"])
+    a.match(method, tr)
+    assert b.match(method, tr) == 0
+    bad = [x for x in H.compare_matchers(a, b, method) if x[1] != 0]
+    assert not bad, bad
