@@ -806,3 +806,19 @@ def fuzz_matcher_case(seed):
         tr[:3, 3] = rng.uniform(-0.05, 0.05, 3)
         tr[2, 3] -= 0.7
     return prm, method, (slice(y0, y0 + h), slice(x0, x0 + w)), tr
+
+def fuzz_vo_params(seed):
+    """a seeded random point of VisualOdometryStereo::parameters (viso_stereo.h:30-44, viso.h:30-66)"""
+    rng = np.random.default_rng(seed)
+    p = vo_defaults(
+        bucket_max_features=int(rng.integers(1, 6)), bucket_width=float(rng.integers(30, 90)),
+        bucket_height=float(rng.integers(30, 90)), ransac_iters=int(rng.integers(20, 260)),
+        inlier_threshold=float(rng.uniform(1.0, 3.0)), reweighting=int(rng.integers(0, 2)))
+    m = p.match
+    m.nms_n = int(rng.integers(2, 5))
+    m.match_binsize = int(rng.integers(30, 70))
+    m.refinement = int(rng.integers(0, 3))
+    m.half_resolution = int(rng.integers(0, 2))
+    m.outlier_flow_tolerance = int(rng.integers(3, 8))
+    p.match = m
+    return p

@@ -72,3 +72,15 @@ def test_estimate_motion_matches_reference(n, seed, kw, oracle_lib):
     if ra[0]:
         assert np.array_equal(ra[1], rb[1])
     assert np.array_equal(ia, b.inliers())
+
+@pytest.mark.skipif(not H.have_ref_viso(), reason="needs the reference in oracle/_ref")
+@pytest.mark.parametrize("seed", range(200, 208))
+def test_oracle_matches_reference_param_fuzz(seed, oracle_lib):
+    prm = H.fuzz_vo_params(seed)
+    a = run(H.RefVo(prm), quad())
+    b = run(H.OracleVo(prm), quad())
+    assert a[0] == b[0]
+    assert a[1].tobytes() == b[1].tobytes()
+    assert np.array_equal(a[2], b[2])
+    assert np.array_equal(a[3], b[3])
+    assert a[4] == b[4]

@@ -114,3 +114,16 @@ def test_no_matches_and_bad_arguments():
     assert ok == 0 and len(vo.inliers()) == 0
     assert np.array_equal(vo.motion(), np.eye(4))
     assert vo.lib.svh_vo_estimate_motion(vo.h, None, 10, None) < 0
+
+@pytest.mark.parametrize("seed", range(200, 208))
+def test_param_fuzz_matches_oracle(seed, oracle_lib):
+    if not H.have_ref_viso():
+        pytest.skip("oracle needs the real Triangle (oracle/_ref) for removeOutliers")
+    prm = H.fuzz_vo_params(seed)
+    a = run(H.OracleVo(prm), quad())
+    b = run(H.ProductVo(prm), quad())
+    assert a[0] == b[0]
+    assert a[1].tobytes() == b[1].tobytes()
+    assert np.array_equal(a[2], b[2])
+    assert np.abs(a[3] - b[3]).max() < TOL
+    assert a[4] == b[4]
