@@ -527,11 +527,6 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         }
     }
     launch_owner(cx, p, d, g, total_tri, G);
-    launch_match(cx, p, d, g, G);
-    if (taps && taps->enabled) {
-        rc = tap_dev(L, taps, SVH_ELAS_D1_RAW, L.Draw, DN); if (rc) return rc;
-        rc = tap_dev(L, taps, SVH_ELAS_D2_RAW, L.Draw + DN, DN); if (rc) return rc;
-    }
     // when the callers' maps live on the device the post-processing chain runs in
     // place on them: no final copy
     DevMaps out;
@@ -540,9 +535,17 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     } else {
         out.D[0] = L.D; out.D[1] = L.D + DN; out.stride[0] = out.stride[1] = 2 * DN;
     }
+    const bool tapping = taps && taps->enabled;
+    const bool fused_tail = !tapping && g_fused.load() && post_fusable(p);
+    // the row kernel also applies the L/R check (its inputs are the row it just matched)
+    const bool lr_done = launch_match(cx, p, d, g, G, fused_tail ? nullptr : &out, tapping);
+    if (tapping) {
+        rc = tap_dev(L, taps, SVH_ELAS_D1_RAW, L.Draw, DN); if (rc) return rc;
+        rc = tap_dev(L, taps, SVH_ELAS_D2_RAW, L.Draw + DN, DN); if (rc) return rc;
+    }
     const PostScratch ps = {L.tmp, L.labels, L.runlen, L.counts};
     const int nside = p.postprocess_only_left ? 1 : 2;
-    if (!(taps && taps->enabled) && g_fused.load() && post_fusable(p)) {
+    if (fused_tail) {
         // fused tail: the L/R check writes the maps that get post-processed into
         // scratch, the others straight to the output; one kernel does the rest
         DevMaps mid = out;
@@ -555,7 +558,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         launch_post_fused(cx, p, d, g, nside, G, mid, out, ps);
         goto copy_out;
     }
-    launch_lr(cx, p, d, g, G, out);
+    if (!lr_done) launch_lr(cx, p, d, g, G, out);
     if (taps && taps->enabled) {
         rc = tap_dev(L, taps, SVH_ELAS_D1_LR, out.D[0], DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_LR, out.D[1], DN); if (rc) return rc;

@@ -819,12 +819,17 @@ __device__ __forceinline__ float match_pixel_keyed(const uint4& own, const float
     return best != 0x7FFFFFFF ? (float)(best & 511) : -1.f;
 }
 
-__global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P) {
+// kLr: the left/right consistency check (E12, elas.cpp:1122-1204) of a row only needs the raw
+// left and right disparities of that same row, which this block has just produced: they stay
+// in LDS, and the checked maps go straight to `out` -- no raw-map round trip, no k_lr launch.
+template <bool kLr>
+__global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P, DevMaps out, int write_raw,
+                                                     float lr_threshold) {
     // One block = one image row of one pair, BOTH disparity maps: the left-map pass compares
     // L[row] with R[row], the right-map pass R[row] with L[row], so the two descriptor rows
     // (2 x 19.9 KB at W = 1242) are staged in LDS once and serve as "own" and "other" row of
     // both passes; the first half of the block matches the left map, the second half the right.
-    extern __shared__ uint4 s_rows[];   // [2][W]: row of image 1, row of image 2
+    extern __shared__ uint4 s_rows[];   // [2][W]: row of image 1, row of image 2; then raw [2][DW]
     __shared__ int s_P[64];
     const int row_id = blockIdx.x;      // (pair, image row)
     const int pair = row_id / P.DH, y = row_id - pair * P.DH;
@@ -853,6 +858,7 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P) 
     const uint32_t* row_bits =
         G.mask + ((size_t)z * P.gw * P.gh + (size_t)(v / P.grid_size) * P.gw) * P.gwords;
     float* out_row = G.Draw + (size_t)z * P.DW * P.DH + (size_t)y * P.DW;
+    float* s_raw = reinterpret_cast<float*>(s_rows + 2 * P.W);   // [2][DW] raw disparities of the row
     for (int x = (int)threadIdx.x - side * half; x < P.DW; x += half) {
         const int u = x * mul;
         float out = -10.f;
@@ -871,7 +877,24 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P) 
                           : match_pixel_keyed<true>(own, pl, u, v, sgn, oth_row, bits, s_P, G.P, P);
             }
         }
-        out_row[x] = out;
+        if (!kLr || write_raw) out_row[x] = out;
+        if (kLr) s_raw[side * P.DW + x] = out;
+    }
+    if (!kLr) return;
+    __syncthreads();
+    // E12: keep d iff the other map, at the warped position, agrees within lr_threshold
+    float* D = out.D[side] + (size_t)pair * out.stride[side] + (size_t)y * P.DW;
+    const float* mine = s_raw + side * P.DW;
+    const float* other = s_raw + (1 - side) * P.DW;
+    for (int x = (int)threadIdx.x - side * half; x < P.DW; x += half) {
+        const float d = mine[x];
+        const float fx = (float)x;
+        const float step = P.sub ? d / 2 : d;
+        const float uw = side ? fx + step : fx - step;
+        float o = -10.f;
+        if (d >= 0 && uw >= 0 && uw < (float)P.DW)
+            if (!(fabsf(other[(int)uw] - d) > lr_threshold)) o = d;
+        D[x] = o;
     }
 }
 
@@ -1643,8 +1666,8 @@ void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
            p.subsampling);
 }
 
-void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
-                  const GroupDev& G) {
+bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                  const GroupDev& G, const DevMaps* lr_out, bool write_raw) {
     MatchParams P;
     P.W = d.W; P.H = d.H; P.DW = d.DW; P.DH = d.DH; P.gw = d.gw; P.gh = d.gh; P.gwords = d.gwords;
     P.grid_size = p.grid_size; P.sub = p.subsampling; P.disp_max = p.disp_max;
@@ -1656,14 +1679,22 @@ void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     static const bool ordered = getenv("SVH_MATCH_ORDERED") != nullptr;
     const bool keyed_ok = !ordered && G.prior_absmax < (1 << 19) && p.disp_max < 512 &&
                           G.plane_radius <= 15 && d.W < 65536 && p.grid_size > 1;
-    if (keyed_ok && 2 * lds <= 64 * 1024) {
+    const size_t lds2 = 2 * lds + (lr_out ? (size_t)2 * d.DW * sizeof(float) : 0);
+    if (keyed_ok && lds2 <= 64 * 1024) {
         Timed timed_(cx, "k_match");
         // threads per map and row block: the row is covered in `iters` equal passes with little idle tail
         static const int mt = getenv("SVH_MATCH_THREADS") ? atoi(getenv("SVH_MATCH_THREADS")) : 256;
         const int iters = (d.DW + mt - 1) / mt;
         const int half = std::min(256, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
-        hipLaunchKernelGGL(k_match_keyed, dim3((unsigned)(d.DH * g)), dim3(2 * half), 2 * lds,
-                           (hipStream_t)cx.stream, G, P);
+        const dim3 grid((unsigned)(d.DH * g)), block(2 * half);
+        hipStream_t s = (hipStream_t)cx.stream;
+        if (lr_out) {
+            hipLaunchKernelGGL(k_match_keyed<true>, grid, block, lds2, s, G, P, *lr_out, write_raw ? 1 : 0,
+                               (float)p.lr_threshold);
+            return true;   // the L/R check is done
+        }
+        DevMaps none{};
+        hipLaunchKernelGGL(k_match_keyed<false>, grid, block, lds2, s, G, P, none, 1, 0.f);
     } else if (lds <= 64 * 1024) {
         Timed timed_(cx, "k_match");
         static const int mt = getenv("SVH_MATCH_THREADS") ? atoi(getenv("SVH_MATCH_THREADS")) : 256;
@@ -1674,6 +1705,7 @@ void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     } else {
         LAUNCH("k_match", k_match<false>, grid2d(d.DW, d.DH, 2 * g), dim3(64, 4), G, P);
     }
+    return false;
 }
 
 void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,

@@ -121,8 +121,11 @@ void launch_prior(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
                   int32_t total_sup, int32_t total_tri, const GroupDev& G);
 void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                   int32_t total_tri, const GroupDev& G);
-void launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
-                  const GroupDev& G);
+// dense matching; when `lr_out` is given and the row kernel applies, the L/R check is fused in
+// (returns true: the checked maps are in *lr_out, launch_lr must be skipped); `write_raw` keeps
+// the raw maps in G.Draw as well (parity taps)
+bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                  const GroupDev& G, const DevMaps* lr_out, bool write_raw);
 void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                const GroupDev& G, const DevMaps& out);
 // post-processing of nside maps per pair, in place on `out`; scratch arrays are
