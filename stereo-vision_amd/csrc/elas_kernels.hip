@@ -1325,23 +1325,17 @@ __global__ __launch_bounds__(256) void k_adaptive_mean(GroupDev G, DevMaps m, Po
     // lines 3..olen-4; centres lead-back .. len-1-back
     if (other >= 3 && other < olen - 3 && pos >= lead - back && pos <= len - 1 - back) {
         const int first = pos + back - lead;  // oldest tap position
-        float ring[kTaps];
-#pragma unroll
-        for (int k = 0; k < kTaps; k++) {
-            float t = in[i + (first + k - pos) * stride];
-            if (!kCols && t < 0) t = -10.f;
-            ring[k] = t;
-        }
         float centre = in[i];
         if (!kCols && centre < 0) centre = -10.f;
-        // slot s holds the tap whose position % kTaps == s
+        // ring slot s holds the tap whose position % kTaps == s (elas.cpp:1674, 1722): load the
+        // taps in slot order directly -- tap index k = (s - first) mod kTaps -- instead of
+        // loading them in position order and rotating with a select chain
         float ws[kTaps], fs[kTaps];
 #pragma unroll
         for (int s = 0; s < kTaps; s++) {
-            const int k = ((s - first) % kTaps + kTaps) % kTaps;  // tap index in ring[]
-            float t = ring[0];
-#pragma unroll
-            for (int q = 1; q < kTaps; q++) t = (k == q) ? ring[q] : t;
+            const int k = (s - first) & (kTaps - 1);   // kTaps is 4 or 8
+            float t = in[i + (first + k - pos) * stride];
+            if (!kCols && t < 0) t = -10.f;
             const float w = am_weight(t, centre);
             ws[s] = w;
             fs[s] = __fmul_rn(t, w);
