@@ -424,6 +424,27 @@ def main():
             del src, dst
             roofline["measured_copy_GBps"] = copy_gbs
             roofline["frac_of_measured_copy"] = achieved / copy_gbs
+            # the streaming (HBM-bound) kernels, from the committed isolated measurements:
+            # measured HBM bytes per 4-pair launch (FETCH/WRITE_SIZE passes) / its duration
+            try:
+                import glob
+                tr = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))
+                iss = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_issue.json")))[-1]))
+                alias = {"k_support_lds": "k_support", "k_match_keyed": "k_match"}
+                rows = []
+                for sym, v in iss["kernels"].items():
+                    tk = tr["kernels"].get(alias.get(sym, sym))
+                    if tk and v["launch_us_under_pmc"] > 0:
+                        gbs = tk["hbm_bytes"] / v["launch_us_under_pmc"] / 1e3
+                        rows.append({"kernel": alias.get(sym, sym), "hbm_GBps": round(gbs, 1),
+                                     "frac_of_peak": round(gbs / HBM_PEAK_GBS, 3),
+                                     "valu_busy": v["valu_busy"]})
+                rows.sort(key=lambda r: -r["hbm_GBps"])
+                roofline["isolated_kernels_hbm"] = {"source": "profiles/*_pmc_traffic.json + *_pmc_issue.json "
+                                                              "(rocprofv3 --pmc, kernels serialised, KITTI workload)",
+                                                    "top": rows[:5]}
+            except (OSError, IndexError, KeyError, ValueError):
+                pass
     if world > 1:
         dist.barrier()
 
