@@ -121,16 +121,32 @@ __global__ __launch_bounds__(256) void k_descriptor(DevImages img, int W, int H,
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
     const int tid = threadIdx.y * TX + threadIdx.x;
 
-    for (int i = tid; i < (TY + 6) * (TX + 6); i += 256) {
-        int r = i / (TX + 6), c = i - r * (TX + 6);
-        int y = y0 - 3 + r, x = x0 - 3 + c;
-        uint8_t val = 0;
-        if (x >= 0 && x < W && y >= 0 && y < H) val = I[(size_t)y * pitch + x];
-        sI[r][c] = val;
+    // linear walks over the (TY+6) x (TX+6) and (TY+4) x (TX+4) windows, 256 entries per step; the
+    // (row, column) of an entry is advanced incrementally (no integer division per entry)
+    {
+        constexpr int CW = TX + 6, dr = 256 / CW, dc = 256 % CW;
+        int r = tid / CW, c = tid - r * CW;
+        for (int i = tid; i < (TY + 6) * CW; i += 256) {
+            const int y = y0 - 3 + r, x = x0 - 3 + c;
+            uint8_t val = 0;
+            if (x >= 0 && x < W && y >= 0 && y < H) val = I[(size_t)y * pitch + x];
+            sI[r][c] = val;
+            r += dr;
+            c += dc;
+            if (c >= CW) {
+                c -= CW;
+                r++;
+            }
+        }
     }
     __syncthreads();
-    for (int i = tid; i < (TY + 4) * (TX + 4); i += 256) {
-        int r = i / (TX + 4), c = i - r * (TX + 4);
+    constexpr int UW = TX + 4, ur = 256 / UW, uc = 256 % UW;
+    int r = tid / UW, c = tid - r * UW;
+    for (int i = tid; i < (TY + 4) * UW; i += 256, r += ur, c += uc) {
+        if (c >= UW) {
+            c -= UW;
+            r++;
+        }
         // (r,c) in sU is image (y0-2+r, x0-2+c) == sI[r+1][c+1]
         int a0 = sI[r][c], a1 = sI[r][c + 1], a2 = sI[r][c + 2];
         int b0 = sI[r + 1][c], b2 = sI[r + 1][c + 2];
