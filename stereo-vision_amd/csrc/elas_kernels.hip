@@ -106,7 +106,7 @@ __device__ __forceinline__ int tri_slot(const GroupHdr* __restrict__ h, int T, i
 // wave writes 1 KiB contiguous.  Border descriptors (and odd rows when half)
 // are written as zero.
 // ---------------------------------------------------------------------------
-constexpr int TX = 64, TY = 64;
+constexpr int TX = 64, TY = 32;
 
 __global__ __launch_bounds__(256) void k_descriptor(DevImages img, int W, int H, int half,
                                                     uint8_t* __restrict__ desc_all) {
