@@ -1234,19 +1234,38 @@ __global__ __launch_bounds__(256) void k_gap_local(GroupDev G, DevMaps m, PostSc
     const int pos = kCols ? y : x, len = kCols ? DH : DW;
     float val = in[i];
     if (!(val >= 0)) {
-        int l = 0, r = 0;
-        for (int k = 1; k <= gap && pos - k >= 0; k++)
-            if (in[i - k * stride] >= 0) {
-                l = k;
-                break;
+        if (gap <= 4) {
+            // the common small gap widths: all neighbours are fetched at once (independent loads)
+            // and the nearest valid one on each side is picked afterwards
+            float nl[4], nr[4];
+#pragma unroll
+            for (int k = 1; k <= 4; k++) {
+                nl[k - 1] = (k <= gap && pos - k >= 0) ? in[i - k * stride] : -1.f;
+                nr[k - 1] = (k <= gap && pos + k < len) ? in[i + k * stride] : -1.f;
             }
-        if (l) {
-            for (int k = 1; k <= gap - l + 1 && pos + k < len; k++)
-                if (in[i + k * stride] >= 0) {
-                    r = k;
+            int l = 0, r = 0;
+            float vl = 0.f, vr = 0.f;
+#pragma unroll
+            for (int k = 4; k >= 1; k--) {
+                if (nl[k - 1] >= 0) { l = k; vl = nl[k - 1]; }
+                if (nr[k - 1] >= 0) { r = k; vr = nr[k - 1]; }
+            }
+            if (l && r && r <= gap - l + 1) val = gap_value(vl, vr);
+        } else {
+            int l = 0, r = 0;
+            for (int k = 1; k <= gap && pos - k >= 0; k++)
+                if (in[i - k * stride] >= 0) {
+                    l = k;
                     break;
                 }
-            if (r) val = gap_value(in[i - l * stride], in[i + r * stride]);
+            if (l) {
+                for (int k = 1; k <= gap - l + 1 && pos + k < len; k++)
+                    if (in[i + k * stride] >= 0) {
+                        r = k;
+                        break;
+                    }
+                if (r) val = gap_value(in[i - l * stride], in[i + r * stride]);
+            }
         }
     }
     out[i] = val;
