@@ -430,13 +430,17 @@ __device__ bool solve3(double A[3][3], double B[3]) {
 }
 
 __global__ __launch_bounds__(256) void k_prior(GroupDev G, int total_tri) {
-    const int T = blockIdx.x * 256 + threadIdx.x;
-    if (T >= total_tri) return;
+    // two lanes per triangle: lane rs = 0 fits the plane in left-image coordinates (t1a..c),
+    // rs = 1 in right-image coordinates (t2a..c); the even lane then builds the raster record
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int T = gid >> 1, rs = gid & 1;
+    const bool live = T < total_tri;
+    const int Tc = live ? T : 0;
     int first;
-    const int slot = tri_slot(G.hdr, T, &first);
+    const int slot = tri_slot(G.hdr, Tc, &first);
     const int pair = slot >> 1, side = slot & 1;
     const int32_t* sup = G.support + 3 * (size_t)G.hdr->sup_off[pair];
-    const int32_t* c = G.tri + 3 * (size_t)T;
+    const int32_t* c = G.tri + 3 * (size_t)Tc;
     int32_t su[3], sv[3], sd[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -445,9 +449,8 @@ __global__ __launch_bounds__(256) void k_prior(GroupDev G, int total_tri) {
         sv[k] = s[1];
         sd[k] = s[2];
     }
-    float pl[6];
-#pragma unroll
-    for (int rs = 0; rs < 2; rs++) {
+    float mine[3];
+    {
         double A[3][3], B[3];
         for (int r = 0; r < 3; r++) {
             A[r][0] = (double)(rs ? su[r] - sd[r] : su[r]);
@@ -456,13 +459,21 @@ __global__ __launch_bounds__(256) void k_prior(GroupDev G, int total_tri) {
             B[r] = (double)sd[r];
         }
         if (solve3(A, B)) {
-            pl[3 * rs + 0] = (float)B[0];
-            pl[3 * rs + 1] = (float)B[1];
-            pl[3 * rs + 2] = (float)B[2];
+            mine[0] = (float)B[0];
+            mine[1] = (float)B[1];
+            mine[2] = (float)B[2];
         } else {
-            pl[3 * rs + 0] = pl[3 * rs + 1] = pl[3 * rs + 2] = 0.f;
+            mine[0] = mine[1] = mine[2] = 0.f;
         }
     }
+    float pl[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float other = __shfl_xor(mine[k], 1);   // partner lane's plane (all lanes take part)
+        pl[k] = rs ? other : mine[k];
+        pl[3 + k] = rs ? mine[k] : other;
+    }
+    if (!live || rs) return;
 #pragma unroll
     for (int k = 0; k < 6; k++) G.planes[6 * (size_t)T + k] = pl[k];
 
@@ -1676,7 +1687,7 @@ void launch_prior(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     const int cells = d.gw * d.gh;
     const size_t words = (size_t)2 * g * cells * d.gwords;
     (void)hipMemsetAsync(G.seed, 0, words * sizeof(uint32_t), s);
-    if (total_tri > 0) LAUNCH("k_prior", k_prior, dim3((total_tri + 255) / 256), dim3(256), G, total_tri);
+    if (total_tri > 0) LAUNCH("k_prior", k_prior, dim3((2 * total_tri + 255) / 256), dim3(256), G, total_tri);
     if (total_sup > 0)
         LAUNCH("k_grid_seed", k_grid_seed, dim3((total_sup + 255) / 256), dim3(256), G, total_sup,
                d.gw, d.gh, d.gwords, p.grid_size, p.disp_max);
