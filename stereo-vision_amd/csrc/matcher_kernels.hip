@@ -613,6 +613,46 @@ __device__ void relocate(const SobelView& s1, const SobelView& s2, int margin, f
     *v2 = (float)((double)*v2 + ((double)(float)(best / 5) - 2.0));
 }
 
+// relocateMinimum with 32 lanes per match: lane k < 25 evaluates search position k, the winner is
+// the smallest (cost, k) pair == the reference's first minimum of its k = 0..24 scan
+__device__ __forceinline__ void relocate_group(const SobelView& s1, const SobelView& s2, int margin, float u1,
+                                               float v1, float* u2, float* v2, int lane) {
+    // group-uniform exit (all 32 lanes hold the same match)
+    if (*u2 - 2 < margin || *u2 + 2 > s2.w - 1 - margin || *v2 - 2 < margin || *v2 + 2 > s2.h - 1 - margin)
+        return;
+    int key = 0x7FFFFFFF;
+    if (lane < 25) {
+        uint32_t ref[4], d[4];
+        small_desc(s1.du, s1.dv, s1.bpl, (int)u1, (int)v1, ref);
+        small_desc(s2.du, s2.dv, s2.bpl, (int)*u2 + lane % 5 - 2, (int)*v2 + lane / 5 - 2, d);
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) c = __builtin_amdgcn_sad_u8(ref[q], d[q], c);
+        key = (int)(c << 5) | lane;   // cost <= 4080
+    }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+        const int o = __shfl_xor(key, m, 32);
+        key = o < key ? o : key;
+    }
+    const int best = key & 31;
+    *u2 = (float)((double)*u2 + ((double)(float)(best % 5) - 2.0));
+    *v2 = (float)((double)*v2 + ((double)(float)(best / 5) - 2.0));
+}
+
+__global__ __launch_bounds__(256) void k_refine_group(svh_p_match* __restrict__ m,
+                                                      const int32_t* __restrict__ count, int method, int margin,
+                                                      SobelView s1p, SobelView s2p, SobelView s1c,
+                                                      SobelView s2c) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x) >> 5, lane = threadIdx.x & 31;
+    if (i >= *count) return;   // whole groups leave together
+    svh_p_match q = m[i];
+    if (method == 0 || method == 2) relocate_group(s1c, s1p, margin, q.u1c, q.v1c, &q.u1p, &q.v1p, lane);
+    if (method == 1 || method == 2) relocate_group(s1c, s2c, margin, q.u1c, q.v1c, &q.u2c, &q.v2c, lane);
+    if (method == 2) relocate_group(s1c, s2p, margin, q.u1c, q.v1c, &q.u2p, &q.v2p, lane);
+    if (lane == 0) m[i] = q;
+}
+
 // Matrix::solve, 6x6 with one right-hand side   libviso2/src/matrix.cpp:648-760
 // (same operation order as the reference's double code; IEEE ops, no contraction)
 __device__ bool solve6(double* A, double* B) {
@@ -829,8 +869,8 @@ void mlaunch_refine(void* stream, svh_p_match* m, const int32_t* count, int cap,
     hipStream_t s = (hipStream_t)stream;
     if (!parabolic) {
         if (cap > 0)
-            hipLaunchKernelGGL(k_refine<false>, dim3((cap + 127) / 128), dim3(128), 0, s, m, count, method,
-                               margin, s1p, s2p, s1c, s2c, flags);
+            hipLaunchKernelGGL(k_refine_group, dim3((unsigned)(((size_t)cap * 32 + 255) / 256)), dim3(256), 0, s, m,
+                               count, method, margin, s1p, s2p, s1c, s2c);
         return;
     }
     if (cap > 0)
