@@ -58,6 +58,7 @@ struct DevView {
     int32_t n[2] = {0, 0};                  // host copy
     int32_t *off[2] = {nullptr, nullptr}, *ids[2] = {nullptr, nullptr};
     int32_t nbins = 0;
+    int32_t off_cap = 0;      // bins the off[] arrays were allocated for
     std::vector<uint8_t> host;              // full image on the host (getGain)
 
     void release() {
@@ -74,6 +75,7 @@ struct DevView {
         w = h = 0;
         half = -1;
         nbins = 0;
+        off_cap = 0;
         valid = false;
     }
 };
@@ -255,22 +257,38 @@ static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* 
     return SVH_OK;   // the caller synchronises once after both cameras
 }
 
-static int ensure_bins(svh_matcher* m, DevView& V, int32_t ub, int32_t vb) {
+// (re)build the bin indices of every view whose tables changed since the last call: one launch
+static int ensure_bins(svh_matcher* m, DevView* const* views, int nviews, int32_t ub, int32_t vb) {
     const int32_t nb = 4 * ub * vb;
-    if (V.nbins == nb) return SVH_OK;
-    for (int k = 0; k < 2; k++) {
-        (void)hipFree(V.off[k]);
-        HIP_TRY(dalloc(&V.off[k], (size_t)nb + 1));
+    BinJobs J;
+    int nj = 0, nmax = 0;
+    for (int v = 0; v < nviews; v++) {
+        DevView& V = *views[v];
+        if (!V.valid || V.nbins == nb) continue;
+        if (nb > V.off_cap) {   // (re)allocate only when the bin grid grows: hipFree synchronises the device
+            for (int k = 0; k < 2; k++) {
+                (void)hipFree(V.off[k]);
+                HIP_TRY(dalloc(&V.off[k], (size_t)nb + 1));
+            }
+            V.off_cap = nb;
+        }
+        for (int k = 0; k < 2; k++) {
+            J.table[nj] = V.tab[k];
+            J.count[nj] = V.cnt + k;
+            J.off[nj] = V.off[k];
+            J.ids[nj] = V.ids[k];
+            nmax = std::max(nmax, V.n[k]);
+            nj++;
+        }
+        V.nbins = nb;
     }
+    if (!nj) return SVH_OK;
     if (nb > m->cursor_cap) {
         (void)hipFree(m->cursor);
         HIP_TRY(dalloc(&m->cursor, (size_t)nb));
         m->cursor_cap = nb;
     }
-    for (int k = 0; k < 2; k++)
-        mlaunch_bin_index(m->stream, V.tab[k], V.cnt + k, V.n[k], ub, vb, m->p.match_binsize, V.off[k], V.ids[k],
-                          m->cursor);
-    V.nbins = nb;
+    mlaunch_bin_index(m->stream, J, nj, nmax, ub, vb, m->p.match_binsize, m->cursor);
     return SVH_OK;
 }
 
@@ -595,12 +613,8 @@ int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double*
     const int32_t ub = (int32_t)ceilf((float)m->dims_c[0] / (float)p.match_binsize);
     const int32_t vb = (int32_t)ceilf((float)m->dims_c[1] / (float)p.match_binsize);
     DevView* views[4] = {&m->prev[0], &m->prev[1], &m->cur[0], &m->cur[1]};
-    const bool used[4] = {need_1p, need_2p, true, need_2c};
-    // an unused view may be empty: give it valid (empty) bin tables anyway
-    for (int v = 0; v < 4; v++) {
-        if (!views[v]->valid && !used[v]) continue;
-        if (!views[v]->valid) continue;
-        int rc = ensure_bins(m, *views[v], ub, vb);
+    {
+        int rc = ensure_bins(m, views, 4, ub, vb);
         if (rc) return rc;
     }
     if (ub * vb > m->ranges_cap) {

@@ -44,9 +44,16 @@ int  mnms_blocks(int extent, int n, int margin);
 void mlaunch_features(void* stream, const int16_t* f1, const int16_t* f2, const uint8_t* du,
                       const uint8_t* dv, int w, int h, int bpl, int n, int tau, int margin, int scale,
                       int4* slots, int32_t* flags, int32_t* order, int32_t* table, int32_t* count);
-// n_host: the table's feature count as known on the host (sizes the LDS build)
-void mlaunch_bin_index(void* stream, const int32_t* table, const int32_t* count, int n_host, int ub,
-                       int vb, int binsize, int32_t* off, int32_t* ids, int32_t* cursor);
+// up to 8 feature tables whose bin indices are built by one launch (one workgroup each)
+struct BinJobs {
+    const int32_t* table[8];
+    const int32_t* count[8];
+    int32_t* off[8];
+    int32_t* ids[8];
+};
+// n_host_max: the largest feature count among the jobs as known on the host (sizes the LDS build)
+void mlaunch_bin_index(void* stream, const BinJobs& J, int njobs, int n_host_max, int ub, int vb, int binsize,
+                       int32_t* cursor);
 void mlaunch_match(void* stream, const MatchParams& P, const FeatView& m1p, const FeatView& m2p,
                    const FeatView& m1c, const FeatView& m2c, int nquery_cap, const float* ranges,
                    int use_prior, svh_p_match* slots, int32_t* flags, int32_t* pixel_owner,

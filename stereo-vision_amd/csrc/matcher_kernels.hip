@@ -261,12 +261,13 @@ __global__ __launch_bounds__(256) void k_feature_records(const int4* __restrict_
 // ---------------------------------------------------------------------------
 // LDS build: histogram, scan, scatter and the per-bin ascending sort all stay on chip;
 // used when 2*nb + 1 + n ints fit the LDS budget (launcher), else k_bin_index below.
-__global__ __launch_bounds__(1024) void k_bin_index_lds(const int32_t* __restrict__ table,
-                                                        const int32_t* __restrict__ count, int ub,
-                                                        int vb, int binsize, int32_t* __restrict__ off,
-                                                        int32_t* __restrict__ ids) {
+__global__ __launch_bounds__(1024) void k_bin_index_lds(BinJobs J, int ub, int vb, int binsize) {
     extern __shared__ int s_bin[];
-    const int n = *count, nb = 4 * ub * vb, t = threadIdx.x;
+    // one workgroup per table (blockIdx.x): the four tables of a stereo frame build concurrently
+    const int32_t* __restrict__ table = J.table[blockIdx.x];
+    int32_t* __restrict__ off = J.off[blockIdx.x];
+    int32_t* __restrict__ ids = J.ids[blockIdx.x];
+    const int n = *J.count[blockIdx.x], nb = 4 * ub * vb, t = threadIdx.x;
     int* s_off = s_bin;            // nb + 1
     int* s_cur = s_bin + nb + 1;   // nb
     int* s_ids = s_cur + nb;       // n
@@ -832,16 +833,17 @@ void mlaunch_features(void* stream, const int16_t* f1, const int16_t* f2, const 
                            count, du, dv, bpl, scale, table);
 }
 
-void mlaunch_bin_index(void* stream, const int32_t* table, const int32_t* count, int n_host, int ub,
-                       int vb, int binsize, int32_t* off, int32_t* ids, int32_t* cursor) {
+void mlaunch_bin_index(void* stream, const BinJobs& J, int njobs, int n_host_max, int ub, int vb, int binsize,
+                       int32_t* cursor) {
     const int nb = 4 * ub * vb;
-    const size_t lds = ((size_t)2 * nb + 1 + (size_t)std::max(n_host, 0)) * sizeof(int32_t);
-    if (lds <= 56 * 1024)
-        hipLaunchKernelGGL(k_bin_index_lds, dim3(1), dim3(1024), lds, (hipStream_t)stream, table, count, ub, vb,
-                           binsize, off, ids);
-    else
-        hipLaunchKernelGGL(k_bin_index, dim3(1), dim3(1024), 0, (hipStream_t)stream, table, count, ub, vb,
-                           binsize, off, ids, cursor);
+    const size_t lds = ((size_t)2 * nb + 1 + (size_t)std::max(n_host_max, 0)) * sizeof(int32_t);
+    if (lds <= 56 * 1024) {
+        hipLaunchKernelGGL(k_bin_index_lds, dim3(njobs), dim3(1024), lds, (hipStream_t)stream, J, ub, vb, binsize);
+    } else {
+        for (int j = 0; j < njobs; j++)
+            hipLaunchKernelGGL(k_bin_index, dim3(1), dim3(1024), 0, (hipStream_t)stream, J.table[j], J.count[j], ub,
+                               vb, binsize, J.off[j], J.ids[j], cursor);
+    }
 }
 
 void mlaunch_match(void* stream, const MatchParams& P, const FeatView& m1p, const FeatView& m2p,
