@@ -172,6 +172,9 @@ int32_t svh_profile_get(int32_t index, const char** name, double* total_ms, int6
  * tri receives up to cap triangles (3 input-order vertex indices each).
  * Returns the triangle count or a negative error.                            */
 int32_t svh_delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap);
+/* same, with the top `par_depth` levels of the divide-and-conquer on two threads each
+ * (2^par_depth threads); the triangle list is identical to svh_delaunay's */
+int32_t svh_delaunay_mt(const float* pts, int32_t n, int32_t* tri, int32_t cap, int32_t par_depth);
 
 /* Lattice filters + support list (libelas/src/elas.cpp:174-318, 495-523) as the
  * engine runs them between the two device phases.  dcan = candidate lattice

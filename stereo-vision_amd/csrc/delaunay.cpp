@@ -36,6 +36,12 @@
 
 #include <algorithm>
 #include <cmath>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/svh.h"
@@ -45,6 +51,64 @@
 #endif
 
 namespace svh {
+
+// ---------------------------------------------------------------------------
+// A few parked helper threads for the latency paths (parallel divide-and-conquer, the two
+// triangulations of one stereo pair).  Creating a std::thread per task costs as much as the
+// task; a helper is woken through a condition variable instead and the submitter spins on the
+// task's completion flag (tasks are ~100 us).  Started lazily, never more than kHelpers.
+// ---------------------------------------------------------------------------
+namespace {
+struct HelperPool {
+    static constexpr int kHelpers = 3;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<std::function<void()>, std::atomic<int>*>> q;
+    int started = 0, idle = 0;
+    void worker() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            idle++;
+            cv.wait(lk, [&] { return !q.empty(); });
+            idle--;
+            auto job = std::move(q.front());
+            q.pop_front();
+            lk.unlock();
+            job.first();
+            job.second->store(1, std::memory_order_release);
+            lk.lock();
+        }
+    }
+    // false: no helper free right now -- the caller runs the task itself
+    bool submit(std::function<void()> fn, std::atomic<int>* done) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (idle - (int)q.size() <= 0) {
+            if (started >= kHelpers) return false;
+            started++;
+            std::thread(&HelperPool::worker, this).detach();
+        }
+        q.emplace_back(std::move(fn), done);
+        lk.unlock();
+        cv.notify_one();
+        return true;
+    }
+};
+HelperPool& helper_pool() {
+    static HelperPool* p = new HelperPool();   // leaked on purpose: helpers outlive static destruction
+    return *p;
+}
+}  // namespace
+
+void run_pair(const std::function<void()>& a, const std::function<void()>& b) {
+    std::atomic<int> done{0};
+    if (helper_pool().submit(b, &done)) {
+        a();
+        while (!done.load(std::memory_order_acquire)) __builtin_ia32_pause();
+    } else {
+        a();
+        b();
+    }
+}
 
 namespace {
 
@@ -57,7 +121,7 @@ struct Handle {
 
 class DivConq {
 public:
-    DivConq(const float* pts, int32_t n) : pts_(pts), n_(n), seed_(1) {}
+    DivConq(const float* pts, int32_t n, int par_depth = 0) : pts_(pts), n_(n), seed_(1), par_depth_(par_depth) {}
 
     // returns triangle count, or <0 on failure
     int32_t run(int32_t* out, int32_t cap);
@@ -66,6 +130,7 @@ private:
     const float* pts_;
     int32_t n_;
     uint64_t seed_;
+    int par_depth_;   // levels of the divide-and-conquer whose halves run on two threads
     std::vector<int64_t> ix_, iy_;   // exact scaled integer coordinates
     // one 32-byte record per triangle: vertices [0..2] (-1 = the ghost apex), neighbour
     // handles [3..5] encoded t*4+o, dead flag [6]
@@ -96,13 +161,17 @@ private:
         rec_[8 * a.t + 3 + a.o] = b.t * 4 + b.o;
         rec_[8 * b.t + 3 + b.o] = a.t * 4 + a.o;
     }
-    Handle make() {
-        if ((size_t)8 * (nrec_ + 1) > rec_.size()) rec_.resize(rec_.size() * 2 + 64);
-        int32_t* r = &rec_[8 * (size_t)nrec_];
+    // `ctr` is the caller's record counter: a subproblem of n vertices creates exactly 2n-2
+    // records (2 for an edge, 4 for a triangle, 2 per merge), so the two halves of a split own
+    // known, disjoint index ranges and can be triangulated by different threads while the
+    // records still come out in the sequential creation order (= Triangle's output order).
+    // rec_ is sized for every record up front (run()), so it never moves.
+    Handle make(int32_t& ctr) {
+        int32_t* r = &rec_[8 * (size_t)ctr];
         r[0] = r[1] = r[2] = -1;
         r[3] = r[4] = r[5] = 0;   // outer space, orientation 0
         r[6] = r[7] = 0;
-        Handle h = {nrec_++, 0};
+        Handle h = {ctr++, 0};
         return h;
     }
 
@@ -265,8 +334,10 @@ private:
         kd_order(lx + half, ly + half, n - half, 1 - axis, out);
     }
 
-    void recurse(const int32_t* a, int32_t n, int axis, Handle* farleft, Handle* farright);
-    void merge(Handle* farleft, Handle* innerleft, Handle* innerright, Handle* farright, int axis);
+    void recurse(const int32_t* a, int32_t n, int axis, Handle* farleft, Handle* farright, int32_t& ctr,
+                 int par_depth);
+    void merge(Handle* farleft, Handle* innerleft, Handle* innerright, Handle* farright, int axis,
+               int32_t& ctr);
     bool scale_coordinates();
 };
 
@@ -315,13 +386,14 @@ bool DivConq::scale_coordinates() {
     return true;
 }
 
-void DivConq::recurse(const int32_t* a, int32_t n, int axis, Handle* farleft, Handle* farright) {
+void DivConq::recurse(const int32_t* a, int32_t n, int axis, Handle* farleft, Handle* farright, int32_t& ctr,
+                      int par_depth) {
     if (n == 2) {
         // an edge: two ghost records glued along all three sides
-        Handle L = make();
+        Handle L = make(ctr);
         set_org(L, a[0]);
         set_dest(L, a[1]);
-        Handle R = make();
+        Handle R = make(ctr);
         set_org(R, a[1]);
         set_dest(R, a[0]);
         bond(L, R);
@@ -334,7 +406,7 @@ void DivConq::recurse(const int32_t* a, int32_t n, int axis, Handle* farleft, Ha
         return;
     }
     if (n == 3) {
-        Handle mid = make(), t1 = make(), t2 = make(), t3 = make();
+        Handle mid = make(ctr), t1 = make(ctr), t2 = make(ctr), t3 = make(ctr);
         int area = ccw(a[0], a[1], a[2]);
         if (area == 0) {
             // collinear: two edges, four ghosts
@@ -377,13 +449,21 @@ void DivConq::recurse(const int32_t* a, int32_t n, int axis, Handle* farleft, Ha
     }
     int32_t half = n >> 1;
     Handle innerleft, innerright;
-    recurse(a, half, 1 - axis, farleft, &innerleft);
-    recurse(a + half, n - half, 1 - axis, &innerright, farright);
-    merge(farleft, &innerleft, &innerright, farright, axis);
+    if (par_depth > 0 && n >= 512) {
+        // the right half on another thread, with the record range the sequential order gives it
+        int32_t ctr_right = ctr + 2 * half - 2;
+        run_pair([&]() { recurse(a, half, 1 - axis, farleft, &innerleft, ctr, par_depth - 1); },
+                 [&]() { recurse(a + half, n - half, 1 - axis, &innerright, farright, ctr_right, par_depth - 1); });
+        ctr = ctr_right;   // == start + 2n - 4: both halves are complete
+    } else {
+        recurse(a, half, 1 - axis, farleft, &innerleft, ctr, 0);
+        recurse(a + half, n - half, 1 - axis, &innerright, farright, ctr, 0);
+    }
+    merge(farleft, &innerleft, &innerright, farright, axis, ctr);
 }
 
 void DivConq::merge(Handle* farleft, Handle* innerleft, Handle* innerright, Handle* farright,
-                    int axis) {
+                    int axis, int32_t& ctr) {
     int32_t il_dest = dest(*innerleft), il_apex = apex(*innerleft);
     int32_t ir_org = org(*innerright), ir_apex = apex(*innerright);
 
@@ -440,7 +520,7 @@ void DivConq::merge(Handle* farleft, Handle* innerleft, Handle* innerright, Hand
 
     Handle lcand = sym(*innerleft), rcand = sym(*innerright);
     // bottom ghost of the seam
-    Handle base = make();
+    Handle base = make(ctr);
     bond(base, *innerleft);
     base = next(base);
     bond(base, *innerright);
@@ -457,7 +537,7 @@ void DivConq::merge(Handle* farleft, Handle* innerleft, Handle* innerright, Hand
         bool rightdone = ccw(upperright, lowerleft, lowerright) <= 0;
         if (leftdone && rightdone) {
             // top ghost of the seam
-            Handle top = make();
+            Handle top = make(ctr);
             set_org(top, lowerleft);
             set_dest(top, lowerright);
             bond(top, base);
@@ -648,9 +728,9 @@ int32_t DivConq::run(int32_t* out, int32_t cap) {
     TICK(2)
     rec_.assign(8 * (2 * (size_t)m + 16), 0);
     nrec_ = 0;
-    make();  // record 0 = outer space
+    make(nrec_);  // record 0 = outer space
     Handle hullleft, hullright;
-    recurse(order.data(), m, 0, &hullleft, &hullright);
+    recurse(order.data(), m, 0, &hullleft, &hullright, nrec_, par_depth_);
 
     // peel the ghost fan off the hull
     TICK(3)
@@ -682,8 +762,8 @@ int32_t DivConq::run(int32_t* out, int32_t cap) {
 
 }  // namespace
 
-int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap) {
-    DivConq dc(pts, n);
+int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap, int par_depth) {
+    DivConq dc(pts, n, par_depth);
     return dc.run(tri, cap);
 }
 
@@ -691,5 +771,10 @@ int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap) {
 
 extern "C" int32_t svh_delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap) {
     if (!pts || !tri || n < 0) return SVH_ERR_BAD_ARG;
-    return svh::delaunay(pts, n, tri, cap);
+    return svh::delaunay(pts, n, tri, cap, 0);
+}
+
+extern "C" int32_t svh_delaunay_mt(const float* pts, int32_t n, int32_t* tri, int32_t cap, int32_t par_depth) {
+    if (!pts || !tri || n < 0 || par_depth < 0 || par_depth > 4) return SVH_ERR_BAD_ARG;
+    return svh::delaunay(pts, n, tri, cap, par_depth);
 }

@@ -447,7 +447,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
             hp.support.clear();
             hp.tri[0].clear();
             hp.tri[1].clear();
-        } else if (!triangulate_support(hp)) {
+        } else if (!triangulate_support(hp, /*parallel=*/!L.poll_wait && g == 1)) {
             return fail(SVH_ERR_UNSUPPORTED, "triangulation failed");
         } else {
             hdr->active[j] = 1;

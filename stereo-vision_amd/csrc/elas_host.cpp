@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 
 #include "svh_internal.h"
 
@@ -131,21 +132,34 @@ void support_from_candidates(const svh_elas_params& p, const Dims& d, int16_t* d
 }
 
 // E7  Elas::computeDelaunayTriangulation   elas.cpp:534-600, on (u,v) and (u-d,v)
-bool triangulate_support(HostPrior& hp) {
+// E7: the two triangulations (left coordinates, right coordinates u - d).  `parallel`: run them
+// on two threads -- for the single-pair call, whose host stage is on the critical path; batch
+// workers already keep every core busy and stay sequential.
+bool triangulate_support(HostPrior& hp, bool parallel) {
     const int32_t n = (int32_t)(hp.support.size() / 3);
-    std::vector<float> pts((size_t)2 * n);
-    for (int side = 0; side < 2; side++) {
+    bool ok[2] = {true, true};
+    auto one = [&](int side) {
+        std::vector<float> pts((size_t)2 * n);
         for (int32_t i = 0; i < n; i++) {
             pts[2 * i] = (float)(side ? hp.support[3 * i] - hp.support[3 * i + 2] : hp.support[3 * i]);
             pts[2 * i + 1] = (float)hp.support[3 * i + 1];
         }
         std::vector<int32_t>& tri = hp.tri[side];
         tri.resize((size_t)3 * (2 * n + 8));
-        int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 8);
-        if (nt < 0) return false;
+        const int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 8);
+        if (nt < 0) {
+            ok[side] = false;
+            return;
+        }
         tri.resize((size_t)3 * nt);
+    };
+    if (parallel && n >= 256) {
+        run_pair([&]() { one(0); }, [&]() { one(1); });
+    } else {
+        one(0);
+        one(1);
     }
-    return true;
+    return ok[0] && ok[1];
 }
 
 // prior table and plane radius (elas.cpp:984-993): float math with the float

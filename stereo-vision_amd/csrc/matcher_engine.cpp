@@ -302,7 +302,9 @@ static int remove_outliers(const svh_matcher_params& p, std::vector<svh_p_match>
         pts[2 * i + 1] = pm[i].v1c;
     }
     std::vector<int32_t> tri((size_t)3 * (2 * n + 16));
-    const int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 16);
+    // the Matcher is a single-stream, latency-bound path: large votes triangulate on 4 threads
+    static const int par = getenv("SVH_DELAUNAY_PAR") ? atoi(getenv("SVH_DELAUNAY_PAR")) : 2;
+    const int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 16, n >= 1500 ? par : 0);
     if (nt < 0) return mfail(SVH_ERR_UNSUPPORTED, "outlier triangulation failed");
     std::vector<int32_t> votes(n, 0);
     const float ft = (float)p.outlier_flow_tolerance, dt = (float)p.outlier_disp_tolerance;

@@ -65,7 +65,9 @@ void mlaunch_refine(void* stream, svh_p_match* m, const int32_t* count, int cap,
                     const SobelView& s2c, int parabolic, int32_t* flags, svh_p_match* compacted,
                     int32_t* compacted_count);
 
-int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap);
+// par_depth > 0: the top `par_depth` levels of the divide-and-conquer run their halves on two
+// threads (2^par_depth threads in all); the output is identical to the sequential run
+int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap, int par_depth = 0);
 
 }  // namespace svh
 #endif

@@ -6,6 +6,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <functional>
 #include <vector>
 
 #include "../../include/svh.h"
@@ -61,14 +62,18 @@ struct HostPrior {
 void support_from_candidates(const svh_elas_params& p, const Dims& d, int16_t* dcan,
                              std::vector<int32_t>& support);
 // E7, both sides.  Returns false when a triangulation fails.
-bool triangulate_support(HostPrior& hp);
+bool triangulate_support(HostPrior& hp, bool parallel = false);
+// runs a() on the calling thread and b() on a parked helper thread (or both here if none is free)
+void run_pair(const std::function<void()>& a, const std::function<void()>& b);
 // prior table + plane radius (elas.cpp:984-993)
 void prior_table(const svh_elas_params& p, std::vector<int32_t>& P, int32_t* plane_radius);
 // reference-layout grid (int32 [gh][gw][disp_max+2]) from the device bit sets, for the tap
 void expand_grid(const svh_elas_params& p, const Dims& d, const uint32_t* mask,
                  std::vector<int32_t>& grid);
 
-int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap);
+// par_depth > 0: the top `par_depth` levels of the divide-and-conquer run their halves on two
+// threads (2^par_depth threads in all); the output is identical to the sequential run
+int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap, int par_depth = 0);
 
 // ---------------------------------------------------------------- device
 // Kernel launchers (elas_kernels.hip).  LaunchCtx carries the hipStream_t (as

@@ -145,3 +145,25 @@ def test_visual_odometry_refuses_to_run_without_a_gpu(S):
     ok, _ = vo.estimate_motion(H.synth_vo_matches(50, seed=1))
     assert ok == S.ERR_NO_DEVICE
     assert np.array_equal(vo.motion(), np.eye(4)) and len(vo.inliers()) == 0
+
+
+def test_parallel_delaunay_is_identical(S):
+    """svh_delaunay_mt (halves of the divide-and-conquer on helper threads, record ranges
+    fixed in advance) returns the sequential triangle list, order included"""
+    lib = S.lib()
+    rng = np.random.default_rng(11)
+    for trial in range(24):
+        n = int(rng.integers(600, 4000))
+        if trial % 3 == 0:
+            pts = rng.integers(0, 700, (n, 2)) * 2.0          # even lattice with duplicates
+        elif trial % 3 == 1:
+            pts = np.unique(rng.integers(1, 300, (n, 2)) * 5.0, axis=0)
+            rng.shuffle(pts)
+        else:
+            pts = rng.integers(-3000, 3000, (n, 2)) / 4.0
+        pts = np.ascontiguousarray(pts, np.float32)
+        want = S.delaunay(pts)
+        for depth in (1, 2, 3):
+            tri = np.zeros((2 * len(pts) + 16) * 3, np.int32)
+            nt = lib.svh_delaunay_mt(H._p(pts), len(pts), H._p(tri), 2 * len(pts) + 16, depth)
+            assert nt == len(want) and np.array_equal(tri[:3 * nt].reshape(-1, 3), want), (trial, depth)
