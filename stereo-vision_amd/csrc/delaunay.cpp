@@ -313,9 +313,12 @@ private:
     // kd-style split over two presorted lists with stable partitions.
     std::vector<uint8_t> mark_;
     std::vector<int32_t> tmp_;
-    void kd_order(int32_t* lx, int32_t* ly, int32_t n, int axis, int32_t*& out) {
+    // `out` receives the n entries of this sub-range, `tmp` is n entries of scratch: both halves
+    // of a split work on disjoint slices of every array (and disjoint vertices in mark_), so the
+    // top levels can run on two threads
+    void kd_order(int32_t* lx, int32_t* ly, int32_t n, int axis, int32_t* out, int32_t* tmp, int par_depth) {
         if (n <= 3) {
-            for (int32_t i = 0; i < n; i++) *out++ = lx[i];
+            for (int32_t i = 0; i < n; i++) out[i] = lx[i];
             return;
         }
         const int32_t half = n >> 1;
@@ -326,12 +329,17 @@ private:
         int32_t a = 0, b = half;
         for (int32_t i = 0; i < n; i++) {
             const int32_t v = oth[i];
-            if (mark_[v]) tmp_[a++] = v;
-            else          tmp_[b++] = v;
+            if (mark_[v]) tmp[a++] = v;
+            else          tmp[b++] = v;
         }
-        memcpy(oth, tmp_.data(), sizeof(int32_t) * n);
-        kd_order(lx, ly, half, 1 - axis, out);
-        kd_order(lx + half, ly + half, n - half, 1 - axis, out);
+        memcpy(oth, tmp, sizeof(int32_t) * n);
+        if (par_depth > 0 && n >= 512) {
+            run_pair([&]() { kd_order(lx, ly, half, 1 - axis, out, tmp, par_depth - 1); },
+                     [&]() { kd_order(lx + half, ly + half, n - half, 1 - axis, out + half, tmp + half, par_depth - 1); });
+        } else {
+            kd_order(lx, ly, half, 1 - axis, out, tmp, 0);
+            kd_order(lx + half, ly + half, n - half, 1 - axis, out + half, tmp + half, 0);
+        }
     }
 
     void recurse(const int32_t* a, int32_t n, int axis, Handle* farleft, Handle* farright, int32_t& ctr,
@@ -717,11 +725,18 @@ int32_t DivConq::run(int32_t* out, int32_t cap) {
             else          tmp_[b++] = v;
         }
         memcpy(ly.data(), tmp_.data(), sizeof(int32_t) * m);
-        int32_t* out = kd.data();
         if (m - half >= 2) {
-            if (half >= 2) kd_order(order.data(), ly.data(), half, 1, out);
-            else for (int32_t i = 0; i < half; i++) *out++ = order[i];
-            kd_order(order.data() + half, ly.data() + half, m - half, 1, out);
+            auto left = [&]() {
+                if (half >= 2) kd_order(order.data(), ly.data(), half, 1, kd.data(), tmp_.data(), 0);
+                else for (int32_t i = 0; i < half; i++) kd[i] = order[i];
+            };
+            auto right = [&]() {
+                kd_order(order.data() + half, ly.data() + half, m - half, 1, kd.data() + half, tmp_.data() + half, 0);
+            };
+            // kept on one thread: the halves' vertices interleave in mark_ (false sharing made the
+            // two-thread version slower than this one)
+            left();
+            right();
             memcpy(order.data(), kd.data(), sizeof(int32_t) * m);
         }
     }
