@@ -195,7 +195,7 @@ class Elas:
 
 
 def set_lanes(n):
-    """pipeline lanes (HIP stream + host worker each) per device"""
+    """batch workers per device (each double-buffered: two HIP streams + buffer sets)"""
     return lib().svh_elas_set_lanes(n)
 
 

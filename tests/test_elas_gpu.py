@@ -275,3 +275,31 @@ def test_param_fuzz_matches_oracle(seed, svhip, oracle_lib):
     assert got.status == want.status
     if got.status == 0:
         assert_same(want, got)
+
+@pytest.mark.parametrize("group,workers", [(1, 1), (2, 3), (4, 2), (8, 8)])
+def test_batch_with_failing_pairs(group, workers, svhip, capfd):
+    """a batch mixing good pairs with flat ones (< 3 support points): statuses per pair, failed
+    pairs' outputs untouched, good pairs identical to single calls -- for several group sizes and
+    worker counts of the double-buffered engine (the default is restored afterwards)"""
+    l, r = H.golden_pair("urban3_640x240")
+    flat = np.full_like(l, 90)
+    n = 11
+    bad = {2, 3, 9}
+    I1 = np.stack([flat if i in bad else np.roll(l, 2 * i, axis=1) for i in range(n)])
+    I2 = np.stack([flat if i in bad else np.roll(r, 2 * i, axis=1) for i in range(n)])
+    prm = H.robotics()
+    svhip.set_group(group)
+    svhip.set_lanes(workers)
+    try:
+        st, D1, D2 = svhip.Elas(prm).process_batch(I1, I2)
+    finally:
+        svhip.set_group(4)
+        svhip.set_lanes(8)
+    assert st == [1 if i in bad else 0 for i in range(n)]
+    assert capfd.readouterr().out.count("Need at least 3 support points") == len(bad)
+    for i in range(n):
+        if i in bad:
+            assert np.all(D1[i] == 0) and np.all(D2[i] == 0)      # process_batch hands in zeroed maps
+        else:
+            rc, a, b = svhip.Elas(prm).process(I1[i], I2[i])
+            assert rc == 0 and np.array_equal(a, D1[i]) and np.array_equal(b, D2[i])
