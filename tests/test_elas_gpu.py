@@ -303,3 +303,41 @@ def test_batch_with_failing_pairs(group, workers, svhip, capfd):
         else:
             rc, a, b = svhip.Elas(prm).process(I1[i], I2[i])
             assert rc == 0 and np.array_equal(a, D1[i]) and np.array_equal(b, D2[i])
+
+@pytest.mark.timeout(180)
+def test_concurrent_batches_share_the_lane_pool(svhip):
+    """three threads call process_batch at once while the pool only holds two workers' lanes:
+    lane pairs are taken atomically (no worker can hold one lane and wait for a second), so the
+    calls queue up instead of deadlocking, and every result equals the single-call result"""
+    import threading
+    l, r = H.golden_pair("urban3_640x240")
+    prm = H.robotics()
+    n = 6
+    want = {}
+    for k in range(3):
+        for i in range(n):
+            want[(k, i)] = svhip.Elas(prm).process(np.roll(l, 5 * k + i, axis=1), np.roll(r, 5 * k + i, axis=1))
+    out = {}
+    svhip.set_group(2)
+    svhip.set_lanes(2)
+
+    def work(k):
+        I1 = np.stack([np.roll(l, 5 * k + i, axis=1) for i in range(n)])
+        I2 = np.stack([np.roll(r, 5 * k + i, axis=1) for i in range(n)])
+        out[k] = svhip.Elas(prm).process_batch(I1, I2)
+
+    try:
+        th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+    finally:
+        svhip.set_group(4)
+        svhip.set_lanes(8)
+    for k in range(3):
+        st, D1, D2 = out[k]
+        assert all(s == 0 for s in st)
+        for i in range(n):
+            rc, a, b = want[(k, i)]
+            assert rc == 0 and np.array_equal(a, D1[i]) and np.array_equal(b, D2[i])
