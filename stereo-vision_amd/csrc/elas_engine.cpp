@@ -130,6 +130,7 @@ struct Lane {
     uint8_t* desc = nullptr;       // [gcap][2][N*16]
     int16_t* dcan = nullptr;       // [gcap][nc]
     int32_t* owner = nullptr;      // [gcap][2][N]
+    int64_t owner_hi = 0;          // every value stored in owner[] so far is <= owner_hi
     uint8_t* prior_dev = nullptr;  // packed upload: header, P, support, triangles
     TriRaster* raster = nullptr;   // [gcap*2*ntri_max]
     float* planes = nullptr;       // 6 per triangle
@@ -182,6 +183,8 @@ struct Lane {
         HIP_TRY(hipMalloc(&img, G2 * N));
         HIP_TRY(hipMalloc(&desc, G2 * N * 16));
         HIP_TRY(hipMalloc(&owner, G2 * N * sizeof(int32_t)));
+        HIP_TRY(hipMemset(owner, 0, G2 * N * sizeof(int32_t)));
+        owner_hi = 0;
         HIP_TRY(hipMalloc(&Draw, G2 * DN * sizeof(float)));
         HIP_TRY(hipMalloc(&D, G2 * DN * sizeof(float)));
         HIP_TRY(hipMalloc(&tmp, G2 * DN * sizeof(float)));
@@ -506,6 +509,14 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     G.mask = L.mask;
     G.desc = L.desc;
     G.owner = L.owner;
+    // triangle ownership is stored as owner_base + 1 + index; the base moves above everything
+    // written so far, so the 2 x N x g map is never cleared (one memset when int32 would overflow)
+    if (L.owner_hi + 1 + total_tri >= INT32_MAX) {
+        HIP_TRY(hipMemsetAsync(L.owner, 0, (size_t)2 * L.gcap * N * sizeof(int32_t), s));
+        L.owner_hi = 0;
+    }
+    G.owner_base = (int32_t)L.owner_hi;
+    L.owner_hi += 1 + total_tri;
     G.Draw = L.Draw;
     G.plane_radius = plane_radius;
     G.prior_absmax = 0;

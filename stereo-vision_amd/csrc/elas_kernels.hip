@@ -584,7 +584,9 @@ __global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri, int W,
     if (T >= total_tri) return;
     int first;
     const int slot = tri_slot(G.hdr, T, &first);
-    const int t = T - first;
+    // stored value = owner_base + 1 + triangle index: everything <= owner_base is a leftover of
+    // an earlier group and reads as "no triangle", so the maps need no clearing between groups
+    const int t = G.owner_base + 1 + (T - first);
     int32_t* owner = G.owner + (size_t)slot * W * H;
     const TriRaster tr = G.raster[T];
     const int cl = lane & 15, rp = lane >> 4;
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(kLds ? 512 : 256) void k_match(GroupDev G, MatchPar
     const int u = x * mul;
     float out = -10.f;
     const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
-    const int t = G.owner[(size_t)z * N + (size_t)v * P.W + u];
+    const int t = G.owner[(size_t)z * N + (size_t)v * P.W + u] - G.owner_base - 1;
     if (t >= 0 && u >= 2 && u < P.W - 2) {
         const uint4* own_line =
             reinterpret_cast<const uint4*>(G.desc + (size_t)z * N * 16) + (size_t)line * P.W;
@@ -889,7 +891,7 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P, 
     for (int x = (int)threadIdx.x - side * half; x < P.DW; x += half) {
         const int u = x * mul;
         float out = -10.f;
-        const int t = own_t[u];
+        const int t = own_t[u] - G.owner_base - 1;   // < 0: no triangle of this group covers the pixel
         const bool live = t >= 0 && u >= 2 && u < P.W - 2;
         // every disparity up to disp_max warps inside [2, W-2) for the whole wave?
         const bool inner = side ? u + P.disp_max < P.W - 2 : u - P.disp_max >= 2;
@@ -1697,8 +1699,7 @@ void launch_prior(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
 
 void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                   int32_t total_tri, const GroupDev& G) {
-    hipStream_t s = (hipStream_t)cx.stream;
-    (void)hipMemsetAsync(G.owner, 0xFF, (size_t)2 * g * d.W * d.H * sizeof(int32_t), s);
+    // no clearing: the engine hands every group a fresh owner_base above all values stored so far
     if (total_tri == 0) return;
     LAUNCH("k_owner", k_owner<false>, dim3((total_tri + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
            p.subsampling);

@@ -114,6 +114,7 @@ struct GroupDev {
     int32_t* owner;            // [g][2][N]
     float* Draw;               // [g][2][DN]
     int32_t plane_radius;
+    int32_t owner_base;        // owner[] holds owner_base + 1 + triangle; values <= owner_base are stale
     int32_t prior_absmax;      // max |P[dd]|, dd <= plane_radius (selects the keyed match kernel)
 };
 
