@@ -140,7 +140,6 @@ struct Lane {
     float* D = nullptr;            // [gcap][2][DN]  (host-output mode)
     float* tmp = nullptr;          // [gcap][2][DN]
     int32_t* labels = nullptr;
-    int32_t* runlen = nullptr;
     int32_t* counts = nullptr;
     // pinned host
     int16_t* h_dcan = nullptr;
@@ -158,9 +157,9 @@ struct Lane {
         (void)hipFree(img); (void)hipFree(desc); (void)hipFree(dcan); (void)hipFree(owner);
         (void)hipFree(prior_dev); (void)hipFree(raster); (void)hipFree(planes); (void)hipFree(seed);
         (void)hipFree(mask); (void)hipFree(Draw); (void)hipFree(D); (void)hipFree(tmp);
-        (void)hipFree(labels); (void)hipFree(runlen); (void)hipFree(counts);
+        (void)hipFree(labels); (void)hipFree(counts);
         img = desc = prior_dev = nullptr; dcan = nullptr; owner = nullptr; raster = nullptr;
-        planes = Draw = D = tmp = nullptr; seed = mask = nullptr; labels = runlen = counts = nullptr;
+        planes = Draw = D = tmp = nullptr; seed = mask = nullptr; labels = counts = nullptr;
         (void)hipHostFree(h_dcan); (void)hipHostFree(h_prior); (void)hipHostFree(h_img);
         h_dcan = nullptr; h_prior = nullptr; h_img = nullptr;
         W = H = 0;
@@ -189,7 +188,6 @@ struct Lane {
         HIP_TRY(hipMalloc(&D, G2 * DN * sizeof(float)));
         HIP_TRY(hipMalloc(&tmp, G2 * DN * sizeof(float)));
         HIP_TRY(hipMalloc(&labels, G2 * DN * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&runlen, G2 * DN * sizeof(int32_t)));
         HIP_TRY(hipMalloc(&counts, G2 * DN * sizeof(int32_t)));
         const size_t nc = (size_t)d.Wc * d.Hc;
         HIP_TRY(hipMalloc(&dcan, g * nc * sizeof(int16_t)));
@@ -554,7 +552,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         rc = tap_dev(L, taps, SVH_ELAS_D1_RAW, L.Draw, DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_RAW, L.Draw + DN, DN); if (rc) return rc;
     }
-    const PostScratch ps = {L.tmp, L.labels, L.runlen, L.counts};
+    const PostScratch ps = {L.tmp, L.labels, L.counts};
     const int nside = p.postprocess_only_left ? 1 : 2;
     if (fused_tail) {
         // fused tail: the L/R check writes the maps that get post-processed into

@@ -1136,8 +1136,7 @@ __global__ __launch_bounds__(256) void k_seg_tile(GroupDev G, DevMaps m, PostScr
             if (root == i) size = sC[i];   // this pixel is the tile-local root
         }
         S.labels[zo + gi] = label;
-        S.runlen[zo + gi] = size;
-        S.counts[zo + gi] = size;
+        S.counts[zo + gi] = size;   // > 0 exactly at the tile-local roots: also their marker for k_seg_sum
     }
 }
 
@@ -1186,7 +1185,9 @@ __global__ __launch_bounds__(256) void k_seg_sum(GroupDev G, PostScratch S, int 
     if (i >= n) return;
     if (!G.hdr->active[blockIdx.y / nside]) return;
     const size_t zo = (size_t)blockIdx.y * n;
-    const int size = S.runlen[zo + i];
+    // a tile-local root that is not a global root is never added to, so its entry still is the
+    // tile-local size written by k_seg_tile (the seam merges of k_seg_border changed labels only)
+    const int size = S.counts[zo + i];
     if (size > 0) {
         int32_t* L = S.labels + zo;
         const int root = uf_find(L, i);

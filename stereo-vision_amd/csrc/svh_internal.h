@@ -139,8 +139,7 @@ void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int
 struct PostScratch {
     float* tmp;
     int32_t* labels;
-    int32_t* runlen;
-    int32_t* counts;
+    int32_t* counts;   // tile-local sizes at tile roots (0 elsewhere), then component sizes at roots
 };
 void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                      int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& s);
