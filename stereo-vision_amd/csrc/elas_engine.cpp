@@ -577,13 +577,17 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         rc = tap_dev(L, taps, SVH_ELAS_D1_SEG, out.D[0], DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_SEG, out.D[1], DN); if (rc) return rc;
     }
-    launch_gap(cx, p, d, g, nside, G, out, ps);
-    if (taps && taps->enabled) {
-        rc = tap_dev(L, taps, SVH_ELAS_D1_GAP, out.D[0], DN); if (rc) return rc;
-        rc = tap_dev(L, taps, SVH_ELAS_D2_GAP, out.D[1], DN); if (rc) return rc;
+    if (!tapping && post_tiles_ok(p)) {
+        launch_gap_mean_tiles(cx, p, d, g, nside, G, out, ps);   // gap + adaptive mean, two tile kernels
+    } else {
+        launch_gap(cx, p, d, g, nside, G, out, ps);
+        if (taps && taps->enabled) {
+            rc = tap_dev(L, taps, SVH_ELAS_D1_GAP, out.D[0], DN); if (rc) return rc;
+            rc = tap_dev(L, taps, SVH_ELAS_D2_GAP, out.D[1], DN); if (rc) return rc;
+        }
+        if (p.filter_adaptive_mean) launch_adaptive_mean(cx, p, d, g, nside, G, out, ps);
+        if (p.filter_median) launch_median(cx, d, g, nside, G, out, ps);
     }
-    if (p.filter_adaptive_mean) launch_adaptive_mean(cx, p, d, g, nside, G, out, ps);
-    if (p.filter_median) launch_median(cx, d, g, nside, G, out, ps);
 
 copy_out:
     if (!io.out_device)

@@ -1814,6 +1814,168 @@ void launch_gap(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, in
     }
 }
 
+// ---------------------------------------------------------------------------
+// Tile versions of E14 + E15 for the default configuration (gap <= 4, no corner extrapolation,
+// adaptive mean, no median): the row pass and the column pass of a filter run in ONE kernel on a
+// 64x32 tile whose halo (the column pass needs row-pass results a few rows up and down) is
+// recomputed in LDS.  gap: D -> tmp, mean: tmp -> D, so two map round trips instead of four.
+// The arithmetic, bounds and tap order are those of k_gap_local / k_adaptive_mean above.
+// ---------------------------------------------------------------------------
+constexpr int QX = 64, QY = 32;
+
+// nearest valid neighbour on each side (<= gap away, inside [0, len)) -> interpolated value
+__device__ __forceinline__ float gap_pick(float val, const float* line, int stride, int pos, int len, int gap) {
+    if (val >= 0) return val;
+    int l = 0, r = 0;
+    float vl = 0.f, vr = 0.f;
+#pragma unroll
+    for (int k = 4; k >= 1; k--) {
+        if (k <= gap && pos - k >= 0) {
+            const float a = line[-k * stride];
+            if (a >= 0) { l = k; vl = a; }
+        }
+        if (k <= gap && pos + k < len) {
+            const float b = line[k * stride];
+            if (b >= 0) { r = k; vr = b; }
+        }
+    }
+    return (l && r && r <= gap - l + 1) ? gap_value(vl, vr) : val;
+}
+
+__global__ __launch_bounds__(256) void k_gap_tile(GroupDev G, DevMaps m, PostScratch S, int nside, int DW,
+                                                  int DH, int gap) {
+    constexpr int HG = 4;
+    __shared__ float sA[QY + 2 * HG][QX + 2 * HG];   // D with halo
+    __shared__ float sB[QY + 2 * HG][QX];            // row-pass result, rows with halo
+    int pair;
+    const float* D = post_map(m, blockIdx.z, nside, &pair);
+    if (!G.hdr->active[pair]) return;
+    float* out = S.tmp + (size_t)blockIdx.z * DW * DH;
+    const int x0 = blockIdx.x * QX, y0 = blockIdx.y * QY;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    for (int i = tid; i < (QY + 2 * HG) * (QX + 2 * HG); i += 256) {
+        const int r = i / (QX + 2 * HG), c = i - r * (QX + 2 * HG);
+        const int gy = y0 - HG + r, gx = x0 - HG + c;
+        sA[r][c] = (gy >= 0 && gy < DH && gx >= 0 && gx < DW) ? D[(size_t)gy * DW + gx] : -10.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < (QY + 2 * HG) * QX; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const int gx = x0 + c;
+        sB[r][c] = gx < DW ? gap_pick(sA[r][c + HG], &sA[r][c + HG], 1, gx, DW, gap) : -10.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < QY * QX; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const int gy = y0 + r, gx = x0 + c;
+        if (gy < DH && gx < DW)
+            out[(size_t)gy * DW + gx] = gap_pick(sB[r + HG][c], &sB[r + HG][c], QX, gy, DH, gap);
+    }
+}
+
+// one 8- or 4-tap adaptive-mean evaluation; `line` points at the centre, taps at (first + k - pos)
+template <int kTaps>
+__device__ __forceinline__ bool am_eval(const float* line, int stride, int pos, float centre, float* res) {
+    constexpr int back = kTaps == 8 ? 3 : 1, lead = kTaps - 1;
+    const int first = pos + back - lead;
+    float ws[kTaps], fs[kTaps];
+#pragma unroll
+    for (int s = 0; s < kTaps; s++) {
+        const int k = (s - first) & (kTaps - 1);
+        const float t = line[(first + k - pos) * stride];
+        const float w = am_weight(t, centre);
+        ws[s] = w;
+        fs[s] = __fmul_rn(t, w);
+    }
+    float wl[4], fl[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (kTaps == 8) {
+            wl[j] = __fadd_rn(ws[j], ws[j + kTaps / 2]);
+            fl[j] = __fadd_rn(fs[j], fs[j + kTaps / 2]);
+        } else {
+            wl[j] = ws[j];
+            fl[j] = fs[j];
+        }
+    }
+    const float wsum = __fadd_rn(__fadd_rn(__fadd_rn(wl[0], wl[1]), wl[2]), wl[3]);
+    const float fsum = __fadd_rn(__fadd_rn(__fadd_rn(fl[0], fl[1]), fl[2]), fl[3]);
+    if (wsum > 0) {
+        const float dv = __fdiv_rn(fsum, wsum);
+        if (dv >= 0) {
+            *res = dv;
+            return true;
+        }
+    }
+    return false;
+}
+
+template <int kTaps>
+__global__ __launch_bounds__(256) void k_mean_tile(GroupDev G, DevMaps m, PostScratch S, int nside, int DW,
+                                                   int DH) {
+    constexpr int back = kTaps == 8 ? 3 : 1, lead = kTaps - 1;
+    constexpr int HL = lead - back, HR = back;         // taps reach HL before and HR after the centre
+    __shared__ float sA[QY + HL + HR][QX + HL + HR];   // input (negatives as -10) with halo
+    __shared__ float sB[QY + HL + HR][QX];             // horizontal-pass result (D_tmp), rows with halo
+    int pair;
+    float* D = post_map(m, blockIdx.z, nside, &pair);
+    if (!G.hdr->active[pair]) return;
+    const float* in = S.tmp + (size_t)blockIdx.z * DW * DH;   // written by k_gap_tile
+    const int x0 = blockIdx.x * QX, y0 = blockIdx.y * QY;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    constexpr int AW = QX + HL + HR, AH = QY + HL + HR;
+    for (int i = tid; i < AH * AW; i += 256) {
+        const int r = i / AW, c = i - r * AW;
+        const int gy = y0 - HL + r, gx = x0 - HL + c;
+        float val = -10.f;
+        if (gy >= 0 && gy < DH && gx >= 0 && gx < DW) {
+            val = in[(size_t)gy * DW + gx];
+            if (val < 0) val = -10.f;     // D_copy initialisation (elas.cpp:1553-1560)
+        }
+        sA[r][c] = val;
+    }
+    __syncthreads();
+    // horizontal pass -> D_tmp: -10 where the input is invalid, 0 where valid but never written
+    for (int i = tid; i < AH * QX; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const int gy = y0 - HL + r, gx = x0 + c;
+        const float centre = sA[r][c + HL];
+        float res = centre < 0 ? -10.f : 0.f;
+        if (gy >= 3 && gy < DH - 3 && gx >= lead - back && gx <= DW - 1 - back)
+            am_eval<kTaps>(&sA[r][c + HL], 1, gx, centre, &res);
+        sB[r][c] = res;
+    }
+    __syncthreads();
+    // vertical pass on D_tmp; where it does not fire the map keeps the filter's input
+    for (int i = tid; i < QY * QX; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const int gy = y0 + r, gx = x0 + c;
+        if (gy >= DH || gx >= DW) continue;
+        float res = in[(size_t)gy * DW + gx];
+        if (gx >= 3 && gx < DW - 3 && gy >= lead - back && gy <= DH - 1 - back)
+            am_eval<kTaps>(&sB[r + HL][c], QX, gy, sB[r + HL][c], &res);
+        D[(size_t)gy * DW + gx] = res;
+    }
+}
+
+// the two tile kernels replace k_gap_rows/cols + k_mean_h/v (four map round trips -> two)
+bool post_tiles_ok(const svh_elas_params& p) {
+    static const bool off = getenv("SVH_NO_POST_TILES") != nullptr;
+    int gap = p.ipol_gap_width;
+    if (p.subsampling) gap = p.ipol_gap_width / 2 + 1;
+    return !off && gap <= 4 && !p.add_corners && p.filter_adaptive_mean && !p.filter_median;
+}
+
+void launch_gap_mean_tiles(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                           int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& S) {
+    int gap = p.ipol_gap_width;
+    if (p.subsampling) gap = p.ipol_gap_width / 2 + 1;  // elas.cpp:1340
+    const dim3 gr((d.DW + QX - 1) / QX, (d.DH + QY - 1) / QY, g * nside), b(64, 4);
+    LAUNCH("k_gap_tile", k_gap_tile, gr, b, G, out, S, nside, d.DW, d.DH, gap);
+    if (p.subsampling) LAUNCH("k_mean_tile", k_mean_tile<4>, gr, b, G, out, S, nside, d.DW, d.DH);
+    else               LAUNCH("k_mean_tile", k_mean_tile<8>, gr, b, G, out, S, nside, d.DW, d.DH);
+}
+
 void launch_adaptive_mean(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                           int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& S) {
     const dim3 gr = grid2d(d.DW, d.DH, g * nside), b(64, 4);

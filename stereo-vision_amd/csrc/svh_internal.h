@@ -141,6 +141,11 @@ struct PostScratch {
     int32_t* labels;
     int32_t* counts;   // tile-local sizes at tile roots (0 elsewhere), then component sizes at roots
 };
+// default configuration only (see post_tiles_ok): gap interpolation + adaptive mean as two tile
+// kernels (D -> tmp -> D); the caller must skip launch_gap / launch_adaptive_mean then
+bool post_tiles_ok(const svh_elas_params& p);
+void launch_gap_mean_tiles(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                           int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& S);
 void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                      int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& s);
 void launch_gap(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,

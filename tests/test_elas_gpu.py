@@ -341,3 +341,26 @@ def test_concurrent_batches_share_the_lane_pool(svhip):
         for i in range(n):
             rc, a, b = want[(k, i)]
             assert rc == 0 and np.array_equal(a, D1[i]) and np.array_equal(b, D2[i])
+
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
+@pytest.mark.parametrize("seed,w,h,kw", [
+    (61, 320, 200, {}), (62, 333, 117, {"postprocess_only_left": 0}),
+    (63, 401, 163, {"ipol_gap_width": 4, "postprocess_only_left": 0}),
+    (64, 322, 201, {"subsampling": 1}), (65, 259, 131, {"subsampling": 1, "ipol_gap_width": 6}),
+    (66, 1242, 375, {"ipol_gap_width": 1}), (67, 96, 64, {"disp_max": 40}),
+    (68, 641, 97, {"speckle_size": 50, "lr_threshold": 1}),
+])
+def test_tile_post_kernels_match_oracle(seed, w, h, kw, svhip, oracle_lib):
+    """without taps the default configuration runs gap interpolation + adaptive mean as two
+    fused tile kernels (k_gap_tile, k_mean_tile); the final maps must equal the oracle's, and the
+    unfused kernels' (taps on) bit for bit -- ragged sizes, both resolutions, gap widths 1..4"""
+    prm = H.robotics(**kw)
+    l, r = H.synth_pair(w, h, seed, dmax=min(48, prm.disp_max - 8))
+    rc, D1, D2 = svhip.Elas(prm).process(l, r)             # tile kernels
+    want = H.oracle_elas_run(prm, l, r)
+    assert rc == want.status == 0
+    assert np.array_equal(D1.ravel(), np.asarray(want[H.D1_FINAL]).ravel())
+    assert np.array_equal(D2.ravel(), np.asarray(want[H.D2_FINAL]).ravel())
+    got = product_run(svhip, prm, l, r)                    # unfused kernels (taps)
+    assert np.array_equal(D1.ravel(), np.asarray(got[H.D1_FINAL]).ravel())
+    assert np.array_equal(D2.ravel(), np.asarray(got[H.D2_FINAL]).ravel())
