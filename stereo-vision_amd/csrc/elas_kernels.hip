@@ -513,6 +513,9 @@ __global__ __launch_bounds__(256) void k_prior(GroupDev G, int total_tri) {
     r.pb = side ? pl[4] : pl[1];
     r.pc = side ? pl[5] : pl[2];
     r.valid = ((double)fabsf(pa) < 0.7 && (double)fabsf(pd) < 0.7) ? 1 : 0;
+    r.slot = slot;      // k_owner takes these from the record instead of scanning tri_end[]
+    r.first = first;
+    r.pad_[0] = 0;
     G.raster[T] = r;
 }
 
@@ -582,13 +585,12 @@ __global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri, int W,
     const int T = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
     const int lane = threadIdx.x & 63;
     if (T >= total_tri) return;
-    int first;
-    const int slot = tri_slot(G.hdr, T, &first);
+    const TriRaster tr = G.raster[T];
+    const int slot = tr.slot, first = tr.first;
     // stored value = owner_base + 1 + triangle index: everything <= owner_base is a leftover of
     // an earlier group and reads as "no triangle", so the maps need no clearing between groups
     const int t = G.owner_base + 1 + (T - first);
     int32_t* owner = G.owner + (size_t)slot * W * H;
-    const TriRaster tr = G.raster[T];
     const int cl = lane & 15, rp = lane >> 4;
 #pragma unroll
     for (int part = 0; part < 2; part++) {

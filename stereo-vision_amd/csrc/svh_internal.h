@@ -48,7 +48,8 @@ struct alignas(16) TriRaster {
     float ACa, ACb;            // long edge
     float ABa, ABb;            // first part
     float BCa, BCb;            // second part
-    int32_t pad_[3];
+    int32_t slot, first;   // (pair, side) slot of the triangle and the index of the slot's first triangle
+    int32_t pad_[1];
 };
 static_assert(sizeof(TriRaster) == 64, "TriRaster is one 64-byte record");
 
