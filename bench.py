@@ -43,8 +43,8 @@ ALG_BYTES_PER_PIXEL = {
     "k_match": 72.0,        # 2 x (16 own + 16 other + 4 out)
     "k_lr": 16.0,
     "k_seg_tile": 8.0, "k_seg_border": 8.0, "k_seg_sum": 8.0, "k_seg_mask": 8.0,
-    "k_gap_rows": 8.0, "k_gap_cols": 8.0,
-    "k_mean_h": 8.0, "k_mean_v": 8.0,
+    "k_gap_rows": 8.0, "k_gap_cols": 8.0, "k_gap_tile": 16.0,     # tile kernels: rows + columns in one
+    "k_mean_h": 8.0, "k_mean_v": 8.0, "k_mean_tile": 16.0,
     "k_owner": 8.0, "k_owner_fix": 8.0,
 }
 
