@@ -546,6 +546,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     }
     const bool tapping = taps && taps->enabled;
     const bool fused_tail = !tapping && g_fused.load() && post_fusable(p);
+    const bool tiles = !tapping && !fused_tail && post_tiles_ok(p);   // gap + mean (+ speckle mask) tile kernels
     // the row kernel also applies the L/R check (its inputs are the row it just matched)
     const bool lr_done = launch_match(cx, p, d, g, G, fused_tail ? nullptr : &out, tapping);
     if (tapping) {
@@ -572,12 +573,12 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         rc = tap_dev(L, taps, SVH_ELAS_D1_LR, out.D[0], DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_LR, out.D[1], DN); if (rc) return rc;
     }
-    launch_segments(cx, p, d, g, nside, G, out, ps);
+    launch_segments(cx, p, d, g, nside, G, out, ps, /*mask=*/!tiles);
     if (taps && taps->enabled) {
         rc = tap_dev(L, taps, SVH_ELAS_D1_SEG, out.D[0], DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_SEG, out.D[1], DN); if (rc) return rc;
     }
-    if (!tapping && post_tiles_ok(p)) {
+    if (tiles) {
         launch_gap_mean_tiles(cx, p, d, g, nside, G, out, ps);   // gap + adaptive mean, two tile kernels
     } else {
         launch_gap(cx, p, d, g, nside, G, out, ps);

@@ -1759,13 +1759,14 @@ void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int
 }
 
 void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
-                     int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& S) {
+                     int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& S, bool mask) {
     const int n = d.DW * d.DH, z = g * nside;
     int min_size = p.speckle_size;
     if (p.subsampling) min_size = (int)(sqrtf((float)p.speckle_size) * 2);  // elas.cpp:1218
     const dim3 lin((n + 255) / 256, z), b256(256);
     launch_segments_label(cx, p, d, g, nside, G, out, S);
-    LAUNCH("k_seg_mask", k_seg_mask, lin, b256, G, out, S, nside, n, min_size);
+    // mask == false: the caller follows up with the tile kernels, which apply the verdict on load
+    if (mask) LAUNCH("k_seg_mask", k_seg_mask, lin, b256, G, out, S, nside, n, min_size);
 }
 
 bool post_fusable(const svh_elas_params& p) {
@@ -1844,8 +1845,10 @@ __device__ __forceinline__ float gap_pick(float val, const float* line, int stri
     return (l && r && r <= gap - l + 1) ? gap_value(vl, vr) : val;
 }
 
+// min_size > 0: the speckle verdict (E13, k_seg_mask) is applied while the tile is loaded --
+// a pixel of a component below min_size reads as -10 -- so the masked map never goes to memory
 __global__ __launch_bounds__(256) void k_gap_tile(GroupDev G, DevMaps m, PostScratch S, int nside, int DW,
-                                                  int DH, int gap) {
+                                                  int DH, int gap, int min_size) {
     constexpr int HG = 4;
     __shared__ float sA[QY + 2 * HG][QX + 2 * HG];   // D with halo
     __shared__ float sB[QY + 2 * HG][QX];            // row-pass result, rows with halo
@@ -1855,10 +1858,39 @@ __global__ __launch_bounds__(256) void k_gap_tile(GroupDev G, DevMaps m, PostScr
     float* out = S.tmp + (size_t)blockIdx.z * DW * DH;
     const int x0 = blockIdx.x * QX, y0 = blockIdx.y * QY;
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    for (int i = tid; i < (QY + 2 * HG) * (QX + 2 * HG); i += 256) {
-        const int r = i / (QX + 2 * HG), c = i - r * (QX + 2 * HG);
-        const int gy = y0 - HG + r, gx = x0 - HG + c;
-        sA[r][c] = (gy >= 0 && gy < DH && gx >= 0 && gx < DW) ? D[(size_t)gy * DW + gx] : -10.f;
+    {
+        // the label -> root -> size look-ups are dependent loads: each level is fetched for all
+        // of a thread's entries before the next one starts
+        constexpr int AW = QX + 2 * HG, NE = ((QY + 2 * HG) * AW + 255) / 256;
+        const int32_t* L = S.labels + (size_t)blockIdx.z * DW * DH;
+        const int32_t* Cn = S.counts + (size_t)blockIdx.z * DW * DH;
+        float val[NE];
+        int lab[NE];
+#pragma unroll
+        for (int k = 0; k < NE; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / AW, c = i - r * AW;
+            const int gy = y0 - HG + r, gx = x0 - HG + c;
+            const bool in = i < (QY + 2 * HG) * AW && gy >= 0 && gy < DH && gx >= 0 && gx < DW;
+            val[k] = in ? D[(size_t)gy * DW + gx] : -10.f;
+            lab[k] = (in && min_size > 0) ? L[(size_t)gy * DW + gx] : -1;
+        }
+        if (min_size > 0) {
+#pragma unroll
+            for (int k = 0; k < NE; k++)
+                if (lab[k] >= 0) lab[k] = L[lab[k]];           // tile root -> component root
+#pragma unroll
+            for (int k = 0; k < NE; k++)
+                if (lab[k] >= 0 && Cn[lab[k]] < min_size) val[k] = -10.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NE; k++) {
+            const int i = tid + 256 * k;
+            if (i < (QY + 2 * HG) * AW) {
+                const int r = i / AW, c = i - r * AW;
+                sA[r][c] = val[k];
+            }
+        }
     }
     __syncthreads();
     for (int i = tid; i < (QY + 2 * HG) * QX; i += 256) {
@@ -1973,7 +2005,9 @@ void launch_gap_mean_tiles(const LaunchCtx& cx, const svh_elas_params& p, const 
     int gap = p.ipol_gap_width;
     if (p.subsampling) gap = p.ipol_gap_width / 2 + 1;  // elas.cpp:1340
     const dim3 gr((d.DW + QX - 1) / QX, (d.DH + QY - 1) / QY, g * nside), b(64, 4);
-    LAUNCH("k_gap_tile", k_gap_tile, gr, b, G, out, S, nside, d.DW, d.DH, gap);
+    int min_size = p.speckle_size;
+    if (p.subsampling) min_size = (int)(sqrtf((float)p.speckle_size) * 2);  // elas.cpp:1218
+    LAUNCH("k_gap_tile", k_gap_tile, gr, b, G, out, S, nside, d.DW, d.DH, gap, min_size > 1 ? min_size : 0);
     if (p.subsampling) LAUNCH("k_mean_tile", k_mean_tile<4>, gr, b, G, out, S, nside, d.DW, d.DH);
     else               LAUNCH("k_mean_tile", k_mean_tile<8>, gr, b, G, out, S, nside, d.DW, d.DH);
 }

@@ -148,7 +148,7 @@ bool post_tiles_ok(const svh_elas_params& p);
 void launch_gap_mean_tiles(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                            int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& S);
 void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
-                     int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& s);
+                     int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& s, bool mask = true);
 void launch_gap(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                 int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& s);
 void launch_adaptive_mean(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
