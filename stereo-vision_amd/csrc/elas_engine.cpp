@@ -5,18 +5,20 @@
 //
 //   device phase A   Sobel+descriptor (both images, one launch), support
 //                    candidate matching  ->  D_can (37 KB) to pinned host memory
-//   host             in-place lattice filters, Delaunay x2, planes, grid, prior
-//                    table  (~1 ms; serial in the reference as well)
-//   device phase B   triangle ownership, dense matching (both sides, one
-//                    launch), L/R check, speckle removal, gap interpolation,
-//                    adaptive mean / median  ->  D1, D2
+//   host             in-place lattice filters, Delaunay x2  (~0.4 ms; serial in the
+//                    reference as well), one packed upload (support, triangles, prior table)
+//   device phase B   planes + raster records, grid bit sets, triangle ownership, dense
+//                    matching of both maps with the L/R check (one launch), speckle
+//                    labelling, gap interpolation + adaptive mean tile kernels (or the
+//                    unfused kernels / median)  ->  D1, D2
 //
 // A "lane" owns one HIP stream, its device buffers (sized once per image
 // geometry and reused: callers construct an Elas per frame,
 // stereomapper/stereothread.cpp:113) and its pinned staging.  A single
-// svh_elas_process() borrows a lane on the calling thread; a batch spreads its
-// pairs over all lanes with one host worker per lane, so the host section of one
-// pair overlaps the device phases of the others.  No default-stream work, no
+// svh_elas_process() borrows a lane on the calling thread.  A batch runs G pairs
+// per launch ("group") on double-buffered workers: each worker owns two lanes and
+// overlaps the host section of group i with phase A of group i+1 (and the tail of
+// group i-1); workers sleep-poll instead of spinning.  No default-stream work, no
 // process-global mutable state besides the lane pool (mutex protected), so
 // objects may be used concurrently from different threads like the reference's
 // (maindialog.cpp:456-465, 514-518).

@@ -1,12 +1,15 @@
 // HIP kernels (gfx950 / CDNA4) of the ELAS dense-disparity path.
 //
-// All of this is integer SAD / rank / stencil work bounded by memory traffic,
-// not by arithmetic: no MFMA.  Design rules followed throughout:
+// All of this is integer SAD / rank / stencil work: no MFMA.  The two matching kernels are
+// bound by VALU issue (v_sad_u8 and its bookkeeping, measured with the SQ counters), the
+// rest by HBM traffic and latency.  Design rules followed throughout:
 //   * wavefront = 64 lanes; every per-pixel kernel maps lanes to consecutive u
 //     so descriptor traffic is 16 B/lane = 1 KiB per wave instruction;
 //   * 8-bit tiles are staged through LDS once and gathered from there;
 //   * SAD uses v_sad_u8 (__builtin_amdgcn_sad_u8), arg-min over disparities is
-//     a packed (cost<<16|d) wave reduction with __shfl_xor;
+//     a packed (cost<<16|d) wave reduction on DPP (v_min_u32_dpp);
+//   * workgroup ids are mapped to work XCD-aware where neighbouring blocks re-read data;
+//   * passes over the maps are fused when a tile (or a row) holds all inputs of the next one;
 //   * float expressions that decide pixel ownership or d_plane are written with
 //     __fmul_rn/__fadd_rn so they are never contracted into FMAs (the reference
 //     is built -msse3 without FMA).
