@@ -111,14 +111,12 @@ int32_t svh_elas_process_batch_device(svh_elas* e, int32_t n,
                                       float* dD1, float* dD2, size_t out_stride,
                                       const int32_t* dims, int32_t* status);
 
-/* number of pipeline lanes (streams + host workers) the engine uses per device */
+/* number of batch workers the engine runs per device (each is double-buffered: two HIP streams
+ * and buffer sets, the host stage of one group overlaps the device stages of the next) */
 int32_t svh_elas_set_lanes(int32_t lanes);
 /* pairs a lane pushes through each kernel launch (1..16): batches are cut into
  * groups of this many consecutive pairs */
 int32_t svh_elas_set_group(int32_t pairs);
-/* 1: mask + gap interpolation + adaptive mean run as one LDS-tiled kernel when
- * the parameters allow it; 0 (default, faster on MI355X so far): separate kernels */
-int32_t svh_elas_set_fused_post(int32_t on);
 
 /* Stage taps for parity tests: after a successful svh_elas_process() the
  * intermediate of the given stage (of the last pair processed through handle

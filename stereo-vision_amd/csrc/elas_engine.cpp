@@ -251,7 +251,6 @@ static std::mutex g_mu;
 static std::map<int, Pool*> g_pools;
 static std::atomic<int> g_lanes{8};
 static std::atomic<int> g_group{4};
-static std::atomic<int> g_fused{0};   // measured slower than the separate kernels on MI355X (133 vs 104 us for G=8): off by default
 
 static Pool* pool_for(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -547,29 +546,15 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         out.D[0] = L.D; out.D[1] = L.D + DN; out.stride[0] = out.stride[1] = 2 * DN;
     }
     const bool tapping = taps && taps->enabled;
-    const bool fused_tail = !tapping && g_fused.load() && post_fusable(p);
-    const bool tiles = !tapping && !fused_tail && post_tiles_ok(p);   // gap + mean (+ speckle mask) tile kernels
+    const bool tiles = !tapping && post_tiles_ok(p);   // gap + mean (+ speckle mask) tile kernels
     // the row kernel also applies the L/R check (its inputs are the row it just matched)
-    const bool lr_done = launch_match(cx, p, d, g, G, fused_tail ? nullptr : &out, tapping);
+    const bool lr_done = launch_match(cx, p, d, g, G, &out, tapping);
     if (tapping) {
         rc = tap_dev(L, taps, SVH_ELAS_D1_RAW, L.Draw, DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_RAW, L.Draw + DN, DN); if (rc) return rc;
     }
     const PostScratch ps = {L.tmp, L.labels, L.counts};
     const int nside = p.postprocess_only_left ? 1 : 2;
-    if (fused_tail) {
-        // fused tail: the L/R check writes the maps that get post-processed into
-        // scratch, the others straight to the output; one kernel does the rest
-        DevMaps mid = out;
-        for (int k = 0; k < nside; k++) {
-            mid.D[k] = L.tmp + (size_t)k * DN;
-            mid.stride[k] = (size_t)nside * DN;
-        }
-        launch_lr(cx, p, d, g, G, mid);
-        launch_segments_label(cx, p, d, g, nside, G, mid, ps);
-        launch_post_fused(cx, p, d, g, nside, G, mid, out, ps);
-        goto copy_out;
-    }
     if (!lr_done) launch_lr(cx, p, d, g, G, out);
     if (taps && taps->enabled) {
         rc = tap_dev(L, taps, SVH_ELAS_D1_LR, out.D[0], DN); if (rc) return rc;
@@ -592,7 +577,6 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         if (p.filter_median) launch_median(cx, d, g, nside, G, out, ps);
     }
 
-copy_out:
     if (!io.out_device)
         for (int32_t j = 0; j < g; j++) {
             if (!hdr->active[j]) continue;
@@ -922,10 +906,6 @@ int32_t svh_elas_support_from_candidates(const svh_elas_params* p, int32_t width
     return n;
 }
 
-int32_t svh_elas_set_fused_post(int32_t on) {
-    g_fused.store(on ? 1 : 0);
-    return SVH_OK;
-}
 
 int32_t svh_elas_set_group(int32_t pairs) {
     if (pairs < 1) pairs = 1;

@@ -1459,170 +1459,6 @@ __global__ __launch_bounds__(256) void k_median(GroupDev G, DevMaps m, PostScrat
     out[i] = res;
 }
 
-// ---------------------------------------------------------------------------
-// Fused tail of the pipeline for the ROBOTICS-style configuration (adaptive mean
-// on, median off, small gap width, no corner extrapolation):
-//   speckle mask (E13, last step) -> gap rows -> gap columns (E14) ->
-//   adaptive mean horizontal -> vertical (E15)
-// Every stage is a pure function of the previous stage in a small
-// neighbourhood, so a block computes them back to back on an LDS tile with a
-// halo of gap+4 pixels; the valid area shrinks stage by stage and the 64x16
-// interior is written once.  Image borders are handled with global coordinates
-// exactly like the separate kernels (a pixel outside the image reads as -10 =
-// invalid, which is what the bound checks of the separate kernels amount to).
-// Replaces five launches and four global round trips of the map.
-// ---------------------------------------------------------------------------
-constexpr int PX = 64, PY = 16, PH = 8;           // tile and halo (gap <= 4)
-constexpr int RW = PX + 2 * PH, RH = PY + 2 * PH;  // 80 x 32 region
-
-__global__ __launch_bounds__(256) void k_post_fused(GroupDev G, DevMaps in, DevMaps out,
-                                                    PostScratch S, int nside, int DW, int DH,
-                                                    int gap, int min_size) {
-    __shared__ float A[RH][RW + 1];
-    __shared__ float B[RH][RW + 1];
-    int pair;
-    const float* D = post_map(in, blockIdx.z, nside, &pair);
-    if (!G.hdr->active[pair]) return;
-    float* O = post_map(out, blockIdx.z, nside, &pair);
-    const size_t zo = (size_t)blockIdx.z * DW * DH;
-    const int x0 = blockIdx.x * PX - PH, y0 = blockIdx.y * PY - PH;
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-
-    // stage 0: speckle mask (k_seg_mask), -10 outside the image
-    for (int i = tid; i < RW * RH; i += 256) {
-        const int r = i / RW, c = i - r * RW;
-        const int gx = x0 + c, gy = y0 + r;
-        float val = -10.f;
-        if (gx >= 0 && gx < DW && gy >= 0 && gy < DH) {
-            const int gi = gy * DW + gx;
-            val = D[gi];
-            const int s = S.labels[zo + gi];
-            if (s < 0) {
-                if (1 < min_size) val = -10.f;
-            } else if (S.counts[zo + S.labels[zo + s]] < min_size) {
-                val = -10.f;
-            }
-        }
-        A[r][c] = val;
-    }
-    __syncthreads();
-    // stage 1: gap interpolation along rows, A -> B
-    for (int i = tid; i < RW * RH; i += 256) {
-        const int r = i / RW, c = i - r * RW;
-        float val = A[r][c];
-        if (!(val >= 0)) {
-            int l = 0, rr = 0;
-            for (int k = 1; k <= gap && c - k >= 0; k++)
-                if (A[r][c - k] >= 0) {
-                    l = k;
-                    break;
-                }
-            if (l) {
-                for (int k = 1; k <= gap - l + 1 && c + k < RW; k++)
-                    if (A[r][c + k] >= 0) {
-                        rr = k;
-                        break;
-                    }
-                if (rr) val = gap_value(A[r][c - l], A[r][c + rr]);
-            }
-        }
-        B[r][c] = val;
-    }
-    __syncthreads();
-    // stage 2: gap interpolation along columns, B -> A
-    for (int i = tid; i < RW * RH; i += 256) {
-        const int r = i / RW, c = i - r * RW;
-        float val = B[r][c];
-        if (!(val >= 0)) {
-            int l = 0, rr = 0;
-            for (int k = 1; k <= gap && r - k >= 0; k++)
-                if (B[r - k][c] >= 0) {
-                    l = k;
-                    break;
-                }
-            if (l) {
-                for (int k = 1; k <= gap - l + 1 && r + k < RH; k++)
-                    if (B[r + k][c] >= 0) {
-                        rr = k;
-                        break;
-                    }
-                if (rr) val = gap_value(B[r - l][c], B[r + rr][c]);
-            }
-        }
-        A[r][c] = val;
-    }
-    __syncthreads();
-    // stage 3: adaptive mean, horizontal, A -> B (taps c-4..c+3, slot = position % 8)
-    for (int i = tid; i < RW * RH; i += 256) {
-        const int r = i / RW, c = i - r * RW;
-        const int gx = x0 + c, gy = y0 + r;
-        float res = A[r][c];
-        if (res < 0) res = -10.f;
-        if (c >= 4 && c + 3 < RW && gy >= 3 && gy < DH - 3 && gx >= 4 && gx <= DW - 4) {
-            float centre = A[r][c];
-            if (centre < 0) centre = -10.f;
-            float ws[8], fs[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int p = gx - 4 + k;           // global position of tap k
-                float tv = A[r][c - 4 + k];
-                if (tv < 0) tv = -10.f;
-                const float w = am_weight(tv, centre);
-                const int slot = p & 7;
-#pragma unroll
-                for (int q = 0; q < 8; q++)
-                    if (slot == q) {
-                        ws[q] = w;
-                        fs[q] = __fmul_rn(tv, w);
-                    }
-            }
-            const float wsum = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(ws[0], ws[4]), __fadd_rn(ws[1], ws[5])),
-                                                   __fadd_rn(ws[2], ws[6])), __fadd_rn(ws[3], ws[7]));
-            const float fsum = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(fs[0], fs[4]), __fadd_rn(fs[1], fs[5])),
-                                                   __fadd_rn(fs[2], fs[6])), __fadd_rn(fs[3], fs[7]));
-            if (wsum > 0) {
-                const float dv = __fdiv_rn(fsum, wsum);
-                if (dv >= 0) res = dv;
-            }
-        }
-        B[r][c] = res;
-    }
-    __syncthreads();
-    // stage 4: adaptive mean, vertical, B -> global (value kept where the filter does not fire: A)
-    for (int i = tid; i < PX * PY; i += 256) {
-        const int ty = i / PX, tx = i - ty * PX;
-        const int r = ty + PH, c = tx + PH;
-        const int gx = x0 + c, gy = y0 + r;
-        if (gx >= DW || gy >= DH) continue;
-        float res = A[r][c];
-        if (gx >= 3 && gx < DW - 3 && gy >= 4 && gy <= DH - 4) {
-            const float centre = B[r][c];
-            float ws[8], fs[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int p = gy - 4 + k;
-                const float tv = B[r - 4 + k][c];
-                const float w = am_weight(tv, centre);
-                const int slot = p & 7;
-#pragma unroll
-                for (int q = 0; q < 8; q++)
-                    if (slot == q) {
-                        ws[q] = w;
-                        fs[q] = __fmul_rn(tv, w);
-                    }
-            }
-            const float wsum = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(ws[0], ws[4]), __fadd_rn(ws[1], ws[5])),
-                                                   __fadd_rn(ws[2], ws[6])), __fadd_rn(ws[3], ws[7]));
-            const float fsum = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(fs[0], fs[4]), __fadd_rn(fs[1], fs[5])),
-                                                   __fadd_rn(fs[2], fs[6])), __fadd_rn(fs[3], fs[7]));
-            if (wsum > 0) {
-                const float dv = __fdiv_rn(fsum, wsum);
-                if (dv >= 0) res = dv;
-            }
-        }
-        O[gy * DW + gx] = res;
-    }
-}
 
 inline dim3 grid2d(int w, int h, int z = 1) { return dim3((w + 63) / 64, (h + 3) / 4, z); }
 
@@ -1772,10 +1608,6 @@ void launch_segments(const LaunchCtx& cx, const svh_elas_params& p, const Dims& 
     if (mask) LAUNCH("k_seg_mask", k_seg_mask, lin, b256, G, out, S, nside, n, min_size);
 }
 
-bool post_fusable(const svh_elas_params& p) {
-    return p.filter_adaptive_mean && !p.filter_median && !p.add_corners && !p.subsampling &&
-           p.ipol_gap_width >= 0 && p.ipol_gap_width <= PH - 4;
-}
 
 void launch_segments_label(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                            int32_t nside, const GroupDev& G, const DevMaps& in, const PostScratch& S) {
@@ -1794,13 +1626,6 @@ void launch_segments_label(const LaunchCtx& cx, const svh_elas_params& p, const 
     LAUNCH("k_seg_sum", k_seg_sum, lin, b256, G, S, nside, n, min_size);
 }
 
-void launch_post_fused(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
-                       int32_t nside, const GroupDev& G, const DevMaps& in, const DevMaps& out,
-                       const PostScratch& S) {
-    const dim3 grid((d.DW + PX - 1) / PX, (d.DH + PY - 1) / PY, g * nside), block(64, 4);
-    LAUNCH("k_post_fused", k_post_fused, grid, block, G, in, out, S, nside, d.DW, d.DH, p.ipol_gap_width,
-           p.speckle_size);
-}
 
 void launch_gap(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                 int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& S) {

@@ -155,14 +155,9 @@ void launch_adaptive_mean(const LaunchCtx& cx, const svh_elas_params& p, const D
                           int32_t nside, const GroupDev& G, const DevMaps& out, const PostScratch& s);
 void launch_median(const LaunchCtx& cx, const Dims& d, int32_t g, int32_t nside, const GroupDev& G,
                    const DevMaps& out, const PostScratch& s);
-// speckle labelling without the mask pass, then ONE kernel for mask + gap rows/cols +
-// adaptive mean h/v on LDS tiles: reads `in` (+labels/counts), writes `out`
-bool post_fusable(const svh_elas_params& p);
+// speckle labelling (tile union-find, seam merge, component sizes) without the mask pass
 void launch_segments_label(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                            int32_t nside, const GroupDev& G, const DevMaps& in, const PostScratch& s);
-void launch_post_fused(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
-                       int32_t nside, const GroupDev& G, const DevMaps& in, const DevMaps& out,
-                       const PostScratch& s);
 
 }  // namespace svh
 #endif

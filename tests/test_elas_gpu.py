@@ -154,23 +154,6 @@ def test_cxx_dropin_call_sites(mode, crop, case, svhip, tmp_path):
     assert np.array_equal(np.fromfile(o2, np.float32), z["d2"])
 
 
-def test_fused_post_kernel_equals_separate_kernels(svhip):
-    """optional one-kernel tail (mask+gap+adaptive mean on LDS tiles) == the separate kernels"""
-    lib = svhip.lib()
-    for crop, kw in (("urban3_640x240", {"postprocess_only_left": 0}), ("urban1_1242x375", {}),
-                     ("urban2_1242x375", {"ipol_gap_width": 4, "speckle_size": 150})):
-        l, r = H.golden_pair(crop)
-        prm = H.robotics(**kw)
-        try:
-            lib.svh_elas_set_fused_post(1)
-            rc1, A1, A2 = svhip.Elas(prm).process(l, r)
-        finally:
-            lib.svh_elas_set_fused_post(0)
-        rc0, B1, B2 = svhip.Elas(prm).process(l, r)
-        assert rc0 == rc1 == 0
-        assert np.array_equal(A1, B1) and np.array_equal(A2, B2)
-
-
 @pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
 def test_full_hd_pairs_batch(svhip, oracle_lib):
     """BASELINE.json configs[3]: synthetic 1920x1080, disp_max=255, a batch sharded over
