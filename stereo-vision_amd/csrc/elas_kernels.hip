@@ -1497,28 +1497,19 @@ void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d
     P.disp_min = p.disp_min; P.disp_max = p.disp_max;
     P.support_texture = p.support_texture; P.lr_threshold = p.lr_threshold;
     P.support_threshold = p.support_threshold;
-    // LDS need of the staged variant: two rows of both strips (16 B slots)
-    static const int variant = getenv("SVH_SUPPORT_VARIANT") ? atoi(getenv("SVH_SUPPORT_VARIANT")) : 1;
-    const int sb = variant == 0 ? 16 : variant == 1 ? 32 : variant == 2 ? 64 : 128;
+    // LDS need of the staged kernel: two rows of both strips (16 B slots).  32 candidates per
+    // 512-thread block was the best of the block shapes tried (16/256 ... 128/1024: all within 3 %).
+    constexpr int sb = 32;
     const int span = (sb - 1) * d.step;
     const size_t wl = (size_t)std::min(d.W, span + 2 * p.disp_max + 5);
     const size_t wr = (size_t)std::min(d.W, span + p.disp_max + 5);
     const size_t lds = 2 * (wl + wr) * sizeof(uint4);
-    if (lds <= 64 * 1024 || (variant == 3 && lds <= 80 * 1024)) {
+    if (lds <= 64 * 1024) {
         Timed timed_(cx, "k_support");
         // (pairs * lattice rows rounded up to 8) * chunks blocks: XCD-aware order, see the kernel
         const int chunks = (d.Wc + sb - 1) / sb;
         const dim3 grid((unsigned)(((d.Hc * g + 7) / 8) * 8 * chunks), 1, 1);
-        hipStream_t s = (hipStream_t)cx.stream;
-        if (variant == 0) hipLaunchKernelGGL((k_support_lds<16, 256>), grid, dim3(256), lds, s, desc, dcan, P);
-        else if (variant == 1) hipLaunchKernelGGL((k_support_lds<32, 512>), grid, dim3(512), lds, s, desc, dcan, P);
-        else if (variant == 2) hipLaunchKernelGGL((k_support_lds<64, 1024>), grid, dim3(1024), lds, s, desc, dcan, P);
-        else {
-            static bool once = ((void)hipFuncSetAttribute((const void*)k_support_lds<128, 1024>,
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), true);
-            (void)once;
-            hipLaunchKernelGGL((k_support_lds<128, 1024>), grid, dim3(1024), lds, s, desc, dcan, P);
-        }
+        hipLaunchKernelGGL((k_support_lds<sb, 512>), grid, dim3(512), lds, (hipStream_t)cx.stream, desc, dcan, P);
     } else {
         const int cands = d.Wc * d.Hc;
         LAUNCH("k_support", k_support, dim3((cands + 3) / 4, g), dim3(256), desc, dcan, P);
