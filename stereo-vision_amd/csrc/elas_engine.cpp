@@ -185,7 +185,9 @@ struct Lane {
         HIP_TRY(hipMalloc(&desc, G2 * N * 16));
         HIP_TRY(hipMalloc(&owner, G2 * N * sizeof(int32_t)));
         HIP_TRY(hipMemset(owner, 0, G2 * N * sizeof(int32_t)));
-        owner_hi = 0;
+        // SVH_TEST_OWNER_HI: start the moving base just below the int32 limit so that a test
+        // reaches the (otherwise once-per-40 000-groups) re-clear path with its first groups
+        owner_hi = getenv("SVH_TEST_OWNER_HI") ? atoll(getenv("SVH_TEST_OWNER_HI")) : 0;
         HIP_TRY(hipMalloc(&Draw, G2 * DN * sizeof(float)));
         HIP_TRY(hipMalloc(&D, G2 * DN * sizeof(float)));
         HIP_TRY(hipMalloc(&tmp, G2 * DN * sizeof(float)));

@@ -347,3 +347,20 @@ def test_tile_post_kernels_match_oracle(seed, w, h, kw, svhip, oracle_lib):
     got = product_run(svhip, prm, l, r)                    # unfused kernels (taps)
     assert np.array_equal(D1.ravel(), np.asarray(got[H.D1_FINAL]).ravel())
     assert np.array_equal(D2.ravel(), np.asarray(got[H.D2_FINAL]).ravel())
+
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
+def test_owner_base_wraparound(svhip, oracle_lib, monkeypatch):
+    """the triangle-ownership map is never cleared: every group stores owner_base + 1 + index
+    with a base above all earlier values, and re-clears only when int32 would overflow.  A lane
+    sized for a new geometry starts its base from SVH_TEST_OWNER_HI; 20 000 below the limit the
+    base crosses it after a few calls -- every call must still give the oracle's maps."""
+    monkeypatch.setenv("SVH_TEST_OWNER_HI", str(2 ** 31 - 1 - 20000))
+    l, r = H.synth_pair(523, 211, 77, dmax=40)          # a geometry no other test uses
+    prm = H.robotics()
+    want = H.oracle_elas_run(prm, l, r)
+    e = svhip.Elas(prm)
+    for k in range(12):                                  # ~3 000 triangles per call
+        rc, D1, D2 = e.process(l, r)
+        assert rc == want.status == 0
+        assert np.array_equal(D1.ravel(), np.asarray(want[H.D1_FINAL]).ravel()), k
+        assert np.array_equal(D2.ravel(), np.asarray(want[H.D2_FINAL]).ravel()), k
