@@ -124,6 +124,7 @@ struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t wait_ev = nullptr;   // completion marker polled by lane_wait
     bool poll_wait = false;         // batch workers sleep-poll; single calls spin (lowest latency)
+    bool parallel_host = true;      // host stage may use helper threads (off when every core is a worker)
     // geometry the buffers were sized for
     int32_t W = 0, H = 0, disp_max = -1, step = 0, grid_size = 0, sub = -1, gcap = 0;
     Dims d{};
@@ -451,7 +452,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
             hp.support.clear();
             hp.tri[0].clear();
             hp.tri[1].clear();
-        } else if (!triangulate_support(hp, /*parallel=*/!L.poll_wait && g == 1)) {
+        } else if (!triangulate_support(hp, /*parallel=*/L.parallel_host)) {
             return fail(SVH_ERR_UNSUPPORTED, "triangulation failed");
         } else {
             hdr->active[j] = 1;
@@ -778,6 +779,10 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
         for (Lane* L : slot)
             if (L) {
                 L->poll_wait = true;
+                // a batch with no more groups than workers is one round deep: latency-bound, so
+                // the two triangulations of a pair may run on two threads; otherwise every core
+                // already has a worker
+                L->parallel_host = ngroups <= lanes;
                 if (hipSetDevice(L->device) == hipSuccess) (void)L->ensure(e->p, dims[0], dims[1], G);
             }
         struct Job { int32_t gi = -1; GroupIO io{}; int32_t first = 0; };
@@ -836,6 +841,7 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
                     note(pending[q], run_group(*slot[q], e->p, dims, pending[q].io, &st[pending[q].first], nullptr,
                                                nullptr, RG_FINISH));
                 slot[q]->poll_wait = false;
+                slot[q]->parallel_host = true;
                 release_lane(slot[q]);
             }
     };
