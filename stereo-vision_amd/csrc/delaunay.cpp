@@ -311,35 +311,42 @@ private:
     // cut takes the n/2 smallest by the lexicographic key of its axis, leaves of <= 3
     // points are x-sorted), so it can be produced without the pivot stream: a
     // kd-style split over two presorted lists with stable partitions.
-    std::vector<uint8_t> mark_;
-    std::vector<int32_t> tmp_;
-    // `out` receives the n entries of this sub-range, `tmp` is n entries of scratch: both halves
-    // of a split work on disjoint slices of every array (and disjoint vertices in mark_), so the
-    // top levels can run on two threads
-    void kd_order(int32_t* lx, int32_t* ly, int32_t n, int axis, int32_t* out, int32_t* tmp, int par_depth) {
+    // List entries are (rank in x order) << 32 | (rank in y order): membership in the lower half
+    // of a cut is one compare against the pivot's rank, so the stable partition of the other
+    // list is branch-free and touches nothing but the two lists.
+    // `out` receives the n vertices of this sub-range, `tmp` is n entries of scratch.
+    static void kd_order(uint64_t* lx, uint64_t* ly, int32_t n, int axis, int32_t* out, uint64_t* tmp,
+                         const int32_t* by_x) {
         if (n <= 3) {
-            for (int32_t i = 0; i < n; i++) out[i] = lx[i];
+            for (int32_t i = 0; i < n; i++) out[i] = by_x[lx[i] >> 32];
             return;
         }
         const int32_t half = n >> 1;
-        int32_t* cut = axis == 0 ? lx : ly;      // list sorted by the cutting key
-        int32_t* oth = axis == 0 ? ly : lx;      // the other list is partitioned stably
-        for (int32_t i = 0; i < half; i++) mark_[cut[i]] = 1;
-        for (int32_t i = half; i < n; i++) mark_[cut[i]] = 0;
         int32_t a = 0, b = half;
-        for (int32_t i = 0; i < n; i++) {
-            const int32_t v = oth[i];
-            if (mark_[v]) tmp[a++] = v;
-            else          tmp[b++] = v;
-        }
-        memcpy(oth, tmp, sizeof(int32_t) * n);
-        if (par_depth > 0 && n >= 512) {
-            run_pair([&]() { kd_order(lx, ly, half, 1 - axis, out, tmp, par_depth - 1); },
-                     [&]() { kd_order(lx + half, ly + half, n - half, 1 - axis, out + half, tmp + half, par_depth - 1); });
+        if (axis == 0) {
+            // lx[0 .. half) is the lower half; split ly the same way
+            const uint64_t pivot = lx[half] >> 32;
+            for (int32_t i = 0; i < n; i++) {
+                const uint64_t e = ly[i];
+                const int32_t low = (e >> 32) < pivot;
+                tmp[low ? a : b] = e;
+                a += low;
+                b += 1 - low;
+            }
+            memcpy(ly, tmp, sizeof(uint64_t) * n);
         } else {
-            kd_order(lx, ly, half, 1 - axis, out, tmp, 0);
-            kd_order(lx + half, ly + half, n - half, 1 - axis, out + half, tmp + half, 0);
+            const uint64_t pivot = ly[half] & 0xffffffffu;
+            for (int32_t i = 0; i < n; i++) {
+                const uint64_t e = lx[i];
+                const int32_t low = (e & 0xffffffffu) < pivot;
+                tmp[low ? a : b] = e;
+                a += low;
+                b += 1 - low;
+            }
+            memcpy(lx, tmp, sizeof(uint64_t) * n);
         }
+        kd_order(lx, ly, half, 1 - axis, out, tmp, by_x);
+        kd_order(lx + half, ly + half, n - half, 1 - axis, out + half, tmp + half, by_x);
     }
 
     void recurse(const int32_t* a, int32_t n, int axis, Handle* farleft, Handle* farright, int32_t& ctr,
@@ -713,32 +720,15 @@ int32_t DivConq::run(int32_t* out, int32_t cap) {
                 return Y(a) < Y(b) || (Y(a) == Y(b) && X(a) < X(b));
             });
         }
-        mark_.assign(n_, 0);
-        tmp_.resize(m);
-        const int32_t half = m >> 1;
-        // split the y-sorted list like the x-sorted one is split at `half`
-        for (int32_t i = 0; i < half; i++) mark_[order[i]] = 1;
-        int32_t a = 0, b = half;
-        for (int32_t i = 0; i < m; i++) {
-            const int32_t v = ly[i];
-            if (mark_[v]) tmp_[a++] = v;
-            else          tmp_[b++] = v;
-        }
-        memcpy(ly.data(), tmp_.data(), sizeof(int32_t) * m);
-        if (m - half >= 2) {
-            auto left = [&]() {
-                if (half >= 2) kd_order(order.data(), ly.data(), half, 1, kd.data(), tmp_.data(), 0);
-                else for (int32_t i = 0; i < half; i++) kd[i] = order[i];
-            };
-            auto right = [&]() {
-                kd_order(order.data() + half, ly.data() + half, m - half, 1, kd.data() + half, tmp_.data() + half, 0);
-            };
-            // kept on one thread: the halves' vertices interleave in mark_ (false sharing made the
-            // two-thread version slower than this one)
-            left();
-            right();
-            memcpy(order.data(), kd.data(), sizeof(int32_t) * m);
-        }
+        // ranks: lx[i] = i << 32 | yrank, ly[j] = xrank << 32 | j
+        std::vector<int32_t> rank(n_);
+        std::vector<uint64_t> lx(m), lyk(m), scratch(m);
+        for (int32_t j = 0; j < m; j++) rank[ly[j]] = j;
+        for (int32_t i = 0; i < m; i++) lx[i] = (uint64_t)i << 32 | (uint32_t)rank[order[i]];
+        for (int32_t i = 0; i < m; i++) rank[order[i]] = i;
+        for (int32_t j = 0; j < m; j++) lyk[j] = (uint64_t)rank[ly[j]] << 32 | (uint32_t)j;
+        kd_order(lx.data(), lyk.data(), m, 0, kd.data(), scratch.data(), order.data());
+        memcpy(order.data(), kd.data(), sizeof(int32_t) * m);
     }
     TICK(2)
     rec_.assign(8 * (2 * (size_t)m + 16), 0);

@@ -151,7 +151,6 @@ struct Lane {
     size_t prior_cap = 0;
     size_t ntri_max = 0;
     std::vector<HostPrior> hp;
-    std::vector<int16_t> dcan_work;
     std::vector<int32_t> P;
 
     void release() {
@@ -373,6 +372,31 @@ static void tap_host(Taps* taps, int stage, const T* src, size_t count) {
 //   RG_FINISH  wait for the stream, collect errors and kernel timings
 enum { RG_A = 1, RG_HOST_B = 2, RG_FINISH = 4, RG_ALL = 7 };
 
+// SVH_HOST_PROF=1: per-stage thread-CPU time of the batch workers, printed at exit
+enum { HP_ENQ_A, HP_WAIT, HP_FILTER, HP_DELAUNAY, HP_PACK, HP_ENQ_B, HP_N };
+static const bool g_hostprof = getenv("SVH_HOST_PROF") != nullptr;
+static std::atomic<uint64_t> g_hp_ns[HP_N];
+static std::atomic<uint64_t> g_hp_pairs{0};
+static uint64_t cpu_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + ts.tv_nsec;
+}
+struct HostProfDump {
+    ~HostProfDump() {
+        if (!g_hostprof || !g_hp_pairs) return;
+        static const char* nm[HP_N] = {"enqueue A", "waits", "filters", "delaunay", "pack", "enqueue B"};
+        double tot = 0;
+        for (int i = 0; i < HP_N; i++) tot += g_hp_ns[i];
+        fprintf(stderr, "[svh host prof] %llu pairs, %.1f us cpu/pair:", (unsigned long long)g_hp_pairs.load(),
+                tot / 1e3 / g_hp_pairs);
+        for (int i = 0; i < HP_N; i++) fprintf(stderr, "  %s %.1f", nm[i], g_hp_ns[i] / 1e3 / g_hp_pairs);
+        fprintf(stderr, "\n");
+    }
+};
+static HostProfDump g_hp_dump;
+#define HP_MARK(slot) do { if (g_hostprof) { uint64_t n_ = cpu_ns(); g_hp_ns[slot] += n_ - hp_t; hp_t = n_; } } while (0)
+
 static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, const GroupIO& io,
                      int32_t* status, Taps* taps, svh_elas* timing, int mode = RG_ALL) {
     const int32_t W = dims[0], H = dims[1], g = io.g;
@@ -390,10 +414,12 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     const size_t N = (size_t)W * H, DN = (size_t)d.DW * d.DH;
     const size_t nc = (size_t)d.Wc * d.Hc;
     double t0 = now_ms();
+    uint64_t hp_t = g_hostprof ? cpu_ns() : 0;
     if (mode == RG_FINISH) {
         HIP_TRY(lane_wait(L));
         HIP_TRY(hipGetLastError());
         L.prof.collect();
+        HP_MARK(HP_WAIT);
         return SVH_OK;
     }
 
@@ -421,11 +447,14 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     launch_descriptor(cx, img, g, W, H, p.subsampling, L.desc);
     launch_support(cx, p, d, g, L.desc, L.dcan);
     HIP_TRY(hipMemcpyAsync(L.h_dcan, L.dcan, g * nc * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    HP_MARK(HP_ENQ_A);
     }
     if (!(mode & RG_HOST_B)) return SVH_OK;
     HIP_TRY(lane_wait(L));
     HIP_TRY(hipGetLastError());
     L.prof.collect();
+    HP_MARK(HP_WAIT);
+    if (g_hostprof) g_hp_pairs += g;
     double t1 = now_ms();
     if (taps && taps->enabled) {
         rc = tap_dev(L, taps, SVH_ELAS_DESC1, L.desc, N * 16); if (rc) return rc;
@@ -440,8 +469,8 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     int32_t total_sup = 0, total_tri = 0, nactive = 0;
     for (int32_t j = 0; j < g; j++) {
         HostPrior& hp = L.hp[j];
-        L.dcan_work.assign(L.h_dcan + j * nc, L.h_dcan + (j + 1) * nc);
-        support_from_candidates(p, d, L.dcan_work.data(), hp.support);
+        support_from_candidates(p, d, L.h_dcan + j * nc, hp.support, /*write_back=*/false);
+        HP_MARK(HP_FILTER);
         hdr->sup_off[j] = total_sup;
         status[j] = SVH_OK;
         if (hp.support.size() / 3 < 3) {
@@ -458,6 +487,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
             hdr->active[j] = 1;
             nactive++;
         }
+        HP_MARK(HP_DELAUNAY);
         total_sup += (int32_t)(hp.support.size() / 3);
         for (int k = 0; k < 2; k++) {
             total_tri += (int32_t)(hp.tri[k].size() / 3);
@@ -497,6 +527,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         }
     if (off > L.prior_cap) return fail(SVH_ERR_BAD_ARG, "prior exceeds staging capacity");
     double t2 = now_ms();
+    HP_MARK(HP_PACK);
 
     // ---- phase B ---------------------------------------------------------
     HIP_TRY(hipMemcpyAsync(L.prior_dev, L.h_prior, off, hipMemcpyHostToDevice, s));
@@ -587,10 +618,12 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
                 HIP_TRY(hipMemcpyAsync(io.hD[k][j], L.D + ((size_t)2 * j + k) * DN, DN * sizeof(float),
                                        hipMemcpyDeviceToHost, s));
         }
+    HP_MARK(HP_ENQ_B);
     if (!(mode & RG_FINISH)) return SVH_OK;
     HIP_TRY(lane_wait(L));
     HIP_TRY(hipGetLastError());
     L.prof.collect();
+    HP_MARK(HP_WAIT);
     double t3 = now_ms();
     if (timing) {
         timing->tnames = {"Descriptor+Support Matches (device)", "Filters+Delaunay (host)",

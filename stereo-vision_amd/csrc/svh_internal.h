@@ -59,9 +59,10 @@ struct HostPrior {
     std::vector<int32_t> tri[2];             // n x 3
 };
 
-// E5/E6 + list + corners (elas.cpp:174-318, 495-523); dcan is modified in place
+// E5/E6 + list + corners (elas.cpp:174-318, 495-523); with write_back dcan receives the filtered
+// lattice (the reference filters D_can in place), otherwise it is only read
 void support_from_candidates(const svh_elas_params& p, const Dims& d, int16_t* dcan,
-                             std::vector<int32_t>& support);
+                             std::vector<int32_t>& support, bool write_back = true);
 // E7, both sides.  Returns false when a triangulation fails.
 bool triangulate_support(HostPrior& hp, bool parallel = false);
 // runs a() on the calling thread and b() on a parked helper thread (or both here if none is free)

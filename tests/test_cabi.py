@@ -103,6 +103,53 @@ def test_host_support_stage_matches_oracle(S, oracle_lib):
         assert np.array_equal(sa[:na], sb[:nb]) and np.array_equal(a, b)
 
 
+def test_host_support_stage_fuzz(S, oracle_lib):
+    """vector and scalar forms of the lattice filters == oracle: window sizes on both sides of
+    the 16-lane limit, thresholds, lattice shapes that are not multiples of 8, sparse and dense
+    lattices, values beyond the 16-bit fast path's range"""
+    lib = S.lib()
+    rng = np.random.default_rng(11)
+    paths = set()
+    for trial in range(60):
+        w = int(rng.integers(40, 700))
+        h = int(rng.integers(40, 420))
+        ws = int(rng.integers(0, 10))
+        prm = H.robotics(candidate_stepsize=int(rng.integers(2, 8)), incon_window_size=ws,
+                         incon_threshold=int(rng.integers(0, 9)), incon_min_support=int(rng.integers(0, 12)),
+                         add_corners=int(rng.integers(0, 2)))
+        wc = C.c_int32()
+        hc = C.c_int32()
+        oracle_lib.orc_dcan_dims(C.byref(prm), w, h, C.byref(wc), C.byref(hc))
+        yy, xx = np.mgrid[0:hc.value, 0:wc.value]
+        kind = trial % 4
+        if kind == 0:      # smooth field with holes and outliers
+            d = (20 + 0.3 * xx + 0.2 * yy + rng.integers(-1, 2, xx.shape)).astype(np.int16)
+            d[rng.random(d.shape) < rng.uniform(0.05, 0.6)] = -1
+            d[rng.random(d.shape) < 0.03] = 150
+        elif kind == 1:    # noise: nearly everything is inconsistent
+            d = rng.integers(-1, 64, xx.shape).astype(np.int16)
+        elif kind == 2:    # plateaus: long redundant runs in both directions
+            d = ((xx // 7 + yy // 5) % 3 * 2 + 10).astype(np.int16)
+            d[rng.random(d.shape) < 0.1] = -1
+        else:              # steps of exactly the redundancy threshold
+            d = (10 + (xx + yy) % 4).astype(np.int16)
+            d[rng.random(d.shape) < 0.2] = -1
+        if trial % 10 == 9:
+            d[hc.value // 2, wc.value // 2] = 9000   # outside the vector path's value range
+        paths.add(ws <= 7 and trial % 10 != 9)
+        a = d.copy()
+        b = d.copy()
+        cap = wc.value * hc.value + 6
+        sa = np.zeros((cap, 3), np.int32)
+        sb = np.zeros((cap, 3), np.int32)
+        na = oracle_lib.orc_support_filter(C.byref(prm), H._p(a), w, h, H._p(sa), cap)
+        nb = lib.svh_elas_support_from_candidates(C.byref(prm), w, h, H._p(b), H._p(sb), cap)
+        assert na == nb, (trial, na, nb)
+        assert np.array_equal(sa[:na], sb[:nb]), trial
+        assert np.array_equal(a, b), trial
+    assert paths == {True, False}
+
+
 def test_refuses_to_run_without_a_gpu(S):
     """no CPU fallback: without a HIP device the call fails loudly, outputs untouched"""
     if S.device_count() > 0:
