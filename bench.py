@@ -234,12 +234,25 @@ def main():
                     help="nccl (= RCCL, the default) or gloo (CPU collectives: lets several ranks "
                          "share one GPU when the multi-rank path is smoke-tested on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kitti-dir", default="",
+                    help="--workload sequence on a real KITTI raw drive directory (image_00/, image_01/ "
+                         "with data/ and timestamps.txt) instead of the 430-frame substitute")
     args = ap.parse_args()
     global W, H, N_PIX
     if args.workload == "hd1080":
         W, H = 1920, 1080
         N_PIX = W * H
-    if args.workload == "sequence":
+    kitti_frames = None
+    if args.workload == "sequence" and args.kitti_dir:
+        from svhip import kitti as _kitti
+        k1, k2, lo_, total_ = _kitti.load_shard(args.kitti_dir, int(os.environ.get("RANK", "0")),
+                                                int(os.environ.get("WORLD_SIZE", "1")))
+        kitti_frames = (k1, k2, total_)
+        args.batch = k1.shape[0]
+        args.seq_first = lo_
+        H, W = k1.shape[1:]
+        N_PIX = W * H
+    elif args.workload == "sequence":
         from svhip import shard as _sh
         lo_, hi_ = _sh.shard_range(430, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
         args.batch = hi_ - lo_
@@ -284,7 +297,12 @@ def main():
     params = Hh.robotics()           # Elas::parameters(ROBOTICS), elas.h:91-116
     # B pairs per step = `unique` different synthetic pairs, tiled (generation is the slow part;
     # the library keeps nothing between pairs, so a repeated pair is full work)
-    if args.workload == "sequence":
+    if kitti_frames is not None:
+        U = B
+        dI1 = torch.from_numpy(kitti_frames[0]).to(dev).contiguous()
+        dI2 = torch.from_numpy(kitti_frames[1]).to(dev).contiguous()
+        I1, I2 = kitti_frames[0], kitti_frames[1]
+    elif args.workload == "sequence":
         # frame f of the sequence = cycle[f % 4]; this rank owns frames [seq_first, seq_first + B)
         U = 4
         s1, s2 = make_inputs(2, seed0=4242)
@@ -463,12 +481,21 @@ def main():
             "scaling": "strong" if args.workload == "sequence" else "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic" if args.workload != "sequence" else "2 crops of the reference's urban images + 2 synthetic pairs",
+            "data": ("KITTI raw drive " + os.path.basename(os.path.normpath(args.kitti_dir))) if kitti_frames is not None
+                    else ("synthetic" if args.workload != "sequence"
+                          else "2 crops of the reference's urban images + 2 synthetic pairs"),
             "config": {"workload": {"kitti": "configs[1]: KITTI-size 1242x375 pairs",
                                     "hd1080": "configs[3]: synthetic 1920x1080 pairs, disp_max 255",
                                     "sequence": "configs[2] substitute: 430-frame 1242x375 sequence (two urban "
                                                 "crops + two synthetic pairs, cycled), frames sharded over GPUs"
-                                    }[args.workload] +
+                                    }[args.workload].replace(
+                                        "configs[2] substitute: 430-frame 1242x375 sequence (two urban crops + two "
+                                        "synthetic pairs, cycled)",
+                                        "configs[2]: %d-frame %dx%d KITTI raw sequence" % (
+                                            kitti_frames[2] if kitti_frames is not None else 0, W, H)
+                                        if kitti_frames is not None else
+                                        "configs[2] substitute: 430-frame 1242x375 sequence (two urban crops + two "
+                                        "synthetic pairs, cycled)") +
                                    ", ELAS ROBOTICS, D1+D2 + LR-check, subsampling=false, inputs "
                                    "and outputs resident in HBM",
                        "pairs_per_step_per_gpu": B, "unique_pairs_per_gpu": U, "lanes_per_gpu": lanes,
