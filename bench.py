@@ -244,14 +244,7 @@ def main():
         N_PIX = W * H
     kitti_frames = None
     if args.workload == "sequence" and args.kitti_dir:
-        from svhip import kitti as _kitti
-        k1, k2, lo_, total_ = _kitti.load_shard(args.kitti_dir, int(os.environ.get("RANK", "0")),
-                                                int(os.environ.get("WORLD_SIZE", "1")))
-        kitti_frames = (k1, k2, total_)
-        args.batch = k1.shape[0]
-        args.seq_first = lo_
-        H, W = k1.shape[1:]
-        N_PIX = W * H
+        pass   # the drive is read below, after torch has brought up the HIP runtime
     elif args.workload == "sequence":
         from svhip import shard as _sh
         lo_, hi_ = _sh.shard_range(430, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
@@ -286,6 +279,14 @@ def main():
     import svhip as S
     import helpers as Hh
     S.lib().svh_set_device(local_rank)
+    if args.workload == "sequence" and args.kitti_dir:
+        from svhip import kitti as _kitti
+        k1, k2, lo_, total_ = _kitti.load_shard(args.kitti_dir, rank, world)
+        kitti_frames = (k1, k2, total_)
+        args.batch = k1.shape[0]
+        args.seq_first = lo_
+        H, W = k1.shape[1:]
+        N_PIX = W * H
     # workers per GPU: each is double-buffered and sleeps while it waits, so ~1.5 per available
     # core keeps the cores busy with the host stage (lattice filters + Delaunay)
     avail = _cpu_quota() or (os.cpu_count() or 8)
