@@ -811,11 +811,11 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
         // device and must not land in the middle of other lanes' launches later
         for (Lane* L : slot)
             if (L) {
-                L->poll_wait = true;
                 // a batch with no more groups than workers is one round deep: latency-bound, so
-                // the two triangulations of a pair may run on two threads; otherwise every core
-                // already has a worker
+                // the two triangulations of a pair may run on two threads and the waits block in
+                // the driver; otherwise every core already has a worker and the waits sleep-poll
                 L->parallel_host = ngroups <= lanes;
+                L->poll_wait = !L->parallel_host;
                 if (hipSetDevice(L->device) == hipSuccess) (void)L->ensure(e->p, dims[0], dims[1], G);
             }
         struct Job { int32_t gi = -1; GroupIO io{}; int32_t first = 0; };
