@@ -100,92 +100,101 @@ __device__ __forceinline__ int tri_slot(const GroupHdr* __restrict__ h, int T, i
 }
 
 // ---------------------------------------------------------------------------
-// E1+E2  3x3 Sobel + 16-byte descriptor, fused
+// E1+E2  3x3 Sobel + 16-byte descriptor, fused, streaming: no LDS, no barriers.
 //   filter::sobel3x3          libelas/src/filter.cpp:408-416 (+372-405, 227-267, 176-222)
 //   Descriptor::createDescriptor   libelas/src/descriptor.cpp:48-121
-// One block = 64x16 pixel tile of one image of one pair (blockIdx.z = 2*pair +
-// image).  The 8-bit tile (+3 halo) goes to LDS once, du/dv (+2 halo) are built
-// in LDS, then every thread gathers its 16 bytes and issues one 16-byte store; a
-// wave writes 1 KiB contiguous.  Border descriptors (and odd rows when half)
-// are written as zero.
+// Border descriptors (and odd rows when half) are written as zero.  A wave owns a strip of 58 image
+// columns (lane l <-> column strip*58 + l - 3, three halo lanes on each side) and walks down a
+// segment of rows.  Per row every lane loads ONE image byte; the 3x3 Sobel needs the last three
+// bytes of the lane (registers) and the column sums of the two neighbour lanes (DPP wave shifts);
+// the 16 descriptor bytes of row y are assembled from per-row packed words of the last five du
+// rows / three dv rows, which ride along in registers as the walk advances.  ~45 VALU operations
+// per pixel instead of ~100 for the LDS tile kernel it replaced (three phases with byte gathers),
+// which was 9 % of all VALU work of a pair.
+// DS_ROWS rows are written per wave (the walk takes DS_ROWS + 6 steps); DS_CHUNK image bytes (one
+// per row) are loaded ahead of the arithmetic.
 // ---------------------------------------------------------------------------
-constexpr int TX = 64, TY = 32;
+constexpr int DS_COLS = 58;    // columns written per wave (lanes 3 .. 60)
 
-__global__ __launch_bounds__(256) void k_descriptor(DevImages img, int W, int H, int half,
-                                                    uint8_t* __restrict__ desc_all) {
-    __shared__ uint8_t sI[TY + 6][TX + 8];
-    __shared__ uint8_t sU[TY + 4][TX + 4];
-    __shared__ uint8_t sV[TY + 4][TX + 4];
+// The shifted value is made opaque so that the compiler keeps the plain v_mov_b32_dpp: folded into
+// a VOP2 operand (v_subrev_u32_dpp ... wave_shl:1) the shift came out wrong on gfx950 (the
+// difference prev(S) - next(S) evaluated to 0 everywhere).
+__device__ __forceinline__ int lane_prev(int v) {   // lane i <- lane i-1 (lane 0: 0)
+    int r = __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true);   // wave_shr:1
+    asm volatile("" : "+v"(r));
+    return r;
+}
+__device__ __forceinline__ int lane_next(int v) {   // lane i <- lane i+1 (lane 63: 0)
+    int r = __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true);   // wave_shl:1
+    asm volatile("" : "+v"(r));
+    return r;
+}
 
-    const int pair = blockIdx.z >> 1, im = blockIdx.z & 1;
-    const uint8_t* __restrict__ I = img.I[im] + (size_t)pair * img.stride;
+template <int DS_ROWS, int DS_CHUNK>
+__global__ __launch_bounds__(256) void k_descriptor_stream(DevImages img, int W, int H, int half, int strips,
+                                                           int nwaves, uint8_t* __restrict__ desc_all) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (wid >= nwaves) return;
+    const int seg = wid / strips, strip = wid - seg * strips;
+    const int pair = blockIdx.y >> 1, im = blockIdx.y & 1;
+    const int x = strip * DS_COLS + lane - 3;
+    const int ys = seg * DS_ROWS;
+    const bool x_in = x >= 0 && x < W;
+    const bool x_out = lane >= 3 && lane < 3 + DS_COLS && x < W;
+    const bool x_inside = x >= 3 && x < W - 3;
+    const uint8_t* __restrict__ src = img.I[im] + (size_t)pair * img.stride + (x_in ? x : 0);
     const int pitch = img.pitch;
-    uint8_t* __restrict__ desc = desc_all + (size_t)blockIdx.z * W * H * 16;
-    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
-    const int tid = threadIdx.y * TX + threadIdx.x;
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(desc_all + (size_t)blockIdx.y * W * H * 16);
+    const uint32_t xo = x_out ? (uint32_t)x : 0u;
 
-    // linear walks over the (TY+6) x (TX+6) and (TY+4) x (TX+4) windows, 256 entries per step; the
-    // (row, column) of an entry is advanced incrementally (no integer division per entry)
-    {
-        constexpr int CW = TX + 6, dr = 256 / CW, dc = 256 % CW;
-        int r = tid / CW, c = tid - r * CW;
-        for (int i = tid; i < (TY + 6) * CW; i += 256) {
-            const int y = y0 - 3 + r, x = x0 - 3 + c;
-            uint8_t val = 0;
-            if (x >= 0 && x < W && y >= 0 && y < H) val = I[(size_t)y * pitch + x];
-            sI[r][c] = val;
-            r += dr;
-            c += dc;
-            if (c >= CW) {
-                c -= CW;
-                r++;
-            }
-        }
-    }
-    __syncthreads();
-    constexpr int UW = TX + 4, ur = 256 / UW, uc = 256 % UW;
-    int r = tid / UW, c = tid - r * UW;
-    for (int i = tid; i < (TY + 4) * UW; i += 256, r += ur, c += uc) {
-        if (c >= UW) {
-            c -= UW;
-            r++;
-        }
-        // (r,c) in sU is image (y0-2+r, x0-2+c) == sI[r+1][c+1]
-        int a0 = sI[r][c], a1 = sI[r][c + 1], a2 = sI[r][c + 2];
-        int b0 = sI[r + 1][c], b2 = sI[r + 1][c + 2];
-        int c0 = sI[r + 2][c], c1 = sI[r + 2][c + 1], c2 = sI[r + 2][c + 2];
-        int Sl = a0 + 2 * b0 + c0, Sr = a2 + 2 * b2 + c2;          // vertical 1 2 1
-        int Tl = a0 - c0, Tm = a1 - c1, Tr = a2 - c2;              // vertical 1 0 -1
-        sU[r][c] = (uint8_t)sat_u8(((Sl - Sr) >> 2) + 128);        // horizontal 1 0 -1
-        sV[r][c] = (uint8_t)sat_u8(((Tl + 2 * Tm + Tr) >> 2) + 128);  // horizontal 1 2 1
-    }
-    __syncthreads();
-    const int x = x0 + threadIdx.x;
-    if (x >= W) return;
-    const int lx = threadIdx.x + 2;
+    int i1 = 0, i2 = 0;                          // image bytes of rows r-1, r-2
+    uint32_t ucar = 0, vcar = 0;                 // own du / dv of the last four centre rows, newest in byte 0
+    uint32_t w1 = 0, w2 = 0, w3 = 0;             // du[x-2] | du[x] << 8 | du[x+2] << 16 of rows c-1, c-2, c-3
+    uint32_t y1 = 0, y2 = 0;                     // du[x-1] | du[x] << 8 | du[x] << 16 | du[x+1] << 24 of rows c-1, c-2
+    uint32_t z1 = 0, z2 = 0;                     // dv[x-1] << 8 | dv[x+1] << 16 of rows c-1, c-2
+    for (int r0 = ys - 3; r0 < ys + DS_ROWS + 3; r0 += DS_CHUNK) {
+        if (r0 - 3 >= H) break;                  // nothing below the image is written
+        int px[DS_CHUNK];
 #pragma unroll
-    for (int k = 0; k < TY / 4; k++) {
-        const int ty = threadIdx.y + 4 * k;
-        const int y = y0 + ty;
-        if (y >= H) break;
-        uint4 out = make_uint4(0, 0, 0, 0);
-        bool inside = x >= 3 && x < W - 3 && y >= 3 && y < H - 3;
-        if (half) inside = inside && y >= 4 && (y & 1) == 0;
-        if (inside) {
-            const int ly = ty + 2;
-            uint32_t b0 = sU[ly - 2][lx], b1 = sU[ly - 1][lx - 2], b2 = sU[ly - 1][lx],
-                     b3 = sU[ly - 1][lx + 2];
-            uint32_t b4 = sU[ly][lx - 1], b5 = sU[ly][lx], b7 = sU[ly][lx + 1];
-            uint32_t b8 = sU[ly + 1][lx - 2], b9 = sU[ly + 1][lx], b10 = sU[ly + 1][lx + 2],
-                     b11 = sU[ly + 2][lx];
-            uint32_t b12 = sV[ly - 1][lx], b13 = sV[ly][lx - 1], b14 = sV[ly][lx + 1],
-                     b15 = sV[ly + 1][lx];
-            out.x = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-            out.y = b4 | (b5 << 8) | (b5 << 16) | (b7 << 24);
-            out.z = b8 | (b9 << 8) | (b10 << 16) | (b11 << 24);
-            out.w = b12 | (b13 << 8) | (b14 << 16) | (b15 << 24);
+        for (int k = 0; k < DS_CHUNK; k++) {
+            const int r = r0 + k;
+            px[k] = (x_in && r >= 0 && r < H) ? (int)src[(size_t)r * pitch] : 0;
         }
-        *reinterpret_cast<uint4*>(desc + ((size_t)y * W + x) * 16) = out;
+#pragma unroll
+        for (int k = 0; k < DS_CHUNK; k++) {
+            const int r = r0 + k, i0 = px[k];
+            // centre row c = r-1: vertical 1 2 1 and 1 0 -1 of this column, then across the lanes
+            const int S = i2 + 2 * i1 + i0, T = i2 - i0;
+            const int u = sat_u8(((lane_prev(S) - lane_next(S)) >> 2) + 128);
+            const int v = sat_u8(((lane_prev(T) + 2 * T + lane_next(T)) >> 2) + 128);
+            i2 = i1;
+            i1 = i0;
+            const uint32_t uL1 = (uint32_t)lane_prev(u), uR1 = (uint32_t)lane_next(u);
+            const uint32_t uL2 = (uint32_t)lane_prev((int)uL1), uR2 = (uint32_t)lane_next((int)uR1);
+            const uint32_t Wc = uL2 | ((uint32_t)u << 8) | (uR2 << 16);
+            const uint32_t Yc = uL1 | ((uint32_t)u * 0x00010100u) | (uR1 << 24);
+            const uint32_t Zc = ((uint32_t)lane_prev(v) << 8) | ((uint32_t)lane_next(v) << 16);
+            const uint32_t u_c4 = ucar >> 24;    // du of row c-4
+            ucar = (ucar << 8) | (uint32_t)u;
+            vcar = (vcar << 8) | (uint32_t)v;    // bytes: c, c-1, c-2, c-3
+            // descriptor of row y = c-2 (descriptor.cpp:88-117)
+            const int y = r - 3;
+            if (y >= ys && y < ys + DS_ROWS && y < H) {
+                bool inside = x_inside && y >= 3 && y < H - 3;
+                if (half) inside = inside && y >= 4 && (y & 1) == 0;
+                uint4 out;
+                out.x = u_c4 | (w3 << 8);
+                out.y = y2;
+                out.z = w1 | ((uint32_t)u << 24);
+                out.w = (vcar >> 24) | z2 | ((vcar << 16) & 0xFF000000u);
+                if (!inside) out = make_uint4(0, 0, 0, 0);
+                if (x_out) dst[(uint32_t)(y * W) + xo] = out;
+            }
+            w3 = w2; w2 = w1; w1 = Wc;
+            y2 = y1; y1 = Yc;
+            z2 = z1; z1 = Zc;
+        }
     }
 }
 
@@ -1486,8 +1495,13 @@ struct Timed {
 // ---------------------------------------------------------------------------
 void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t g, int32_t W, int32_t H,
                        int32_t half, uint8_t* desc) {
-    dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, 2 * g), block(TX, 4);
-    LAUNCH("k_descriptor", k_descriptor, grid, block, img, W, H, half, desc);
+    // 26 rows per wave, 16 loads in flight: shorter walks (more waves) measured marginally better
+    // than 42 .. 90 rows, all within 2 %
+    constexpr int rows = 26, chunk = 16;
+    static_assert((rows + 6) % chunk == 0, "the walk is a whole number of load chunks");
+    const int strips = (W + DS_COLS - 1) / DS_COLS, segs = (H + rows - 1) / rows, nwaves = strips * segs;
+    LAUNCH("k_descriptor", (k_descriptor_stream<rows, chunk>), dim3((nwaves + 3) / 4, 2 * g), dim3(256), img, W, H,
+           half, strips, nwaves, desc);
 }
 
 void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,

@@ -364,3 +364,23 @@ def test_owner_base_wraparound(svhip, oracle_lib, monkeypatch):
         assert rc == want.status == 0
         assert np.array_equal(D1.ravel(), np.asarray(want[H.D1_FINAL]).ravel()), k
         assert np.array_equal(D2.ravel(), np.asarray(want[H.D2_FINAL]).ravel()), k
+
+
+@pytest.mark.parametrize("w,h,sub", [(64, 48, 0), (59, 27, 0), (58, 26, 0), (117, 53, 0), (61, 33, 1),
+                                      (175, 29, 0), (1242, 375, 1), (1920, 1080, 0)])
+def test_descriptor_strips_and_segments(w, h, sub, svhip, oracle_lib):
+    """the streaming descriptor kernel at widths / heights around its strip (58 columns) and
+    segment (26 rows) sizes, full and half resolution: every byte == oracle, borders zero"""
+    import ctypes as C
+    rng = np.random.default_rng(w * 7 + h)
+    l = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    r = np.ascontiguousarray(l[:, ::-1])
+    prm = H.robotics(subsampling=sub, disp_max=min(255, max(8, w // 3)))
+    e = svhip.Elas(prm)
+    e.set_taps(True)
+    e.process(l, r)          # may end with "few support points": the descriptor taps are taken before that
+    for img, stage in ((l, H.DESC1), (r, H.DESC2)):
+        want = np.zeros((h, w, 16), np.uint8)
+        oracle_lib.orc_descriptor(H._p(img), w, h, w, sub, H._p(want))
+        got = e.stage(stage, np.uint8).reshape(h, w, 16)
+        assert np.array_equal(got, want), (w, h, sub, np.argwhere(got != want)[:5])
