@@ -48,6 +48,14 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     v = dpp_min_step<0x143, 0xC>(v);   // row_bcast:31      -> row 3 (lane 63) holds the minimum
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// minimum over each row of 16 lanes, in every lane of that row
+__device__ __forceinline__ uint32_t row_min_u32(uint32_t v) {
+    v = dpp_min_step<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_min_step<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_min_step<0x141, 0xF>(v);   // row_half_mirror
+    v = dpp_min_step<0x140, 0xF>(v);   // row_mirror
+    return v;
+}
 
 // sum |a.byte - b.byte| over 16 bytes (== psadbw lanes 0+4, elas.cpp:406-414)
 __device__ __forceinline__ uint32_t sad16(const uint4& a, const uint4& b) {
@@ -291,21 +299,35 @@ struct StripView {
     __device__ __forceinline__ uint4 at(int row, int x) const { return base[row * w + (x - x0)]; }
 };
 
-__device__ __forceinline__ int support_match_lds(const StripView& own, const StripView& oth,
-                                                 const uint4 centre, int u, int v, bool right,
-                                                 const SupportParams& P, int lane) {
-    if (!(u >= 5 && u <= P.W - 6 && v >= 5 && v <= P.H - 6)) return -1;
-    if ((int)texture16(centre) < P.support_texture) return -1;
+// Four candidates per wave: lanes 16g .. 16g+15 search candidate g, 16 disparities per trip.
+// The inner loop is one 64-byte SAD per lane and trip, as with one candidate per wave; what is shared by the four candidates is everything around it -- range set-up, the two
+// minimum reductions (4 DPP steps inside a row of 16 instead of 6 across the wave + readlane)
+// and the ratio test -- which was ~40 % of the instructions of a search.  A quarter wave reads 16
+// consecutive 16-byte slots, so the ds_read_b128 stay conflict-free.  `act`: this lane's
+// candidate takes part; u is per lane (uniform inside a row of 16).  Returns d or -1 per lane.
+__device__ __forceinline__ int support_match_rows(const StripView& own, const StripView& oth, const uint4 centre,
+                                                  int u, bool right, bool act, const SupportParams& P, int gl) {
+    act = act && u >= 5 && u <= P.W - 6 && (int)texture16(centre) >= P.support_texture;
     const int dmin = P.disp_min > 0 ? P.disp_min : 0;
     int dmax = right ? P.W - u - 5 : u - 5;
     dmax = dmax < P.disp_max ? dmax : P.disp_max;
-    if (dmax - dmin < 10) return -1;
-    const uint4 r0 = own.at(0, u - 2), r1 = own.at(0, u + 2);
-    const uint4 r2 = own.at(1, u - 2), r3 = own.at(1, u + 2);
+    act = act && dmax - dmin >= 10;
+    if (__builtin_amdgcn_ballot_w64(act) == 0) return -1;
+    const int us = act ? u : own.x0 + 2;          // idle rows read a slot that exists
+    const uint4 r0 = own.at(0, us - 2), r1 = own.at(0, us + 2);
+    const uint4 r2 = own.at(1, us - 2), r3 = own.at(1, us + 2);
+    // the trip count of the wave is that of its widest row
+    const int dm = act ? dmax : -1;
+    int top = __builtin_amdgcn_readlane(dm, 0);
+    const int t1 = __builtin_amdgcn_readlane(dm, 16), t2 = __builtin_amdgcn_readlane(dm, 32),
+              t3 = __builtin_amdgcn_readlane(dm, 48);
+    top = top > t1 ? top : t1;
+    top = top > t2 ? top : t2;
+    top = top > t3 ? top : t3;
     uint32_t best1 = 0xFFFFFFFFu, best2 = 0xFFFFFFFFu;
-    for (int d0 = dmin; d0 <= dmax; d0 += kWave) {
-        const int d = d0 + lane;
-        if (d <= dmax) {
+    for (int d0 = dmin; d0 <= top; d0 += 16) {
+        const int d = d0 + gl;
+        if (d <= dm) {
             const int uw = right ? u + d : u - d;
             uint32_t e = sad16(r0, oth.at(0, uw - 2));
             e = sad16_acc(r1, oth.at(0, uw + 2), e);
@@ -314,12 +336,11 @@ __device__ __forceinline__ int support_match_lds(const StripView& own, const Str
             keep_two((e << 16) | (uint32_t)d, best1, best2);
         }
     }
-    const uint32_t m1 = wave_min_u32(best1);
-    const uint32_t m2 = wave_min_u32(best1 == m1 ? best2 : best1);
-    if (m1 == 0xFFFFFFFFu || m2 == 0xFFFFFFFFu) return -1;
+    const uint32_t m1 = row_min_u32(best1);
+    const uint32_t m2 = row_min_u32(best1 == m1 ? best2 : best1);
     const float e1 = (float)(m1 >> 16), e2 = (float)(m2 >> 16);
-    if (e1 < __fmul_rn(P.support_threshold, e2)) return (int)(m1 & 0xFFFFu);
-    return -1;
+    const bool good = m1 != 0xFFFFFFFFu && m2 != 0xFFFFFFFFu && e1 < __fmul_rn(P.support_threshold, e2);
+    return good ? (int)(m1 & 0xFFFFu) : -1;
 }
 
 template <int kSB, int kST>
@@ -371,23 +392,23 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
     }
     __syncthreads();
     const StripView L = {sL, xl0, wl}, R = {sR, xr0, wr};
-    for (int c = wave; c < ncand; c += kST / kWave) {
-        const int uc = uc0 + c, u = uc * P.step;
-        int out = 0;  // column 0 stays at calloc's 0
-        if (uc > 0) {
-            out = -1;
-            const bool in = u >= 5 && u <= P.W - 6;
-            const uint4 c1 = in ? d1[(size_t)v * P.W + u] : make_uint4(0, 0, 0, 0);
-            const int d = support_match_lds(L, R, c1, u, v, false, P, lane);
-            if (d >= 0) {
-                const int ub = u - d;   // >= 5 because d <= u-5
-                const uint4 c2 = d2[(size_t)v * P.W + ub];
-                const int dd = support_match_lds(R, L, c2, ub, v, true, P, lane);
-                const int diff = d > dd ? d - dd : dd - d;
-                if (dd >= 0 && diff <= P.lr_threshold) out = d;
-            }
-        }
-        if (lane == 0) dcan[c] = (int16_t)out;
+    const int grp = lane >> 4, gl = lane & 15;
+    for (int c0 = 4 * wave; c0 < ncand; c0 += 4 * (kST / kWave)) {
+        const int c = c0 + grp;
+        const bool have = c < ncand;
+        const int uc = uc0 + (have ? c : 0), u = uc * P.step;
+        const bool act = have && uc > 0;
+        const bool in = act && u >= 5 && u <= P.W - 6;
+        const uint4 c1 = in ? d1[(size_t)v * P.W + u] : make_uint4(0, 0, 0, 0);
+        const int d = support_match_rows(L, R, c1, u, false, in, P, gl);
+        const bool fwd = d >= 0;
+        const int ub = fwd ? u - d : 5;   // >= 5 because d <= u-5
+        const uint4 c2 = fwd ? d2[(size_t)v * P.W + ub] : make_uint4(0, 0, 0, 0);
+        const int dd = support_match_rows(R, L, c2, ub, true, fwd, P, gl);
+        const int diff = d > dd ? d - dd : dd - d;
+        // column 0 stays at calloc's 0
+        const int out = uc > 0 ? ((fwd && dd >= 0 && diff <= P.lr_threshold) ? d : -1) : 0;
+        if (have && gl == 0) dcan[c] = (int16_t)out;
     }
 }
 
