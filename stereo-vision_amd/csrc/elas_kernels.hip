@@ -855,6 +855,9 @@ __device__ __forceinline__ float match_pixel_keyed(const uint4& own, const float
         const uint32_t wb[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
 #pragma unroll
         for (int q = 0; q < 8; q++) {
+            // the cells of one wave hold similar candidate sets, clustered in a few of the eight
+            // words: a word that is empty in every lane is skipped before any per-lane work
+            if (__builtin_amdgcn_ballot_w64(wb[q] != 0) == 0) continue;
             const uint32_t keep = q == wlo ? m0 : (q == wlo + 1 ? m1 : ~0u);
             scan_word<kCheck>(wb[q] & keep, q * 32, u, sgn, P.W, own, row, best);
         }
