@@ -796,7 +796,7 @@ __global__ __launch_bounds__(kLds ? 512 : 256) void k_match(GroupDev G, MatchPar
 // Needs |cost| < 2^20 and d < 512; launch_match falls back to k_match otherwise.
 // ---------------------------------------------------------------------------
 template <bool kCheck>
-__device__ __forceinline__ void scan_word(uint32_t b, int base, int u, int sgn, int W, const uint4& own,
+__device__ __forceinline__ void scan_word(uint32_t b, int base, int pos, int W, const uint4& own,
                                           const uint4* row, int& best) {
     while (b) {
         const int i0 = __builtin_ctz(b);
@@ -805,7 +805,7 @@ __device__ __forceinline__ void scan_word(uint32_t b, int base, int u, int sgn, 
         const int i1 = has1 ? __builtin_ctz(b) : i0;   // odd count: evaluate the same one twice
         b &= b - 1;
         const int dc0 = base + i0, dc1 = base + i1;
-        int uw0 = u + __mul24(sgn, dc0), uw1 = u + __mul24(sgn, dc1);
+        int uw0 = pos + dc0, uw1 = pos + dc1;
         bool ok0 = true, ok1 = true;
         if (kCheck) {
             ok0 = (uint32_t)(uw0 - 2) < (uint32_t)(W - 4);
@@ -826,7 +826,7 @@ __device__ __forceinline__ void scan_word(uint32_t b, int base, int u, int sgn, 
 }
 
 template <bool kCheck>
-__device__ __forceinline__ float match_pixel_keyed(const uint4& own, const float4& pl, int u, int v, int sgn,
+__device__ __forceinline__ float match_pixel_keyed(const uint4& own, const float4& pl, int u, int v, int pos,
                                                    const uint4* row, const uint32_t* __restrict__ bits,
                                                    const int* s_P, const int32_t* __restrict__ gP,
                                                    const MatchParams& P) {
@@ -859,18 +859,18 @@ __device__ __forceinline__ float match_pixel_keyed(const uint4& own, const float
             // words: a word that is empty in every lane is skipped before any per-lane work
             if (__builtin_amdgcn_ballot_w64(wb[q] != 0) == 0) continue;
             const uint32_t keep = q == wlo ? m0 : (q == wlo + 1 ? m1 : ~0u);
-            scan_word<kCheck>(wb[q] & keep, q * 32, u, sgn, P.W, own, row, best);
+            scan_word<kCheck>(wb[q] & keep, q * 32, pos, P.W, own, row, best);
         }
     } else {
         for (int q = 0; q < P.gwords; q++) {
             const uint32_t keep = q == wlo ? m0 : (q == wlo + 1 ? m1 : ~0u);
-            scan_word<kCheck>(bits[q] & keep, q * 32, u, sgn, P.W, own, row, best);
+            scan_word<kCheck>(bits[q] & keep, q * 32, pos, P.W, own, row, best);
         }
     }
     // the band, two disparities per trip, with the plane prior
     for (int dc = dlo; dc <= dhi; dc += 2) {
         const int dc1 = dc + 1 <= dhi ? dc + 1 : dc;
-        int uw0 = u + __mul24(sgn, dc), uw1 = u + __mul24(sgn, dc1);
+        int uw0 = pos + dc, uw1 = pos + dc1;
         bool ok0 = true, ok1 = true;
         if (kCheck) {
             ok0 = (uint32_t)(uw0 - 2) < (uint32_t)(P.W - 4);
@@ -920,17 +920,18 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P, 
     {
         const uint4* l1 = reinterpret_cast<const uint4*>(G.desc + (size_t)(2 * pair) * N * 16) + (size_t)line * P.W;
         const uint4* l2 = l1 + N;
+        // the image-2 row is stored REVERSED: a left-map candidate u - d is then slot (W-1-u) + d, a
+        // right-map candidate u + d slot u + d of the image-1 row -- position + disparity on both
+        // sides, one v_lshl_add per address
         for (int i = threadIdx.x; i < 2 * P.W; i += blockDim.x)
-            s_rows[i] = i < P.W ? l1[i] : l2[i - P.W];
+            s_rows[i] = i < P.W ? l1[i] : l2[2 * P.W - 1 - i];
     }
     __syncthreads();
     const int half = blockDim.x >> 1;
     const int side = (int)threadIdx.x >= half;        // wave-uniform: half is a multiple of 64
     const int z = 2 * pair + side;
-    const uint4* own_row = s_rows + side * P.W;
     const uint4* oth_row = s_rows + (1 - side) * P.W;
     const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
-    const int sgn = side ? 1 : -1;
     const int32_t* own_t = G.owner + (size_t)z * N + (size_t)v * P.W;
     const uint32_t* row_bits =
         G.mask + ((size_t)z * P.gw * P.gh + (size_t)(v / P.grid_size) * P.gw) * P.gwords;
@@ -945,13 +946,14 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P, 
         const bool inner = side ? u + P.disp_max < P.W - 2 : u - P.disp_max >= 2;
         const bool wave_inner = __builtin_amdgcn_ballot_w64(live && !inner) == 0;
         if (live) {
-            const uint4 own = own_row[u];
+            const int pos = side ? u : P.W - 1 - u;          // this pixel in the other row's slot order
+            const uint4 own = side ? s_rows[2 * P.W - 1 - u] : s_rows[u];
             if ((int)texture16(own) >= P.match_texture) {
                 const float4 pl = *reinterpret_cast<const float4*>(G.raster + tri0 + t);
                 const uint32_t* bits = row_bits + (size_t)__umulhi((uint32_t)u, P.grid_magic) * P.gwords;
                 out = wave_inner
-                          ? match_pixel_keyed<false>(own, pl, u, v, sgn, oth_row, bits, s_P, G.P, P)
-                          : match_pixel_keyed<true>(own, pl, u, v, sgn, oth_row, bits, s_P, G.P, P);
+                          ? match_pixel_keyed<false>(own, pl, u, v, pos, oth_row, bits, s_P, G.P, P)
+                          : match_pixel_keyed<true>(own, pl, u, v, pos, oth_row, bits, s_P, G.P, P);
             }
         }
         if (!kLr || write_raw) out_row[x] = out;
