@@ -848,6 +848,7 @@ __device__ __forceinline__ float match_pixel_keyed(const uint4& own, const float
         m0 = ~(bm << sh);
         m1 = sh ? ~(bm >> (32 - sh)) : ~0u;
     }
+    const int vmask = valid ? -1 : 0;   // planes of invalid triangles carry no prior (elas.cpp:921-927)
     int best = 0x7FFFFFFF;
     if (P.gwords == 8) {
         const uint4 lo4 = reinterpret_cast<const uint4*>(bits)[0];
@@ -882,8 +883,9 @@ __device__ __forceinline__ float match_pixel_keyed(const uint4& own, const float
         int dd0 = dc - d_plane, dd1 = dc1 - d_plane;
         dd0 = dd0 < 0 ? -dd0 : dd0;
         dd1 = dd1 < 0 ? -dd1 : dd1;
-        const int p0 = valid ? (dd0 < 64 ? s_P[dd0] : gP[dd0]) : 0;
-        const int p1 = valid ? (dd1 < 64 ? s_P[dd1] : gP[dd1]) : 0;
+        // dd <= plane_radius <= 15 here (launch_match), always inside the LDS copy of the table
+        const int p0 = s_P[dd0] & vmask;
+        const int p1 = s_P[dd1] & vmask;
         int k0 = ((int)sad16(own, o0) + p0) * 1024 + 512 + dc;
         int k1 = ((int)sad16(own, o1) + p1) * 1024 + 512 + dc1;
         if (kCheck) {
