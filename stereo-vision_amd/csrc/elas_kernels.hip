@@ -952,7 +952,7 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P, 
             const uint4 own = side ? s_rows[2 * P.W - 1 - u] : s_rows[u];
             if ((int)texture16(own) >= P.match_texture) {
                 const float4 pl = *reinterpret_cast<const float4*>(G.raster + tri0 + t);
-                const uint32_t* bits = row_bits + (size_t)__umulhi((uint32_t)u, P.grid_magic) * P.gwords;
+                const uint32_t* bits = row_bits + __umulhi((uint32_t)u, P.grid_magic) * (uint32_t)P.gwords;
                 out = wave_inner
                           ? match_pixel_keyed<false>(own, pl, u, v, pos, oth_row, bits, s_P, G.P, P)
                           : match_pixel_keyed<true>(own, pl, u, v, pos, oth_row, bits, s_P, G.P, P);
@@ -1077,11 +1077,13 @@ __device__ __forceinline__ bool seg_joined(float a, float b, float thr) {
 // deep.  k_seg_sum adds the local sizes of merged components into their root.
 constexpr int CX = 64, CY = 16;
 
-__device__ __forceinline__ int lds_find(volatile int* L, int x) {
-    int p = L[x];
+// (relaxed workgroup-scope loads: re-read on every hop like a volatile access, but they stay
+// ds_read_b32 -- a volatile int* loses the LDS address space and compiles to flat loads)
+__device__ __forceinline__ int lds_find(int* L, int x) {
+    int p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     while (p != x) {
         x = p;
-        p = L[x];
+        p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     return x;
 }
