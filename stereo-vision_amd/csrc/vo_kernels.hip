@@ -255,6 +255,48 @@ __global__ __launch_bounds__(64) void k_vo_ransac(const svh_p_match* __restrict_
     if (lane == 0) hyp_count[k] = count;
 }
 
+// Gauss-Newton refinement on the inlier set (viso_stereo.cpp:122-150 on the winning hypothesis):
+// all 256 threads fill the Jacobian / residual rows, wave 0 forms and solves the normal equations.
+__device__ __forceinline__ int vo_refine_loop(double* J, double* res, const svh_p_match* __restrict__ pm,
+                                              const int32_t* __restrict__ inliers, int nin, const VoCalib& c,
+                                              double* s_tr, int* s_status, int t) {
+    int status = VO_UPDATED, iter = 0;
+    while (status == VO_UPDATED) {
+        double tr[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) tr[i] = s_tr[i];
+        const Rot R = make_rot(tr);
+        for (int a = t; a < nin; a += 256) {
+            const svh_p_match m = pm[inliers[a]];
+            const Point3 P = back_project(m, c);
+            const Pred q = predict(R, tr, P, c);
+            const double w = obs_weight((double)m.u1c, c);
+#pragma unroll
+            for (int col = 0; col < 6; col++) {
+                double j0, j1, j2;
+                jacobian_col(R, P, q, w, c, col, &j0, &j1, &j2);
+                J[(size_t)(4 * a + 0) * 6 + col] = j0;
+                J[(size_t)(4 * a + 1) * 6 + col] = j1;
+                J[(size_t)(4 * a + 2) * 6 + col] = j2;
+                J[(size_t)(4 * a + 3) * 6 + col] = j1;
+            }
+            res[4 * a + 0] = w * ((double)m.u1c - q.p[0]);
+            res[4 * a + 1] = w * ((double)m.v1c - q.p[1]);
+            res[4 * a + 2] = w * ((double)m.u2c - q.p[2]);
+            res[4 * a + 3] = w * ((double)m.v2c - q.p[3]);
+        }
+        __syncthreads();
+        if (t < 64) {   // wave 0 forms and solves the normal equations
+            const int st = wave_gn_step(J, res, 4 * nin, t, s_tr, 1e-8);
+            if (t == 0) *s_status = st;
+        }
+        __syncthreads();
+        status = *s_status;
+        if (iter++ > 100 || status == VO_CONVERGED) break;
+    }
+    return status == VO_CONVERGED;
+}
+
 // One workgroup of 256.  The Jacobian / residual rows of the inliers live in LDS when they fit
 // (lds_rows >= 4 * inliers; the launcher sizes the dynamic LDS from N), else in global scratch.
 __global__ __launch_bounds__(256) void k_vo_refine(const svh_p_match* __restrict__ pm, int N, int iters,
@@ -302,46 +344,14 @@ __global__ __launch_bounds__(256) void k_vo_refine(const svh_p_match* __restrict
         if (t < 6) s_tr[t] = hyp_tr[6 * best + t];
     }
     __syncthreads();
-    const bool in_lds = 4 * nin <= lds_rows;
-    double* J = in_lds ? s_rows : Jg;
-    double* res = in_lds ? s_rows + (size_t)6 * lds_rows : resg;
+    // two calls, so that each sees where J / res live (LDS: ds_read / ds_write; global scratch
+    // otherwise) -- one generic pointer would turn every access into a flat load
     int success = 0;
     if (nin >= 6) {
-        int status = VO_UPDATED, iter = 0;
-        while (status == VO_UPDATED) {
-            double tr[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++) tr[i] = s_tr[i];
-            const Rot R = make_rot(tr);
-            for (int a = t; a < nin; a += 256) {
-                const svh_p_match m = pm[out_inliers[a]];
-                const Point3 P = back_project(m, c);
-                const Pred q = predict(R, tr, P, c);
-                const double w = obs_weight((double)m.u1c, c);
-#pragma unroll
-                for (int col = 0; col < 6; col++) {
-                    double j0, j1, j2;
-                    jacobian_col(R, P, q, w, c, col, &j0, &j1, &j2);
-                    J[(size_t)(4 * a + 0) * 6 + col] = j0;
-                    J[(size_t)(4 * a + 1) * 6 + col] = j1;
-                    J[(size_t)(4 * a + 2) * 6 + col] = j2;
-                    J[(size_t)(4 * a + 3) * 6 + col] = j1;
-                }
-                res[4 * a + 0] = w * ((double)m.u1c - q.p[0]);
-                res[4 * a + 1] = w * ((double)m.v1c - q.p[1]);
-                res[4 * a + 2] = w * ((double)m.u2c - q.p[2]);
-                res[4 * a + 3] = w * ((double)m.v2c - q.p[3]);
-            }
-            __syncthreads();
-            if (t < 64) {   // wave 0 forms and solves the normal equations
-                const int st = wave_gn_step(J, res, 4 * nin, t, s_tr, 1e-8);
-                if (t == 0) s_status = st;
-            }
-            __syncthreads();
-            status = s_status;
-            if (iter++ > 100 || status == VO_CONVERGED) break;
-        }
-        success = status == VO_CONVERGED;
+        if (4 * nin <= lds_rows)
+            success = vo_refine_loop(s_rows, s_rows + (size_t)6 * lds_rows, pm, out_inliers, nin, c, s_tr, &s_status, t);
+        else
+            success = vo_refine_loop(Jg, resg, pm, out_inliers, nin, c, s_tr, &s_status, t);
     }
     if (t == 0) {
         out->success = success;
