@@ -459,6 +459,16 @@ def main():
                                      "frac_of_peak": round(gbs / HBM_PEAK_GBS, 3),
                                      "valu_busy": v["valu_busy"]})
                 rows.sort(key=lambda r: -r["hbm_GBps"])
+                # issue-slot view of the same run: wave-level VALU instructions of one pair (PMC,
+                # kernels serialised) x this run's pairs/s, against 1024 SIMDs issuing one VALU
+                # instruction per 4 cycles at the nominal 2.4 GHz
+                if args.workload == "kitti":
+                    per_pair = sum(v["valu_wave_instr"] for v in iss["kernels"].values()) / float(tr["pairs_per_launch"])
+                    rate = total_pairs / elapsed / world
+                    roofline["valu_issue"] = {"wave_instr_per_pair": round(per_pair),
+                                              "frac_of_issue_slots": round(per_pair * rate * 4 / (1024 * 2.4e9), 3),
+                                              "note": "SQ_INSTS_VALU per pair (profiles/*_pmc_issue.json) x measured "
+                                                      "pairs/s; 256 CUs x 4 SIMDs, 4 cycles per wave64 VALU op"}
                 roofline["isolated_kernels_hbm"] = {"source": "profiles/*_pmc_traffic.json + *_pmc_issue.json "
                                                               "(rocprofv3 --pmc, kernels serialised, KITTI workload)",
                                                     "top": rows[:5]}
