@@ -173,6 +173,37 @@ def vo_bench(iters=40):
     return out
 
 
+def map_bench(iters=30):
+    """3-D reprojection + map fusion of one 1242x375 frame (createCurrentMap +
+    addDisparityMapToReconstruction), device vs the CPU restatement (oracle, "port": the reference's
+    own code sits in Qt classes that cannot be built here)"""
+    import test_map as TM
+    from svhip import mapper
+    import helpers as Hh
+    (f, cu, cv, base), frames = TM.synth_frames(W, H, 6, seed=3)
+
+    def run(mk, n):
+        m = mk()
+        d, img, Ht, g = frames[0]
+        m.add(d, img, Ht, g)
+        t = time.perf_counter()
+        for i in range(n):
+            d, img, Ht, g = frames[1 + i % 5]
+            m.add(d, img, Ht, g)
+        ms = 1e3 * (time.perf_counter() - t) / n
+        return ms, len(m.points(0)), len(m.points(1))
+
+    run(lambda: mapper.Mapper(f, cu, cv, base, 20), 3)
+    ms, n0, n1 = run(lambda: mapper.Mapper(f, cu, cv, base, 20), iters)
+    out = {"workload": "map fusion of synthetic %dx%d frames (host disparity map in, point lists on the device)" % (W, H),
+           "frame_ms": ms, "points_prev": n0, "points_curr": n1}
+    L = TM.oracle_map(Hh.oracle())
+    cms, c0, c1 = run(lambda: TM.OracleMapper(L, TM.MapParams(f, cu, cv, base, 20)), 5)
+    out["cpu_port"] = {"frame_ms": cms, "cores": 1, "kind": "port",
+                       "note": "oracle/map_oracle.cpp, 5 frames (the device leg runs %d; parity is tests/test_map.py)" % iters}
+    return out
+
+
 def _cpu_quota():
     """CPU cores this process may use (cgroup v2 cpu.max), None when unlimited / unknown"""
     try:
@@ -531,6 +562,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["matcher"] = matcher_bench()     # before the CPU leg: the GPU is still at its clocks
             out["visual_odometry"] = vo_bench()
+            out["map_fusion"] = map_bench()
             out["cpu_baseline"] = cpu_baseline(I1, I2, params)
         print(json.dumps(out), flush=True)
     if world > 1:

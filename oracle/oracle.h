@@ -21,6 +21,7 @@
 #define ORACLE_H
 #include <stdint.h>
 #include "../include/svh.h"
+#include "../include/svh_map.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -108,6 +109,18 @@ int32_t orc_vo_get_inliers(orc_vo* v, int32_t* out, int32_t cap);
 int32_t orc_vo_num_matches(orc_vo* v);
 int32_t orc_vo_get_matches(orc_vo* v, svh_p_match* out, int32_t cap);
 float   orc_vo_get_gain(orc_vo* v, const int32_t* inliers, int32_t n);
+
+/* ---- map fusion (stereomapper/stereothread.cpp:180-437), see map_oracle.cpp ---------------- */
+typedef svh_map_params orc_map_params;
+typedef struct orc_map orc_map;
+void     orc_map_coeffs(const orc_map_params* p, const double* H16, float* hcf12, float* hfc4, float* pfc12);
+orc_map* orc_map_create(const orc_map_params* p);
+void     orc_map_destroy(orc_map* m);
+void     orc_map_clear(orc_map* m);
+void     orc_map_add(orc_map* m, const float* D1, const uint8_t* I1, const int32_t* dims, const double* H16,
+                     float gain);
+int64_t  orc_map_points(const orc_map* m, int32_t which, float* xyzv, int64_t cap);
+void     orc_map_planes(const orc_map* m, float* out5);
 
 #ifdef __cplusplus
 }

@@ -364,4 +364,26 @@ float ref_vo_get_gain(ref_vo* h, const int32_t* inl, int32_t n) {
 }
 void ref_srand(uint32_t s) { srand(s); }
 
+
+// ---- coefficient matrices of stereomapper's map fusion, computed with the reference's own Matrix
+// (stereothread.cpp:196-199, 306-314, 444-455): pins oracle/map_oracle.cpp's orc_map_coeffs
+void ref_map_coeffs(const double* H16, float f, float cu, float cv, float* hcf12, float* hfc4, float* pfc12) {
+    Matrix Ht(4, 4);
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) Ht._val[i][j] = H16[4 * i + j];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++) hcf12[4 * i + j] = Ht._val[i][j];
+    Matrix H = Matrix::inv(Ht);
+    for (int j = 0; j < 4; j++) hfc4[j] = H._val[2][j];
+    Matrix K(3, 3);
+    K._val[0][0] = f;
+    K._val[1][1] = f;
+    K._val[0][2] = cu;
+    K._val[1][2] = cv;
+    K._val[2][2] = 1;
+    Matrix P = K * H.getMat(0, 0, 2, 3);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++) pfc12[4 * i + j] = P._val[i][j];
+}
+
 }  // extern "C"

@@ -20,7 +20,8 @@ def S():
 
 def test_exports_every_declared_symbol(S):
     hdr = open(os.path.join(H.ROOT, "include", "svh.h")).read() + \
-        open(os.path.join(H.ROOT, "include", "svh_kitti.h")).read()
+        open(os.path.join(H.ROOT, "include", "svh_kitti.h")).read() + \
+        open(os.path.join(H.ROOT, "include", "svh_map.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = sorted(set(re.findall(r"\b(svh_[a-z0-9_]+)\s*\(", hdr)))
     assert len(names) >= 15
