@@ -206,3 +206,45 @@ def test_many_points_on_one_pixel_and_strided_input(oracle_lib):
         assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), which
     assert np.array_equal(o.planes().view(np.uint32), g.planes().view(np.uint32))
     assert len(o.points(0)) < 0.9 * np.count_nonzero(d0 > 0)      # many merged into the patch
+
+
+@pytest.mark.gpu
+def test_consumes_the_disparity_map_elas_left_on_the_device(oracle_lib):
+    """ELAS -> map fusion without the map leaving the GPU: svh_elas_process_batch_device writes D1
+    to device memory, svh_map_add reads it there; same points as with a downloaded copy"""
+    import svhip as S
+    from svhip import mapper
+    hip = C.CDLL("libamdhip64.so")
+
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
+        return p
+
+    l, r = H.golden_pair("urban3_640x240")
+    h, w = l.shape
+    n = w * h
+    dI1, dI2, dD1, dD2 = dmalloc(n), dmalloc(n), dmalloc(4 * n), dmalloc(4 * n)
+    assert hip.hipMemcpy(dI1, C.c_void_p(l.ctypes.data), C.c_size_t(n), 1) == 0
+    assert hip.hipMemcpy(dI2, C.c_void_p(r.ctypes.data), C.c_size_t(n), 1) == 0
+    e = S.Elas(H.robotics())
+    st = e.process_batch_device(1, dI1.value, dI2.value, n, dD1.value, dD2.value, 4 * n, w, h, w)
+    assert st == [0]
+    D1 = np.zeros((h, w), np.float32)
+    assert hip.hipMemcpy(C.c_void_p(D1.ctypes.data), dD1, C.c_size_t(4 * n), 2) == 0   # DeviceToHost
+    assert (D1 > 0).mean() > 0.5
+    a = mapper.Mapper(645.24, 321.0, 118.0, 0.5707)
+    b = mapper.Mapper(645.24, 321.0, 118.0, 0.5707)
+    o = OracleMapper(oracle_map(oracle_lib), MapParams(645.24, 321.0, 118.0, 0.5707, 20))
+    for k in range(2):
+        Ht = pose(0, 0.004 * k, 0, 0.01 * k, 0, 0.3 * k)
+        a.add(None, l, Ht, 1.05, device_ptr=dD1.value)
+        b.add(D1, l, Ht, 1.05)
+        o.add(D1, l, Ht, 1.05)
+        for which in (0, 1):
+            pa, pb, po = a.points(which), b.points(which), o.points(which)
+            assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32))
+            assert np.array_equal(pa.view(np.uint32), po.view(np.uint32))
+    assert len(a.points(1)) > 50000
+    for p in (dI1, dI2, dD1, dD2):
+        hip.hipFree(p)
