@@ -54,6 +54,11 @@ int32_t svh_map_add(svh_map* m, const float* D1, int32_t d1_on_device, const uin
  * Copies up to cap points to `xyzv` (may be NULL) and returns the number of points.            */
 int64_t svh_map_points(svh_map* m, int32_t which, float* xyzv, int64_t cap);
 
+/* The colour-coded disparity map StereoThread shows next to the image (stereothread.cpp:117-147):
+ * hue from red (near, d >= 200) over green to magenta (far), black where D <= 0.  D: n floats on the
+ * host or (d_on_device) on the device; rgb receives 3*n floats on the host, interleaved.           */
+int32_t svh_disparity_colormap(const float* D, int32_t d_on_device, int64_t n, float* rgb);
+
 /* Test access: the current map's planes I, D, X, Y, Z (5 x width*height floats) after the frame. */
 int32_t svh_map_planes(svh_map* m, float* out5, size_t cap_floats);
 

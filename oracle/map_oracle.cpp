@@ -238,6 +238,25 @@ int64_t orc_map_points(const orc_map* m, int32_t which, float* out, int64_t cap)
     return n;
 }
 
+// colour-coded disparity, stereothread.cpp:117-147 (untouched cells -- none for finite input -- are 0)
+void orc_disparity_colormap(const float* D, int64_t n, float* rgb) {
+    const float d_max = 200;
+    for (int64_t i = 0; i < n; i++) {
+        float* c = rgb + 3 * i;
+        c[0] = c[1] = c[2] = 0;
+        const float val = std::min(D[i] / d_max, (float)1.0);
+        if (val <= 0) continue;
+        const float h2 = 6.0 * (1.0 - val);
+        const float x = 1.0 * (1.0 - fabs(fmodf(h2, (float)2.0) - 1.0));
+        if (0 <= h2 && h2 < 1)       { c[0] = 1; c[1] = x; c[2] = 0; }
+        else if (1 <= h2 && h2 < 2)  { c[0] = x; c[1] = 1; c[2] = 0; }
+        else if (2 <= h2 && h2 < 3)  { c[0] = 0; c[1] = 1; c[2] = x; }
+        else if (3 <= h2 && h2 < 4)  { c[0] = 0; c[1] = x; c[2] = 1; }
+        else if (4 <= h2 && h2 < 5)  { c[0] = x; c[1] = 0; c[2] = 1; }
+        else if (5 <= h2 && h2 <= 6) { c[0] = 1; c[1] = 0; c[2] = x; }
+    }
+}
+
 // the maps after the last frame (I, D, X, Y, Z planes of w*h floats): tests compare them too
 void orc_map_planes(const orc_map* m, float* out5) {
     const size_t n = (size_t)m->prev.w * m->prev.h;

@@ -121,6 +121,7 @@ void     orc_map_add(orc_map* m, const float* D1, const uint8_t* I1, const int32
                      float gain);
 int64_t  orc_map_points(const orc_map* m, int32_t which, float* xyzv, int64_t cap);
 void     orc_map_planes(const orc_map* m, float* out5);
+void     orc_disparity_colormap(const float* D, int64_t n, float* rgb);
 
 #ifdef __cplusplus
 }

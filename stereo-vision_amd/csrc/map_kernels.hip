@@ -254,6 +254,27 @@ __global__ __launch_bounds__(256) void k_map_scatter(const uint8_t* __restrict__
         if (addr[k] >= 0) out[pos++] = make_float4(pl.X[addr[k]], pl.Y[addr[k]], pl.Z[addr[k]], pl.I[addr[k]]);
 }
 
+// ---- colour-coded disparity (stereothread.cpp:117-147) -------------------------------------------
+__global__ __launch_bounds__(256) void k_disp_color(const float* __restrict__ D, long long n, float* __restrict__ rgb) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float val = fminf(__fdiv_rn(D[i], 200.f), 1.0f);
+    float r = 0.f, g = 0.f, b = 0.f;
+    if (val > 0) {
+        const float h2 = (float)(6.0 * (1.0 - (double)val));
+        const float x = (float)(1.0 * (1.0 - fabs((double)fmodf(h2, 2.0f) - 1.0)));
+        if (0 <= h2 && h2 < 1)       { r = 1; g = x; b = 0; }
+        else if (1 <= h2 && h2 < 2)  { r = x; g = 1; b = 0; }
+        else if (2 <= h2 && h2 < 3)  { r = 0; g = 1; b = x; }
+        else if (3 <= h2 && h2 < 4)  { r = 0; g = x; b = 1; }
+        else if (4 <= h2 && h2 < 5)  { r = x; g = 0; b = 1; }
+        else if (5 <= h2 && h2 <= 6) { r = 1; g = 0; b = x; }
+    }
+    rgb[3 * i + 0] = r;
+    rgb[3 * i + 1] = g;
+    rgb[3 * i + 2] = b;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -448,6 +469,28 @@ int64_t svh_map_points(svh_map* m, int32_t which, float* xyzv, int64_t cap) {
         (void)hipMemcpy(xyzv, m->pts[k], (size_t)std::min(n, cap) * sizeof(float4), hipMemcpyDeviceToHost);
     }
     return n;
+}
+
+int32_t svh_disparity_colormap(const float* D, int32_t d_on_device, int64_t n, float* rgb) {
+    if (!D || !rgb || n < 0) return svh::fail(SVH_ERR_BAD_ARG, "null argument");
+    if (n == 0) return SVH_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
+        return svh::fail(SVH_ERR_NO_DEVICE, "no HIP device visible: libsvhip has no CPU fallback");
+    float *dD = nullptr, *dC = nullptr;
+    MAP_TRY(hipMalloc(&dC, (size_t)n * 12));
+    const float* src = D;
+    if (!d_on_device) {
+        MAP_TRY(hipMalloc(&dD, (size_t)n * 4));
+        MAP_TRY(hipMemcpy(dD, D, (size_t)n * 4, hipMemcpyHostToDevice));
+        src = dD;
+    }
+    hipLaunchKernelGGL(k_disp_color, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, src, (long long)n, dC);
+    const hipError_t e = hipMemcpy(rgb, dC, (size_t)n * 12, hipMemcpyDeviceToHost);
+    (void)hipFree(dD);
+    (void)hipFree(dC);
+    if (e != hipSuccess) return svh::fail(SVH_ERR_HIP, std::string("colormap: ") + hipGetErrorString(e));
+    return SVH_OK;
 }
 
 int32_t svh_map_planes(svh_map* m, float* out5, size_t cap_floats) {

@@ -24,6 +24,7 @@ def _bind():
         L.svh_map_points.restype = C.c_int64
         L.svh_map_points.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         L.svh_map_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.svh_disparity_colormap.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
         L._map_bound = True
     return L
 
@@ -77,3 +78,13 @@ class Mapper:
         h, self._h = getattr(self, "_h", None), None
         if h:
             self._L.svh_map_destroy(h)
+
+
+def disparity_colormap(D):
+    """[h, w] float32 disparities -> [h, w, 3] float32 colours (stereothread.cpp:117-147)"""
+    D = np.ascontiguousarray(D, np.float32)
+    out = np.zeros(D.shape + (3,), np.float32)
+    rc = _bind().svh_disparity_colormap(D.ctypes.data, 0, D.size, out.ctypes.data)
+    if rc:
+        raise SvhError(rc, last_error())
+    return out

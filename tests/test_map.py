@@ -248,3 +248,17 @@ def test_consumes_the_disparity_map_elas_left_on_the_device(oracle_lib):
     assert len(a.points(1)) > 50000
     for p in (dI1, dI2, dD1, dD2):
         hip.hipFree(p)
+
+
+@pytest.mark.gpu
+def test_disparity_colormap_matches_oracle(oracle_lib):
+    from svhip import mapper
+    rng = np.random.default_rng(4)
+    D = rng.uniform(-20, 260, (97, 131)).astype(np.float32)
+    D[0, :12] = [0, -1, -10, 200, 199.99998, 200.00002, 1e-30, 33.333332, 66.666664, 100, 133.33333, 166.66667]
+    want = np.zeros(D.shape + (3,), np.float32)
+    oracle_lib.orc_disparity_colormap.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    oracle_lib.orc_disparity_colormap(D.ctypes.data, D.size, want.ctypes.data)
+    got = mapper.disparity_colormap(D)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.all(got[D <= 0] == 0) and got[0, 3].tolist() == [1.0, 0.0, 0.0]
