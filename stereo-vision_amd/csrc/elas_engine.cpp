@@ -123,6 +123,8 @@ struct Lane {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t wait_ev = nullptr;   // completion marker polled by lane_wait
+    hipStream_t copy_stream = nullptr;   // early D2H of maps that are final before the stream is done
+    hipEvent_t match_ev = nullptr, copy_ev = nullptr;
     bool poll_wait = false;         // batch workers sleep-poll; single calls spin (lowest latency)
     bool parallel_host = true;      // host stage may use helper threads (off when every core is a worker)
     // geometry the buffers were sized for
@@ -583,6 +585,17 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     const bool tiles = !tapping && post_tiles_ok(p);   // gap + mean (+ speckle mask) tile kernels
     // the row kernel also applies the L/R check (its inputs are the row it just matched)
     const bool lr_done = launch_match(cx, p, d, g, G, &out, tapping);
+    // With postprocess_only_left the right map is final once the L/R check is done: its copy to the
+    // caller's host buffer runs on a second stream while the left map is still being post-processed.
+    const bool early_d2 = !io.out_device && lr_done && !tapping && p.postprocess_only_left;
+    if (early_d2) {
+        if (!L.copy_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&L.copy_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&L.match_ev, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&L.copy_ev, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(L.match_ev, s));
+    }
     if (tapping) {
         rc = tap_dev(L, taps, SVH_ELAS_D1_RAW, L.Draw, DN); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_D2_RAW, L.Draw + DN, DN); if (rc) return rc;
@@ -611,13 +624,23 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         if (p.filter_median) launch_median(cx, d, g, nside, G, out, ps);
     }
 
-    if (!io.out_device)
+    if (!io.out_device) {
+        if (early_d2) {   // (issued after the post-processing launches: a pageable copy blocks this thread)
+            HIP_TRY(hipStreamWaitEvent(L.copy_stream, L.match_ev, 0));
+            for (int32_t j = 0; j < g; j++)
+                if (hdr->active[j])
+                    HIP_TRY(hipMemcpyAsync(io.hD[1][j], L.D + ((size_t)2 * j + 1) * DN, DN * sizeof(float),
+                                           hipMemcpyDeviceToHost, L.copy_stream));
+            HIP_TRY(hipEventRecord(L.copy_ev, L.copy_stream));
+        }
         for (int32_t j = 0; j < g; j++) {
             if (!hdr->active[j]) continue;
-            for (int k = 0; k < 2; k++)
+            for (int k = 0; k < (early_d2 ? 1 : 2); k++)
                 HIP_TRY(hipMemcpyAsync(io.hD[k][j], L.D + ((size_t)2 * j + k) * DN, DN * sizeof(float),
                                        hipMemcpyDeviceToHost, s));
         }
+        if (early_d2) HIP_TRY(hipStreamWaitEvent(s, L.copy_ev, 0));   // the lane's stream ends after both
+    }
     HP_MARK(HP_ENQ_B);
     if (!(mode & RG_FINISH)) return SVH_OK;
     HIP_TRY(lane_wait(L));
