@@ -329,7 +329,7 @@ private:
             for (int32_t i = 0; i < n; i++) {
                 const uint64_t e = ly[i];
                 const int32_t low = (e >> 32) < pivot;
-                tmp[low ? a : b] = e;
+                tmp[b + ((a - b) & -low)] = e;   // a or b without a branch (random points mispredict)
                 a += low;
                 b += 1 - low;
             }
@@ -339,7 +339,7 @@ private:
             for (int32_t i = 0; i < n; i++) {
                 const uint64_t e = lx[i];
                 const int32_t low = (e & 0xffffffffu) < pivot;
-                tmp[low ? a : b] = e;
+                tmp[b + ((a - b) & -low)] = e;
                 a += low;
                 b += 1 - low;
             }
