@@ -173,6 +173,18 @@ def test_cxx_dropin_header_builds():
     assert os.path.exists(os.path.join(H.ROOT, "tests", "cxx", "elas_dropin"))
 
 
+def test_headers_are_plain_c():
+    """svh.h, svh_kitti.h and svh_map.h compile as C99 -pedantic -Werror; the program links against
+    libsvhip.so and runs its host-side entries (PNG reader, parameter defaults, device-less refusal)"""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(H.ROOT, "tests", "cxx"), "capi_c99"], stdout=subprocess.DEVNULL)
+    png = os.path.join(H.ROOT, "tests", "golden", "viso_I1c.png")
+    out = subprocess.check_output([os.path.join(H.ROOT, "tests", "cxx", "capi_c99"), png, "1344", "391"]).decode()
+    want = H.read_pgm(os.path.join(H.ROOT, "tests", "golden", "viso_I1c.pgm"))
+    assert out.splitlines()[0] == "1344 391 %d" % want[0, 0]
+    assert "capi ok" in out
+
+
 def test_matcher_refuses_to_run_without_a_gpu(S):
     if S.device_count() > 0:
         pytest.skip("a GPU is present")
