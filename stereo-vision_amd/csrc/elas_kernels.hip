@@ -766,7 +766,12 @@ __global__ __launch_bounds__(kLds ? 512 : 256) void k_match(GroupDev G, MatchPar
                 int dd = dc - d_plane;
                 dd = dd < 0 ? -dd : dd;
                 const uint4 o = kLds ? s_row[uw - s0] : oth_line[uw];
-                const int val = (int)sad16(own, o) + (valid ? (dd < 64 ? s_P[dd] : G.P[dd]) : 0);
+                // (two separate loads: selecting between an LDS and a global POINTER would make the
+                // access a flat load)
+                int prior = s_P[dd < 64 ? dd : 63];
+                asm volatile("" : "+v"(prior));   // keeps the two loads from being merged back
+                if (dd >= 64) prior = G.P[dd];
+                const int val = (int)sad16(own, o) + (valid ? prior : 0);
                 if (val < min_val) {
                     min_val = val;
                     min_d = dc;
