@@ -3,25 +3,36 @@
 
   python bench.py --gpus N --steps K --warmup W [--batch B] [--lanes L]
 
-Workload (BASELINE.json configs[1]): KITTI-sized 1242x375 pairs, full ELAS
-ROBOTICS parameters, D1+D2 with L/R check, subsampling off.  A "step" is one
-pass of the hot path over one batch of B synthetic pairs that are already
-resident in HBM; disparity maps are written to HBM.  For N>1 the driver starts
-one process per GPU (torch.distributed.run); pairs are independent, so ranks
-shard them with no data-path collective ("weak" scaling: B pairs per rank and
-step) and only a tiny per-rank result record is gathered over RCCL.
+Workload (BASELINE.json configs[1]): the four KITTI-size 1242x375 crops of
+the reference's own urban{1..4} images (tests/golden/, offset x=51 y=8), tiled; full ELAS ROBOTICS
+parameters, D1+D2 with L/R check, subsampling off.  A "step" is one pass of the hot path over one
+batch of B pairs that are already resident in HBM; disparity maps are written to HBM.
+
+Multi-GPU: pairs are independent, so ranks shard them with no data-path collective ("weak"
+scaling: B pairs per rank and step); only a small per-rank record is gathered over RCCL.  The
+driver starts one process per GPU (torch.distributed.run).  From a plain shell `--gpus N` with N>1
+and no WORLD_SIZE in the environment makes this script start the N ranks itself (same launcher,
+127.0.0.1 rendezvous).  `--dist-backend gloo` lets several ranks share one GPU, which is how the
+N>1 path is exercised on a 1-GPU box.
 
 Besides the contract fields the JSON line carries
-  roofline      achieved algorithmic GB/s of the dominant kernel, from HIP events
-                recorded on the kernels' own streams (svh_profile_*), vs 8 TB/s
-  cpu_baseline  the reference Elas::process (oracle/_ref) timed on this host,
-                1 thread, on a bounded sample of the same pairs.
-torch is used only for device memory, the barrier and the result gather.
+  roofline                 achieved algorithmic GB/s of the dominant kernel, from HIP events
+                           recorded on the kernels' own streams (svh_profile_*), vs 8 TB/s
+  cpu_baseline             the reference Elas::process (oracle/_ref) on this host: 1 thread, and
+                           `nproc_workers` = one independent process per available core
+  throughput_host_buffers  the reference's ownership contract (host pointers in and out,
+                           SURVEY 8b) through svh_elas_process_batch on pinned buffers --
+                           PCIe-inclusive, never `value`
+  value_synthetic          the same step on seeded synthetic pairs (round-1 headline workload)
+  ranks                    per rank: pairs/s, host cores used, workers, host-core ceiling
+torch is used only for device memory, pinned memory, the barrier and the result gather.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,6 +46,7 @@ W, H = 1242, 375        # --workload kitti (BASELINE.json configs[1]); hd1080 re
 N_PIX = W * H
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_PIXEL_PAIR = 174.8   # staged model, whole Elas::process, per pixel
+URBAN = ["urban%d_1242x375" % i for i in (1, 2, 3, 4)]
 
 # algorithmic bytes per pair and kernel launch (SURVEY 8d staged model, N = W*H)
 ALG_BYTES_PER_PIXEL = {
@@ -58,45 +70,92 @@ def make_inputs(batch, seed0=1000):
     return I1, I2
 
 
-def cpu_baseline(I1, I2, params, budget_s=15.0):
-    """reference (or port) on host cores, 1 thread, bounded sample of the same pairs"""
+def urban_inputs():
+    """the four KITTI-size crops of the reference's urban images (committed under tests/golden)"""
     import helpers as Hh
-    n_done, t_used = 0, 0.0
+    pairs = [Hh.golden_pair(n) for n in URBAN]
+    return np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+
+
+def _cpu_run_fn(params, I1, I2):
+    """(kind, run(i)) for the CPU leg: the reference itself when oracle/_ref is present"""
+    import helpers as Hh
     D1 = np.zeros((H, W), np.float32)
     D2 = np.zeros((H, W), np.float32)
     dims = (C.c_int32 * 3)(W, H, W)
     if Hh.have_ref_elas():
         lib = C.CDLL(Hh.ref_elas_path())   # no ref_init(1): plain allocator, fair timing
-        kind = "reference"
 
         def run(i):
             lib.ref_elas_process(C.byref(params), I1[i].ctypes.data_as(C.c_void_p),
                                  I2[i].ctypes.data_as(C.c_void_p), D1.ctypes.data_as(C.c_void_p),
                                  D2.ctypes.data_as(C.c_void_p), dims)
-    else:
-        import svhip as S
-        lib = Hh.oracle()
-        kind = "port"
-        tri = C.cast(S.lib().svh_delaunay, C.c_void_p)   # timing leg only: Triangle is not restated
+        return "reference", run
+    import svhip as S
+    lib = Hh.oracle()
+    tri = C.cast(S.lib().svh_delaunay, C.c_void_p)   # timing leg only: Triangle is not restated
 
-        def run(i):
-            lib.orc_elas_process(C.byref(params), I1[i].ctypes.data_as(C.c_void_p),
-                                 I2[i].ctypes.data_as(C.c_void_p), D1.ctypes.data_as(C.c_void_p),
-                                 D2.ctypes.data_as(C.c_void_p), dims, tri)
+    def run(i):
+        lib.orc_elas_process(C.byref(params), I1[i].ctypes.data_as(C.c_void_p),
+                             I2[i].ctypes.data_as(C.c_void_p), D1.ctypes.data_as(C.c_void_p),
+                             D2.ctypes.data_as(C.c_void_p), dims, tri)
+    return "port", run
+
+
+def _cpu_loop(run, n_unique, budget_s, cap=400):
     run(0)  # warm
-    i = 0
-    while t_used < budget_s and n_done < 400:
+    n_done, t_used, i = 0, 0.0, 0
+    while t_used < budget_s and n_done < cap:
         t = time.perf_counter()
-        run(i % len(I1))
+        run(i % n_unique)
         t_used += time.perf_counter() - t
         n_done += 1
         i += 1
-    return {"value": n_done / t_used, "unit": "pairs/s", "cores": 1, "kind": kind,
-            "ms_per_pair": 1e3 * t_used / n_done,
-            "sample": "%d x Elas::process on the bench's own %dx%d synthetic pairs, 1 thread, "
-                      "%s" % (n_done, W, H, "oracle/_ref (reference compiled -O3 -msse3)" if kind == "reference"
-                              else "oracle/ scalar port"),
-            "host": _cpu_model(), "host_cores": os.cpu_count()}
+    return n_done, t_used
+
+
+def cpu_worker(budget_s):
+    """hidden mode (--cpu-worker S): one of the `nproc` independent CPU workers; no torch"""
+    import helpers as Hh
+    I1, I2 = urban_inputs()
+    kind, run = _cpu_run_fn(Hh.robotics(), I1, I2)
+    n, t = _cpu_loop(run, len(I1), budget_s)
+    print(json.dumps({"n": n, "t": t, "kind": kind}), flush=True)
+
+
+def cpu_baseline(I1, I2, params, what, budget_s=5.0, workers=0):
+    """reference (or port) on host cores on a bounded sample of the bench's own pairs: 1 thread,
+    and -- SURVEY 8(d): the only parallelism the reference admits -- one independent worker
+    process per available core, one pair each"""
+    kind, run = _cpu_run_fn(params, I1, I2)
+    n_done, t_used = _cpu_loop(run, len(I1), budget_s)
+    out = {"value": n_done / t_used, "unit": "pairs/s", "cores": 1, "kind": kind,
+           "ms_per_pair": 1e3 * t_used / n_done,
+           "sample": "%d x Elas::process on %s, 1 thread, %s"
+                     % (n_done, what, "oracle/_ref (reference compiled -O3 -msse3)" if kind == "reference"
+                        else "oracle/ scalar port"),
+           "host": _cpu_model(), "host_cores": os.cpu_count(), "host_cpu_quota": _cpu_quota()}
+    if workers > 1:
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(budget_s)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                 for _ in range(workers)]
+        recs = []
+        for p in procs:
+            o, _ = p.communicate(timeout=60 + 20 * budget_s)
+            try:
+                recs.append(json.loads(o.strip().splitlines()[-1]))
+            except (ValueError, IndexError):
+                pass
+        if recs:
+            # every worker loops for the same budget; throughput = pairs finished / slowest loop
+            tot = sum(r["n"] for r in recs)
+            out["nproc_workers"] = {
+                "value": tot / max(r["t"] for r in recs), "unit": "pairs/s", "workers": len(recs),
+                "cores": len(recs), "pairs": tot, "wall_s": round(time.perf_counter() - t0, 2),
+                "sample": "%d independent processes (one per available core), each Elas::process on the four "
+                          "urban crops for %.0f s" % (len(recs), budget_s)}
+    return out
 
 
 def matcher_bench(iters=40):
@@ -236,6 +295,47 @@ def read_profile(S):
     return out
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_spawn(argv, n):
+    """`python bench.py --gpus N` from a plain shell: start the N ranks with the same launcher the
+    driver uses (one process per GPU, rendezvous on 127.0.0.1)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL)
+    return subprocess.call(cmd, env=env)
+
+
+def load_pmc(build):
+    """the committed rocprofv3 --pmc summaries, only if they were taken on the library that is
+    loaded now (tools/pmc_*.py stamp them with svh_version(), which carries the source hash)"""
+    import glob
+    out = {"traffic": None, "issue": None, "notes": []}
+    for key, pat in (("traffic", "*_pmc_traffic.json"), ("issue", "*_pmc_issue.json")):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+        if not files:
+            continue
+        try:
+            d = json.load(open(files[-1]))
+        except (OSError, ValueError):
+            continue
+        if d.get("build") == build:
+            out[key] = d
+            out[key + "_file"] = os.path.basename(files[-1])
+        else:
+            out["notes"].append("%s was measured on build '%s', the loaded library is '%s': not quoted"
+                                % (os.path.basename(files[-1]), d.get("build", "unstamped"), build))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,11 +346,14 @@ def main():
                          "configs[3] / SURVEY 8(d) config 4 (synthetic 1920x1080, disp_max 255); "
                          "sequence = configs[2]: a 430-frame 1242x375 sequence streamed once per step, "
                          "frames sharded contiguously over the GPUs (strong scaling).  drive_0029 is "
-                         "not available offline: the frames cycle the two committed KITTI-size crops "
-                         "of the reference's urban images and two synthetic pairs")
+                         "not available offline: the frames cycle the four committed KITTI-size crops "
+                         "of the reference's urban images (SURVEY 8d config 3 substitute)")
+    ap.add_argument("--data", choices=("urban", "synthetic"), default="urban",
+                    help="kitti workload: the four urban crops tiled (default) or seeded synthetic pairs")
     ap.add_argument("--batch", type=int, default=0,
-                    help="pairs per step and GPU (0 = 768 for kitti, 8 for hd1080)")
-    ap.add_argument("--unique", type=int, default=256,
+                    help="pairs per step and GPU (0 = 6144 for kitti: a step of ~0.2 s, so that the "
+                         "driver's 20 steps run for seconds; 8 for hd1080)")
+    ap.add_argument("--unique", type=int, default=64,
                     help="different synthetic pairs generated per rank; the batch tiles them")
     ap.add_argument("--lanes", type=int, default=0,
                     help="double-buffered pipeline workers per GPU (0 = auto: 1.5 per available core, <= 24)")
@@ -263,26 +366,40 @@ def main():
                          "from exactly those launches); 0: a separate pass after them")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the default) or gloo (CPU collectives: lets several ranks "
-                         "share one GPU when the multi-rank path is smoke-tested on a 1-GPU box)")
+                         "share one GPU when the multi-rank path is exercised on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary legs (synthetic, host buffers, latency, Matcher, VO, map)")
+    ap.add_argument("--cpu-budget", type=float, default=5.0, help="seconds per CPU baseline leg")
+    ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
     ap.add_argument("--kitti-dir", default="",
                     help="--workload sequence on a real KITTI raw drive directory (image_00/, image_01/ "
                          "with data/ and timestamps.txt) instead of the 430-frame substitute")
     args = ap.parse_args()
+    if args.cpu_worker > 0:
+        return cpu_worker(args.cpu_worker)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_spawn(sys.argv[1:], args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     global W, H, N_PIX
     if args.workload == "hd1080":
         W, H = 1920, 1080
         N_PIX = W * H
+        args.data = "synthetic"
     kitti_frames = None
     if args.workload == "sequence" and args.kitti_dir:
         pass   # the drive is read below, after torch has brought up the HIP runtime
     elif args.workload == "sequence":
         from svhip import shard as _sh
-        lo_, hi_ = _sh.shard_range(430, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+        lo_, hi_ = _sh.shard_range(430, rank, world)
         args.batch = hi_ - lo_
         args.seq_first = lo_
     if args.batch <= 0:
-        args.batch = 768 if args.workload == "kitti" else 8
+        args.batch = 6144 if args.workload == "kitti" else 8
     if args.group <= 0:
         # hd1080: 8 pairs per step, one pair per lane
         args.group = 1 if args.workload == "hd1080" else 8
@@ -290,18 +407,21 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    if args.dist_backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if world > ndev and args.dist_backend == "nccl":
+        raise SystemExit("bench.py: %d ranks but %d GPU(s): RCCL needs one GPU per rank "
+                         "(--dist-backend gloo lets ranks share a GPU)" % (world, ndev))
+    device_index = local_rank % ndev
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where collectives run
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            raise SystemExit("bench.py: WORLD_SIZE>1 without MASTER_PORT (use --gpus N from a plain shell, "
+                             "or torch.distributed.run)")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -309,7 +429,8 @@ def main():
 
     import svhip as S
     import helpers as Hh
-    S.lib().svh_set_device(local_rank)
+    S.lib().svh_set_device(device_index)
+    build = S.lib().svh_version().decode()
     if args.workload == "sequence" and args.kitti_dir:
         from svhip import kitti as _kitti
         k1, k2, lo_, total_ = _kitti.load_shard(args.kitti_dir, rank, world)
@@ -319,38 +440,43 @@ def main():
         H, W = k1.shape[1:]
         N_PIX = W * H
     # workers per GPU: each is double-buffered and sleeps while it waits, so ~1.5 per available
-    # core keeps the cores busy with the host stage (lattice filters + Delaunay)
+    # core keeps the cores busy with the host stage
     avail = _cpu_quota() or (os.cpu_count() or 8)
-    lanes = args.lanes or int(max(2, min(24, round(1.5 * avail / max(world, 1)))))
+    cores_per_rank = avail / max(world, 1)
+    lanes = args.lanes or int(max(2, min(24, round(1.5 * cores_per_rank))))
     S.set_lanes(lanes)
     group = S.set_group(args.group)
 
     B = args.batch
     params = Hh.robotics()           # Elas::parameters(ROBOTICS), elas.h:91-116
-    # B pairs per step = `unique` different synthetic pairs, tiled (generation is the slow part;
-    # the library keeps nothing between pairs, so a repeated pair is full work)
+
+    def tile_to_device(a1, a2, first=0):
+        """B pairs = the unique pairs cycled (each copy at its own HBM address; the library keeps
+        nothing between pairs, so a repeated pair is full work)"""
+        idx = torch.tensor([(first + k) % len(a1) for k in range(B)], device=dev)
+        return (torch.from_numpy(a1).to(dev)[idx].contiguous(),
+                torch.from_numpy(a2).to(dev)[idx].contiguous())
+
     if kitti_frames is not None:
         U = B
         dI1 = torch.from_numpy(kitti_frames[0]).to(dev).contiguous()
         dI2 = torch.from_numpy(kitti_frames[1]).to(dev).contiguous()
         I1, I2 = kitti_frames[0], kitti_frames[1]
-    elif args.workload == "sequence":
-        # frame f of the sequence = cycle[f % 4]; this rank owns frames [seq_first, seq_first + B)
+        data = "KITTI raw drive " + os.path.basename(os.path.normpath(args.kitti_dir))
+        what = "the drive's frames"
+    elif args.workload == "sequence" or (args.workload == "kitti" and args.data == "urban"):
+        # frame f = crop f % 4; in the sequence workload this rank owns [seq_first, seq_first + B)
         U = 4
-        s1, s2 = make_inputs(2, seed0=4242)
-        cyc = [Hh.golden_pair("urban1_1242x375"), Hh.golden_pair("urban2_1242x375"),
-               (s1[0], s2[0]), (s1[1], s2[1])]
-        I1 = np.stack([c[0] for c in cyc])
-        I2 = np.stack([c[1] for c in cyc])
-        idx = torch.tensor([(args.seq_first + k) % 4 for k in range(B)], device=dev)
-        dI1 = torch.from_numpy(I1).to(dev)[idx].contiguous()
-        dI2 = torch.from_numpy(I2).to(dev)[idx].contiguous()
+        I1, I2 = urban_inputs()
+        dI1, dI2 = tile_to_device(I1, I2, getattr(args, "seq_first", 0))
+        data = "urban crops"
+        what = "the four 1242x375 urban crops"
     else:
         U = min(B, args.unique)
         I1, I2 = make_inputs(U, seed0=1000 + 100000 * rank)
-        reps = (B + U - 1) // U
-        dI1 = torch.from_numpy(I1).to(dev).repeat(reps, 1, 1)[:B].contiguous()
-        dI2 = torch.from_numpy(I2).to(dev).repeat(reps, 1, 1)[:B].contiguous()
+        dI1, dI2 = tile_to_device(I1, I2)
+        data = "synthetic"
+        what = "the bench's own %dx%d synthetic pairs" % (W, H)
     dD1 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     dD2 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
@@ -368,6 +494,7 @@ def main():
         torch.cuda.synchronize()
 
     t_spin = time.perf_counter()
+    step()
     while time.perf_counter() - t_spin < args.spinup:   # untimed: clocks up, lanes allocated
         step()
     for _ in range(args.warmup):
@@ -395,30 +522,42 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
-    host_cores_used = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / elapsed
+    cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
+    host_cores_used = cpu_s / elapsed
     if in_region:
         S.lib().svh_profile_enable(0)
         S.lib().svh_profile_only(None)
+    # the only collective on the path: a small per-rank result record (RCCL over xGMI, or gloo)
+    from svhip import shard
+    my_pairs = B * args.steps
+    rec = [float(my_pairs), float((dD1[0] >= 0).sum().item()), host_cores_used, float(lanes),
+           elapsed_local, cpu_s / my_pairs, float(device_index)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the only collective on the path: a tiny per-rank result record over RCCL
-        from svhip import shard
-        recs = shard.gather_records([float(B * args.steps), float((dD1[0] >= 0).sum().item())],
-                                    dist, cdev)
-        total_pairs = int(recs[:, 0].sum())
+        recs = shard.gather_records(rec, dist, cdev)
     else:
-        total_pairs = B * args.steps
+        recs = np.asarray([rec])
+    total_pairs = int(recs[:, 0].sum())
+    ranks = [{"rank": r, "device": int(x[6]), "pairs": int(x[0]), "pairs_per_s": x[0] / x[4],
+              "host_cores_used": round(x[2], 2), "workers": int(x[3]),
+              "host_cpu_us_per_pair": round(1e6 * x[5], 1),
+              # what this rank's share of the host cores could feed at that CPU cost per pair
+              "host_core_ceiling_pairs_per_s": round(cores_per_rank / x[5]) if x[5] > 0 else None,
+              "d1_valid_px_first_pair": int(x[1])} for r, x in enumerate(recs)]
 
     # ---- roofline of the dominant kernel from HIP events recorded on its own stream
     # during the timed steps (only that kernel is bracketed there: <1 % of value)
     roofline = None
     if rank == 0:
         prof = read_profile(S) if in_region else prof_all
+        pmc = load_pmc(build)
         if prof:
             dom = max(prof, key=lambda k: prof[k][0])
             ms, cnt = prof[dom]
@@ -429,38 +568,32 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "avg_launch_us": 1e6 * avg_s, "alg_bytes_per_launch": abytes,
-                        "timed_region": bool(in_region),
+                        "timed_region": bool(in_region), "launches_timed": int(cnt),
                         "kernels_us_probe_step": {k: round(1e3 * v[0] / v[1], 2)
                                                   for k, v in sorted(prof_all.items())}}
-            # measured HBM traffic of that kernel (rocprofv3 --pmc passes, profiles/*_pmc_traffic.json)
-            try:
-                import glob
-                pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))
-                kk = pmc["kernels"].get(dom)
-                if kk and args.workload == "kitti":   # the PMC passes were taken on the KITTI workload
-                    roofline["traffic"] = kk["hbm_bytes"] * min(group, B) / pmc["pairs_per_launch"]
-                    roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), " \
-                                                 "read = 2*FETCH_SIZE*1024 (gfx950), scaled to pairs per launch"
-            except (OSError, IndexError, KeyError, ValueError):
-                pass
+            if pmc["notes"]:
+                roofline["pmc_notes"] = pmc["notes"]
+            tr, iss = pmc["traffic"], pmc["issue"]
+            # measured HBM traffic of that kernel (rocprofv3 --pmc passes, taken on the KITTI workload)
+            if tr and args.workload != "hd1080":
+                kk = tr["kernels"].get(dom)
+                if kk:
+                    roofline["traffic"] = kk["hbm_bytes"] * min(group, B) / tr["pairs_per_launch"]
+                    roofline["traffic_source"] = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate " \
+                                                 "passes), read = 2*FETCH_SIZE*1024 (gfx950), scaled to pairs " \
+                                                 "per launch" % pmc["traffic_file"]
             # whole-path view: staged-model bytes of all pairs / wall time
-            e2e = ALG_BYTES_PER_PIXEL_PAIR * N_PIX * B * args.steps / elapsed / 1e9
+            e2e = ALG_BYTES_PER_PIXEL_PAIR * N_PIX * B * args.steps / elapsed_local / 1e9
             roofline["end_to_end"] = {"alg_bytes_per_pair": ALG_BYTES_PER_PIXEL_PAIR * N_PIX,
                                       "achieved": e2e, "frac": e2e / HBM_PEAK_GBS,
                                       "note": "this rank's pairs; staged model 174.8 B/pixel"}
-            # measured HBM traffic of the whole pipeline (sum over the kernels of the PMC passes)
-            try:
-                import glob
-                pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))
+            if tr and args.workload != "hd1080":
                 twice = ("k_adaptive_mean", "k_gap_local", "k_owner")   # two launches per group share a symbol
                 per_pair = sum(v["hbm_bytes"] * (2 if k in twice else 1)
-                               for k, v in pmc["kernels"].items()) / pmc["pairs_per_launch"]
-                if args.workload != "hd1080":
-                    mt = per_pair * B * args.steps / elapsed / 1e9
-                    roofline["end_to_end"].update(measured_hbm_bytes_per_pair=per_pair, measured_achieved=mt,
-                                                  measured_frac=mt / HBM_PEAK_GBS)
-            except (OSError, IndexError, KeyError, ValueError):
-                pass
+                               for k, v in tr["kernels"].items()) / tr["pairs_per_launch"]
+                mt = per_pair * B * args.steps / elapsed_local / 1e9
+                roofline["end_to_end"].update(measured_hbm_bytes_per_pair=per_pair, measured_achieved=mt,
+                                              measured_frac=mt / HBM_PEAK_GBS)
             # the box's own copy bandwidth (device-to-device, read + write counted)
             src = torch.empty(1 << 29, dtype=torch.uint8, device=dev)
             dst = torch.empty_like(src)
@@ -474,12 +607,9 @@ def main():
             del src, dst
             roofline["measured_copy_GBps"] = copy_gbs
             roofline["frac_of_measured_copy"] = achieved / copy_gbs
-            # the streaming (HBM-bound) kernels, from the committed isolated measurements:
-            # measured HBM bytes per 4-pair launch (FETCH/WRITE_SIZE passes) / its duration
-            try:
-                import glob
-                tr = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))
-                iss = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_issue.json")))[-1]))
+            if tr and iss:
+                # the streaming (HBM-bound) kernels, from the committed isolated measurements:
+                # measured HBM bytes per launch (FETCH/WRITE_SIZE passes) / its duration
                 alias = {"k_support_lds": "k_support", "k_match_keyed": "k_match"}
                 rows = []
                 for sym, v in iss["kernels"].items():
@@ -493,28 +623,33 @@ def main():
                 # issue-slot view of the same run: wave-level VALU instructions of one pair (PMC,
                 # kernels serialised) x this run's pairs/s, against 1024 SIMDs issuing one VALU
                 # instruction per 4 cycles at the nominal 2.4 GHz
-                if args.workload == "kitti":
+                if args.workload != "hd1080":
                     per_pair = sum(v["valu_wave_instr"] for v in iss["kernels"].values()) / float(tr["pairs_per_launch"])
-                    rate = total_pairs / elapsed / world
+                    rate = B * args.steps / elapsed_local
                     roofline["valu_issue"] = {"wave_instr_per_pair": round(per_pair),
                                               "frac_of_issue_slots": round(per_pair * rate * 4 / (1024 * 2.4e9), 3),
-                                              "note": "SQ_INSTS_VALU per pair (profiles/*_pmc_issue.json) x measured "
-                                                      "pairs/s; 256 CUs x 4 SIMDs, 4 cycles per wave64 VALU op"}
-                roofline["isolated_kernels_hbm"] = {"source": "profiles/*_pmc_traffic.json + *_pmc_issue.json "
-                                                              "(rocprofv3 --pmc, kernels serialised, KITTI workload)",
+                                              "note": "SQ_INSTS_VALU per pair (profiles/%s) x measured "
+                                                      "pairs/s; 256 CUs x 4 SIMDs, 4 cycles per wave64 VALU op"
+                                                      % pmc["issue_file"]}
+                roofline["isolated_kernels_hbm"] = {"source": "profiles/%s + %s (rocprofv3 --pmc, kernels "
+                                                              "serialised, KITTI workload)"
+                                                              % (pmc["traffic_file"], pmc["issue_file"]),
                                                     "top": rows[:5]}
-            except (OSError, IndexError, KeyError, ValueError):
-                pass
     if world > 1:
         dist.barrier()
 
     if rank == 0:
-        valid = float((dD1 >= 0).float().mean().item())
+        valid = float((dD1[:min(B, 64)] >= 0).float().mean().item())
+        seq_note = ("configs[2]: %d-frame %dx%d KITTI raw sequence, frames sharded over GPUs"
+                    % (kitti_frames[2], W, H)) if kitti_frames is not None else \
+            "configs[2] substitute: 430-frame 1242x375 sequence (the four urban crops cycled), frames " \
+            "sharded over GPUs"
         out = {
             "metric": "stereo pairs/sec (ELAS %dx%d, ROBOTICS, D1+D2+LR)" % (W, H),
             "value": total_pairs / elapsed,
             "unit": "pairs/s",
             "n_gpus": world,
+            "ranks_seen": int(len(recs)),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -523,30 +658,71 @@ def main():
             "scaling": "strong" if args.workload == "sequence" else "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": ("KITTI raw drive " + os.path.basename(os.path.normpath(args.kitti_dir))) if kitti_frames is not None
-                    else ("synthetic" if args.workload != "sequence"
-                          else "2 crops of the reference's urban images + 2 synthetic pairs"),
+            "data": data,
             "config": {"workload": {"kitti": "configs[1]: KITTI-size 1242x375 pairs",
                                     "hd1080": "configs[3]: synthetic 1920x1080 pairs, disp_max 255",
-                                    "sequence": "configs[2] substitute: 430-frame 1242x375 sequence (two urban "
-                                                "crops + two synthetic pairs, cycled), frames sharded over GPUs"
-                                    }[args.workload].replace(
-                                        "configs[2] substitute: 430-frame 1242x375 sequence (two urban crops + two "
-                                        "synthetic pairs, cycled)",
-                                        "configs[2]: %d-frame %dx%d KITTI raw sequence" % (
-                                            kitti_frames[2] if kitti_frames is not None else 0, W, H)
-                                        if kitti_frames is not None else
-                                        "configs[2] substitute: 430-frame 1242x375 sequence (two urban crops + two "
-                                        "synthetic pairs, cycled)") +
+                                    "sequence": seq_note}[args.workload] +
                                    ", ELAS ROBOTICS, D1+D2 + LR-check, subsampling=false, inputs "
                                    "and outputs resident in HBM",
                        "pairs_per_step_per_gpu": B, "unique_pairs_per_gpu": U, "lanes_per_gpu": lanes,
-                       "pairs_per_launch": group, "host_cores_used": round(host_cores_used, 1),
-                       "host_cpu_quota": _cpu_quota(),
+                       "pairs_per_launch": group, "host_cores_used": round(float(recs[:, 2].sum()), 1),
+                       "host_cpu_quota": _cpu_quota(), "host_cores_per_rank": round(cores_per_rank, 2),
+                       "dist_backend": args.dist_backend if world > 1 else None,
+                       "gpus_visible": ndev, "build": build,
                        "d1_valid_fraction": round(valid, 4)},
+            "ranks": ranks,
             "roofline": roofline,
         }
-        if world == 1:
+        extras = world == 1 and not args.no_extras
+        if extras and args.workload != "hd1080":
+            # SURVEY 8(b) ownership contract: host pointers in, host pointers out, through the
+            # batch entry (pinned buffers; `lanes` workers x `group` pairs in flight).  PCIe-inclusive.
+            nb = min(B, 768)
+            hI1 = torch.from_numpy(I1).repeat((nb + U - 1) // U, 1, 1)[:nb].contiguous().pin_memory()
+            hI2 = torch.from_numpy(I2).repeat((nb + U - 1) // U, 1, 1)[:nb].contiguous().pin_memory()
+            hD1 = torch.empty((nb, H, W), dtype=torch.float32).pin_memory()
+            hD2 = torch.empty((nb, H, W), dtype=torch.float32).pin_memory()
+            arr = C.c_void_p * nb
+            a1 = arr(*[hI1[i].data_ptr() for i in range(nb)])
+            a2 = arr(*[hI2[i].data_ptr() for i in range(nb)])
+            d1 = arr(*[hD1[i].data_ptr() for i in range(nb)])
+            d2 = arr(*[hD2[i].data_ptr() for i in range(nb)])
+            st = (C.c_int32 * nb)()
+            dims = (C.c_int32 * 3)(W, H, W)
+
+            def host_step():
+                rc = S.lib().svh_elas_process_batch(e._h, nb, a1, a2, d1, d2, dims, st)
+                assert rc == 0, (rc, S.last_error())
+            host_step()
+            t = time.perf_counter()
+            for _ in range(4):
+                host_step()
+            dt = time.perf_counter() - t
+            same = bool(torch.equal(hD1[1].to(dev), dD1[1]) and torch.equal(hD2[1].to(dev), dD2[1]))
+            out["throughput_host_buffers"] = {
+                "value": 4 * nb / dt, "unit": "pairs/s", "pairs_per_call": nb, "calls": 4,
+                "pairs_in_flight": lanes * group,
+                "bytes_over_pcie_per_pair": 2 * N_PIX + 8 * N_PIX,
+                "pcie_GBps": 4 * nb * 10 * N_PIX / dt / 1e9,
+                "note": "svh_elas_process_batch: pinned host images in, pinned host D1+D2 out (the reference's "
+                        "ownership contract, SURVEY 8b); PCIe-inclusive, never `value`"}
+            out["throughput_host_buffers"]["maps_equal_device_path"] = same
+            del hI1, hI2, hD1, hD2
+        if extras and args.workload == "kitti" and args.data == "urban":
+            # the round-1 headline workload for comparison: seeded synthetic pairs, same step
+            s1, s2 = make_inputs(min(B, args.unique), seed0=1000)
+            dI1, dI2 = tile_to_device(s1, s2)
+            torch.cuda.synchronize()
+            step()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            out["value_synthetic"] = {"value": 3 * B / (time.perf_counter() - t), "unit": "pairs/s",
+                                      "data": "%d seeded synthetic pairs, tiled" % len(s1),
+                                      "d1_valid_fraction": round(float((dD1[:64] >= 0).float().mean().item()), 4)}
+        if extras:
             # single-stream latency of the reference-style call: one pair, pageable HOST buffers in
             # and out (PCIe-inclusive; never part of `value`)
             e1 = S.Elas(params)
@@ -559,11 +735,12 @@ def main():
                 e1.process(I1[i % U], I2[i % U], D1h, D2h)
             out["latency_ms_single_pair_host_buffers"] = 1e3 * (time.perf_counter() - t) / 20
             out["latency_stages_ms"] = {k: round(v, 3) for k, v in e1.last_timing()}
-        if world == 1 and not args.no_cpu_baseline:
             out["matcher"] = matcher_bench()     # before the CPU leg: the GPU is still at its clocks
             out["visual_odometry"] = vo_bench()
             out["map_fusion"] = map_bench()
-            out["cpu_baseline"] = cpu_baseline(I1, I2, params)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(I1, I2, params, what, budget_s=args.cpu_budget,
+                                               workers=int(avail) if args.workload == "kitti" else 0)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

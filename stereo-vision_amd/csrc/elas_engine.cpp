@@ -665,7 +665,10 @@ using namespace svh;
 
 extern "C" {
 
-const char* svh_version(void) { return "svhip 0.1 (gfx950)"; }
+#ifndef SVH_SRC_SHA
+#define SVH_SRC_SHA "unstamped"
+#endif
+const char* svh_version(void) { return "svhip 0.2 (gfx950) src " SVH_SRC_SHA; }
 const char* svh_last_error(void) { return t_error.c_str(); }
 
 int32_t svh_device_count(void) {

@@ -69,6 +69,21 @@ def test_stages_match_oracle_on_golden(case, svhip, oracle_lib):
     assert np.array_equal(got[H.D2_FINAL], z["d2"])
 
 
+@pytest.mark.parametrize("case", ["urban3_kitti", "urban4_kitti"])
+def test_final_maps_match_slim_golden(case, svhip):
+    """the bench headline's other two crops: support list, both triangulations and the final
+    maps against the reference's"""
+    z = np.load(os.path.join(H.GOLDEN, case + ".npz"))
+    prm = H.ElasParams.from_buffer_copy(z["params"].tobytes())
+    l, r = H.golden_pair(str(z["crop"]))
+    got = product_run(svhip, prm, l, r)
+    assert got.status == 0
+    for s in (H.SUPPORT, H.TRI1, H.TRI2):
+        assert np.array_equal(got[s], z[H.STAGE_NAMES[s]]), H.STAGE_NAMES[s]
+    assert np.array_equal(got[H.D1_FINAL], z["d1"])
+    assert np.array_equal(got[H.D2_FINAL], z["d2"])
+
+
 @pytest.mark.parametrize("seed,w,h,kw", [
     (11, 320, 200, {}),
     (12, 333, 117, {"postprocess_only_left": 0}),        # ragged width

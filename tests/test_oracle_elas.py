@@ -46,6 +46,18 @@ def test_oracle_matches_golden(case, oracle_lib):
     assert np.array_equal(run[H.D2_FINAL], z["d2"])
 
 
+@pytest.mark.parametrize("case", ["urban3_kitti", "urban4_kitti"])
+def test_oracle_matches_slim_golden(case, oracle_lib):
+    """the other two KITTI-size crops of the bench headline: support
+    list and final maps of the reference"""
+    z, prm, l, r = load_case(case)
+    run = H.oracle_elas_run(prm, l, r, H.fixture_triangulator([z["tri1"], z["tri2"]]))
+    assert run.status == 0
+    assert np.array_equal(run[H.SUPPORT], z["support"])
+    assert np.array_equal(run[H.D1_FINAL], z["d1"])
+    assert np.array_equal(run[H.D2_FINAL], z["d2"])
+
+
 def test_known_answers(oracle_lib):
     """SURVEY 8c known-answer facts: prior table, plane radius, mean-filter mask."""
     import ctypes as C

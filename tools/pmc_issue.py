@@ -16,8 +16,19 @@ Derived per launch (MI355X: 256 CUs, 4 SIMDs per CU, 8 XCDs):
 """
 import json
 import re
+import os
 import sqlite3
 import sys
+
+
+def build_stamp():
+    """svh_version() of the libsvhip.so these counters were taken on (carries the source hash):
+    bench.py quotes the file only while it matches the library it has loaded"""
+    import ctypes
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "stereo-vision_amd", "libsvhip.so")
+    lib = ctypes.CDLL(so)
+    lib.svh_version.restype = ctypes.c_char_p
+    return lib.svh_version().decode()
 
 
 def load(path, table):
@@ -39,7 +50,7 @@ def main(paths):
     table = {}
     for p in paths:
         load(p, table)
-    out = {"note": __doc__.split("Derived per launch")[1].strip().splitlines()[0], "kernels": {}}
+    out = {"build": build_stamp(), "note": __doc__.split("Derived per launch")[1].strip().splitlines()[0], "kernels": {}}
     for k in sorted(table):
         c = {}
         dur = 0.0

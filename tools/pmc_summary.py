@@ -11,8 +11,19 @@ covered by that calibration and are flagged.  WRITE_SIZE is taken as is.
 """
 import json
 import re
+import os
 import sqlite3
 import sys
+
+
+def build_stamp():
+    """svh_version() of the libsvhip.so these counters were taken on (carries the source hash):
+    bench.py quotes the file only while it matches the library it has loaded"""
+    import ctypes
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "stereo-vision_amd", "libsvhip.so")
+    lib = ctypes.CDLL(so)
+    lib.svh_version.restype = ctypes.c_char_p
+    return lib.svh_version().decode()
 
 
 ALIAS = {"k_support_lds": "k_support", "k_match_keyed": "k_match"}   # symbol -> bench.py profile name
@@ -43,7 +54,7 @@ def per_kernel(path, counter):
 def main(fetch_db, write_db, pairs):
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
-    res = {"pairs_per_launch": int(pairs), "unit": "bytes per launch",
+    res = {"build": build_stamp(), "pairs_per_launch": int(pairs), "unit": "bytes per launch",
            "note": "read = 2*FETCH_SIZE*1024 (gfx950 128-B requests tallied at 64 B), write = WRITE_SIZE*1024",
            "kernels": {}}
     for k in sorted(set(f) | set(w)):
