@@ -358,7 +358,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0,
                     help="double-buffered pipeline workers per GPU (0 = auto: 1.5 per available core, <= 24)")
     ap.add_argument("--group", type=int, default=0,
-                    help="pairs per kernel launch, 1..16 (0 = 8 for kitti, 1 for hd1080)")
+                    help="pairs per kernel launch, 1..32 (0 = 32 for kitti, 1 for hd1080)")
     ap.add_argument("--spinup", type=float, default=1.0,
                     help="seconds of untimed steps before the warmup (GPU clocks, lane buffers)")
     ap.add_argument("--profile-in-timed-region", type=int, default=1,
@@ -367,6 +367,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the default) or gloo (CPU collectives: lets several ranks "
                          "share one GPU when the multi-rank path is exercised on a 1-GPU box)")
+    ap.add_argument("--stage", choices=("auto", "host", "device"), default="auto",
+                    help="where lattice filters + Delaunay run (svh_elas_set_stage): auto = device for batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary legs (synthetic, host buffers, latency, Matcher, VO, map)")
@@ -401,8 +403,9 @@ def main():
     if args.batch <= 0:
         args.batch = 6144 if args.workload == "kitti" else 8
     if args.group <= 0:
-        # hd1080: 8 pairs per step, one pair per lane
-        args.group = 1 if args.workload == "hd1080" else 8
+        # hd1080: 8 pairs per step, one pair per lane; kitti: the stages between the matching phases
+        # (k_lattice, k_delaunay) are latency-bound single-workgroup jobs -- 32 pairs share one launch
+        args.group = 1 if args.workload == "hd1080" else 32
 
     import torch
     import torch.distributed as dist
@@ -430,6 +433,7 @@ def main():
     import svhip as S
     import helpers as Hh
     S.lib().svh_set_device(device_index)
+    S.set_stage({"auto": -1, "host": 0, "device": 1}[args.stage])
     build = S.lib().svh_version().decode()
     if args.workload == "sequence" and args.kitti_dir:
         from svhip import kitti as _kitti
@@ -443,7 +447,8 @@ def main():
     # core keeps the cores busy with the host stage
     avail = _cpu_quota() or (os.cpu_count() or 8)
     cores_per_rank = avail / max(world, 1)
-    lanes = args.lanes or int(max(2, min(24, round(1.5 * cores_per_rank))))
+    # (with the device stage the workers only enqueue and sleep: 12 keep 24 streams busy)
+    lanes = args.lanes or int(max(2, min(12 if args.stage != "host" else 24, round(1.5 * cores_per_rank))))
     S.set_lanes(lanes)
     group = S.set_group(args.group)
 
@@ -485,7 +490,8 @@ def main():
     def step():
         st = e.process_batch_device(B, dI1.data_ptr(), dI2.data_ptr(), W * H, dD1.data_ptr(),
                                     dD2.data_ptr(), W * H * 4, W, H, W)
-        assert all(s == 0 for s in st), st
+        assert all(s == 0 for s in st), ("non-zero statuses", [(i, s) for i, s in enumerate(st) if s != 0][:8],
+                                         S.last_error())
 
     def barrier():
         torch.cuda.synchronize()
@@ -668,7 +674,8 @@ def main():
                        "pairs_per_launch": group, "host_cores_used": round(float(recs[:, 2].sum()), 1),
                        "host_cpu_quota": _cpu_quota(), "host_cores_per_rank": round(cores_per_rank, 2),
                        "dist_backend": args.dist_backend if world > 1 else None,
-                       "gpus_visible": ndev, "build": build,
+                       "gpus_visible": ndev, "build": build, "stage": args.stage,
+                       "stage_groups_device_handed_back": list(S.stage_stats()),
                        "d1_valid_fraction": round(valid, 4)},
             "ranks": ranks,
             "roofline": roofline,

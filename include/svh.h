@@ -114,9 +114,21 @@ int32_t svh_elas_process_batch_device(svh_elas* e, int32_t n,
 /* number of batch workers the engine runs per device (each is double-buffered: two HIP streams
  * and buffer sets, the host stage of one group overlaps the device stages of the next) */
 int32_t svh_elas_set_lanes(int32_t lanes);
-/* pairs a lane pushes through each kernel launch (1..16): batches are cut into
+/* pairs a lane pushes through each kernel launch (1..32, default 16): batches are cut into
  * groups of this many consecutive pairs */
 int32_t svh_elas_set_group(int32_t pairs);
+
+/* where the stages between the two matching phases run (lattice filters elas.cpp:174-279, support
+ * list :495-523, the two Delaunay triangulations :534-600): 1 = on the device (k_lattice,
+ * k_delaunay: no host round trip inside a pair), 0 = on the host (elas_host.cpp, delaunay.cpp),
+ * -1 = automatic (the default: batches on the device, a single svh_elas_process on the host,
+ * where two host threads are the shorter path for one pair).  Results are identical.  Returns
+ * the mode in effect. */
+int32_t svh_elas_set_stage(int32_t where);
+/* diagnostics: groups of pairs that took the device stage since the library was loaded, and how
+ * many of them it handed back to the host path (coincident support points in a triangulation,
+ * whose survivor depends on Triangle's pivot stream -- triangle.cpp:5446-5501, 6179-6196) */
+void svh_elas_stage_stats(int64_t* device_groups, int64_t* handed_back);
 
 /* Stage taps for parity tests: after a successful svh_elas_process() the
  * intermediate of the given stage (of the last pair processed through handle

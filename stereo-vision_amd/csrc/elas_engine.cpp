@@ -154,6 +154,16 @@ struct Lane {
     size_t ntri_max = 0;
     std::vector<HostPrior> hp;
     std::vector<int32_t> P;
+    // device-side E5-E7 (elas_stage_kernels.hip): scratch, counts read back through pinned memory
+    StageDev stg{};
+    bool stage_ok = false;          // the geometry fits the device stage and its scratch exists
+    void* stage_blob = nullptr;     // one allocation behind the StageDev arrays
+    StageCounts* h_counts = nullptr;
+    hipEvent_t stage_ev = nullptr;  // the counts have arrived
+    bool resident = false;          // the group on this lane runs the device stage
+    bool force_host = false;        // rerun of a group the device stage handed back
+    float P_key[5] = {-1, -1, -1, -1, -1};   // parameters the prior table on the device was built for
+    size_t o_P = 0, o_sup = 0, o_tri = 0;    // fixed layout of prior_dev in resident mode
 
     void release() {
         if (!stream) return;
@@ -166,6 +176,9 @@ struct Lane {
         planes = Draw = D = tmp = nullptr; seed = mask = nullptr; labels = counts = nullptr;
         (void)hipHostFree(h_dcan); (void)hipHostFree(h_prior); (void)hipHostFree(h_img);
         h_dcan = nullptr; h_prior = nullptr; h_img = nullptr;
+        (void)hipFree(stage_blob); (void)hipHostFree(h_counts);
+        stage_blob = nullptr; h_counts = nullptr; stage_ok = false; stg = StageDev{};
+        P_key[0] = -1;
         W = H = 0;
     }
 
@@ -212,6 +225,46 @@ struct Lane {
         HIP_TRY(hipMalloc(&seed, gw_bytes));
         HIP_TRY(hipMalloc(&mask, gw_bytes));
         hp.resize(g);
+        // fixed layout of the packed lists when the device builds them
+        o_P = (sizeof(GroupHdr) + 63) & ~(size_t)63;
+        o_sup = (o_P + (size_t)(p.disp_max + 1) * sizeof(int32_t) + 63) & ~(size_t)63;
+        o_tri = (o_sup + (size_t)g * nsup * 3 * sizeof(int32_t) + 63) & ~(size_t)63;
+        if (stage_device_ok(p, d) && o_tri + (size_t)g * 2 * ntri_max * 3 * sizeof(int32_t) <= prior_cap) {
+            // scratch of the device stage, one allocation: see StageDev
+            const size_t cap = std::min<size_t>(nsup, 65535), rec = 2 * cap + 2, S2 = (size_t)2 * g;
+            size_t off = 0;
+            auto take = [&](size_t bytes) { size_t at = off; off = (off + bytes + 255) & ~(size_t)255; return at; };
+            const size_t a_sup = take((size_t)g * 3 * cap * 4), a_cnt = take(sizeof(StageCounts));
+            const size_t a_ids = take(S2 * 4 * rec * 4), a_xys = take(S2 * 4 * rec * 4), a_nbr = take(S2 * 4 * rec * 4);
+            size_t a_arr[10];
+            for (int k = 0; k < 10; k++) a_arr[k] = take(S2 * cap * 4);
+            const size_t a_fl = take(S2 * 2 * cap * 4), a_fr = take(S2 * 2 * cap * 4);
+            const size_t a_wl = take((size_t)g * 3 * nc * 4), a_cw = take((size_t)g * (nc / 4 + 1) * 4);
+            HIP_TRY(hipMalloc(&stage_blob, off));
+            HIP_TRY(hipMemset(stage_blob, 0, off));
+            HIP_TRY(hipHostMalloc(&h_counts, sizeof(StageCounts)));
+            uint8_t* b = static_cast<uint8_t*>(stage_blob);
+            stg.dcan = dcan;
+            stg.sup_raw = reinterpret_cast<int32_t*>(b + a_sup);
+            stg.counts = reinterpret_cast<StageCounts*>(b + a_cnt);
+            stg.ids = reinterpret_cast<int32_t*>(b + a_ids);
+            stg.xys = reinterpret_cast<int32_t*>(b + a_xys);
+            stg.nbr = reinterpret_cast<uint32_t*>(b + a_nbr);
+            int32_t** ia[6] = {&stg.pxy, &stg.buck, &stg.buck2, &stg.byx, &stg.order, &stg.oxy};
+            uint32_t** ua[4] = {&stg.lx, &stg.ly, &stg.tmp, &stg.P};
+            for (int k = 0; k < 6; k++) *ia[k] = reinterpret_cast<int32_t*>(b + a_arr[k]);
+            for (int k = 0; k < 4; k++) *ua[k] = reinterpret_cast<uint32_t*>(b + a_arr[6 + k]);
+            stg.fl = reinterpret_cast<uint32_t*>(b + a_fl);
+            stg.fr = reinterpret_cast<uint32_t*>(b + a_fr);
+            stg.wl = reinterpret_cast<int32_t*>(b + a_wl);
+            stg.cntw = reinterpret_cast<uint32_t*>(b + a_cw);
+            stg.sup_cap = (int32_t)cap;
+            stg.rec_cap = (int32_t)rec;
+            stage_ok = true;
+        }
+        // the memsets above run on the null stream, which the lanes' non-blocking streams do not
+        // wait for: they must have landed before the first kernel of this lane
+        HIP_TRY(hipDeviceSynchronize());
         W = w; H = h; disp_max = p.disp_max; step = st; grid_size = p.grid_size; sub = p.subsampling;
         gcap = g;
         return SVH_OK;
@@ -254,7 +307,7 @@ struct Pool {
 static std::mutex g_mu;
 static std::map<int, Pool*> g_pools;
 static std::atomic<int> g_lanes{8};
-static std::atomic<int> g_group{4};
+static std::atomic<int> g_group{16};
 
 static Pool* pool_for(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -399,8 +452,24 @@ struct HostProfDump {
 static HostProfDump g_hp_dump;
 #define HP_MARK(slot) do { if (g_hostprof) { uint64_t n_ = cpu_ns(); g_hp_ns[slot] += n_ - hp_t; hp_t = n_; } } while (0)
 
+// where E5-E7 run: -1 = auto (batches on the device, single calls on the host: two host threads
+// are the lower latency for one pair), 0 = host, 1 = device.  SVH_STAGE=host|device, svh_elas_set_stage()
+static std::atomic<int> g_stage_mode{getenv("SVH_STAGE") ? (strcmp(getenv("SVH_STAGE"), "device") == 0 ? 1 : 0) : -1};
+
+static std::atomic<int64_t> g_stage_dev_groups{0}, g_stage_redo_groups{0};
+
+// sleep-poll (batch workers) or block on an event
+static hipError_t event_wait(Lane& L, hipEvent_t ev) {
+    if (!L.poll_wait || g_wait_us <= 0) return hipEventSynchronize(ev);
+    for (;;) {
+        hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        std::this_thread::sleep_for(std::chrono::microseconds(g_wait_us));
+    }
+}
+
 static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, const GroupIO& io,
-                     int32_t* status, Taps* taps, svh_elas* timing, int mode = RG_ALL) {
+                     int32_t* status, Taps* taps, svh_elas* timing, int mode = RG_ALL, bool prefer_device = false) {
     const int32_t W = dims[0], H = dims[1], g = io.g;
     int rc = check_params(p, W, H);
     if (rc) return rc;
@@ -415,57 +484,273 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     const LaunchCtx cx = {s, g_prof_on.load() ? &L.prof : nullptr};
     const size_t N = (size_t)W * H, DN = (size_t)d.DW * d.DH;
     const size_t nc = (size_t)d.Wc * d.Hc;
+    const bool tapping = taps && taps->enabled;
     double t0 = now_ms();
     uint64_t hp_t = g_hostprof ? cpu_ns() : 0;
-    if (mode == RG_FINISH) {
+
+    GroupHdr* hdr = reinterpret_cast<GroupHdr*>(L.h_prior);   // host view of the header
+    DevMaps out;
+    if (io.out_device) {
+        // the callers' maps live on the device: the post-processing chain runs in place on them
+        out.D[0] = io.dD[0]; out.D[1] = io.dD[1]; out.stride[0] = out.stride[1] = io.out_stride;
+    } else {
+        out.D[0] = L.D; out.D[1] = L.D + DN; out.stride[0] = out.stride[1] = 2 * DN;
+    }
+    // With postprocess_only_left the right map is final once the L/R check is done: its copy to the
+    // caller's host buffer runs on a second stream while the left map is still being post-processed.
+    bool early_d2 = false;
+    int32_t plane_radius = 2;
+
+    // ---- everything after the triangulations (E8 .. E16); totals < 0: counts are on the device
+    auto enqueue_phase_b = [&](size_t o_P, size_t o_sup, size_t o_tri, int32_t total_sup, int32_t total_tri,
+                               int32_t tri_bound) -> int {
+        GroupDev G;
+        G.hdr = reinterpret_cast<const GroupHdr*>(L.prior_dev);
+        G.P = reinterpret_cast<const int32_t*>(L.prior_dev + o_P);
+        G.support = reinterpret_cast<const int32_t*>(L.prior_dev + o_sup);
+        G.tri = reinterpret_cast<const int32_t*>(L.prior_dev + o_tri);
+        G.raster = L.raster;
+        G.planes = L.planes;
+        G.seed = L.seed;
+        G.mask = L.mask;
+        G.desc = L.desc;
+        G.owner = L.owner;
+        // triangle ownership is stored as owner_base + 1 + index; the base moves above everything
+        // written so far, so the 2 x N x g map is never cleared (one memset when int32 would overflow)
+        if (L.owner_hi + 1 + tri_bound >= INT32_MAX) {
+            HIP_TRY(hipMemsetAsync(L.owner, 0, (size_t)2 * L.gcap * N * sizeof(int32_t), s));
+            L.owner_hi = 0;
+        }
+        G.owner_base = (int32_t)L.owner_hi;
+        L.owner_hi += 1 + tri_bound;
+        G.Draw = L.Draw;
+        G.plane_radius = plane_radius;
+        G.prior_absmax = 0;
+        for (int32_t dd = 0; dd <= plane_radius && dd < (int32_t)L.P.size(); dd++)
+            G.prior_absmax = std::max(G.prior_absmax, (int32_t)std::min<int64_t>(std::llabs((long long)L.P[dd]), INT32_MAX));
+        launch_prior(cx, p, d, g, total_sup, total_tri, G);
+        if (tapping) {
+            const int32_t n1 = hdr->tri_end[0], n2 = hdr->tri_end[1] - hdr->tri_end[0];
+            rc = tap_dev(L, taps, SVH_ELAS_PLANES1, L.planes, (size_t)6 * n1); if (rc) return rc;
+            rc = tap_dev(L, taps, SVH_ELAS_PLANES2, L.planes + (size_t)6 * n1, (size_t)6 * n2); if (rc) return rc;
+            const size_t words = (size_t)d.gw * d.gh * d.gwords;
+            std::vector<uint32_t> m(2 * words);
+            HIP_TRY(hipMemcpyAsync(m.data(), L.mask, m.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(lane_wait(L));
+            for (int k = 0; k < 2; k++) {
+                std::vector<int32_t> gr;
+                expand_grid(p, d, m.data() + k * words, gr);
+                tap_host(taps, SVH_ELAS_GRID1 + k, gr.data(), gr.size());
+            }
+        }
+        launch_owner(cx, p, d, g, total_tri, G);
+        const bool tiles = !tapping && post_tiles_ok(p);   // gap + mean (+ speckle mask) tile kernels
+        // the row kernel also applies the L/R check (its inputs are the row it just matched)
+        const bool lr_done = launch_match(cx, p, d, g, G, &out, tapping);
+        early_d2 = !io.out_device && lr_done && !tapping && p.postprocess_only_left;
+        if (early_d2) {
+            if (!L.copy_stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&L.copy_stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&L.match_ev, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&L.copy_ev, hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventRecord(L.match_ev, s));
+        }
+        if (tapping) {
+            rc = tap_dev(L, taps, SVH_ELAS_D1_RAW, L.Draw, DN); if (rc) return rc;
+            rc = tap_dev(L, taps, SVH_ELAS_D2_RAW, L.Draw + DN, DN); if (rc) return rc;
+        }
+        const PostScratch ps = {L.tmp, L.labels, L.counts};
+        const int nside = p.postprocess_only_left ? 1 : 2;
+        if (!lr_done) launch_lr(cx, p, d, g, G, out);
+        if (tapping) {
+            rc = tap_dev(L, taps, SVH_ELAS_D1_LR, out.D[0], DN); if (rc) return rc;
+            rc = tap_dev(L, taps, SVH_ELAS_D2_LR, out.D[1], DN); if (rc) return rc;
+        }
+        launch_segments(cx, p, d, g, nside, G, out, ps, /*mask=*/!tiles);
+        if (tapping) {
+            rc = tap_dev(L, taps, SVH_ELAS_D1_SEG, out.D[0], DN); if (rc) return rc;
+            rc = tap_dev(L, taps, SVH_ELAS_D2_SEG, out.D[1], DN); if (rc) return rc;
+        }
+        if (tiles) {
+            launch_gap_mean_tiles(cx, p, d, g, nside, G, out, ps);   // gap + adaptive mean, two tile kernels
+        } else {
+            launch_gap(cx, p, d, g, nside, G, out, ps);
+            if (tapping) {
+                rc = tap_dev(L, taps, SVH_ELAS_D1_GAP, out.D[0], DN); if (rc) return rc;
+                rc = tap_dev(L, taps, SVH_ELAS_D2_GAP, out.D[1], DN); if (rc) return rc;
+            }
+            if (p.filter_adaptive_mean) launch_adaptive_mean(cx, p, d, g, nside, G, out, ps);
+            if (p.filter_median) launch_median(cx, d, g, nside, G, out, ps);
+        }
+        return SVH_OK;
+    };
+
+    // ---- finished maps of the active pairs to the callers' host buffers
+    auto copy_out = [&](const int32_t* active) -> int {
+        if (io.out_device) return SVH_OK;
+        if (early_d2) {   // (issued after the post-processing launches: a pageable copy blocks this thread)
+            HIP_TRY(hipStreamWaitEvent(L.copy_stream, L.match_ev, 0));
+            for (int32_t j = 0; j < g; j++)
+                if (active[j])
+                    HIP_TRY(hipMemcpyAsync(io.hD[1][j], L.D + ((size_t)2 * j + 1) * DN, DN * sizeof(float),
+                                           hipMemcpyDeviceToHost, L.copy_stream));
+            HIP_TRY(hipEventRecord(L.copy_ev, L.copy_stream));
+        }
+        for (int32_t j = 0; j < g; j++) {
+            if (!active[j]) continue;
+            for (int k = 0; k < (early_d2 ? 1 : 2); k++)
+                HIP_TRY(hipMemcpyAsync(io.hD[k][j], L.D + ((size_t)2 * j + k) * DN, DN * sizeof(float),
+                                       hipMemcpyDeviceToHost, s));
+        }
+        if (early_d2) HIP_TRY(hipStreamWaitEvent(s, L.copy_ev, 0));   // the lane's stream ends after both
+        return SVH_OK;
+    };
+    // per-pair result of the device stage, from the counts it sent back
+    auto active_of = [&](int32_t j) {
+        return L.h_counts->nsup[j] >= 3 && !(L.h_counts->flags[j] & (STG_DUP | STG_OVERFLOW));
+    };
+
+    auto finish = [&]() -> int {
         HIP_TRY(lane_wait(L));
         HIP_TRY(hipGetLastError());
         L.prof.collect();
         HP_MARK(HP_WAIT);
+        if (!L.resident) return SVH_OK;
+        g_stage_dev_groups++;
+        bool redo = false;
+        for (int32_t j = 0; j < g; j++) {
+            if (L.h_counts->flags[j] & (STG_DUP | STG_OVERFLOW)) {
+                redo = true;
+            } else if (L.h_counts->nsup[j] < 3) {
+                // elas.cpp:69-75: message on stdout, outputs untouched
+                printf("ERROR: Need at least 3 support points!\n");
+                fflush(stdout);
+                status[j] = SVH_ERR_FEW_SUPPORT;
+            } else {
+                status[j] = SVH_OK;
+            }
+        }
+        if (redo) {
+            // coincident support points (or more points than the scratch holds): which duplicate
+            // survives is decided by Triangle's pivot stream -- the host path reproduces that
+            g_stage_redo_groups++;
+            L.resident = false;
+            L.force_host = true;
+            std::vector<int32_t> st2(g, SVH_OK);
+            rc = run_group(L, p, dims, io, st2.data(), taps, timing, RG_ALL, false);
+            L.force_host = false;
+            if (rc) return rc;
+            for (int32_t j = 0; j < g; j++)
+                if (L.h_counts->flags[j] & (STG_DUP | STG_OVERFLOW)) status[j] = st2[j];
+        }
         return SVH_OK;
-    }
+    };
+    if (mode == RG_FINISH) return finish();
 
     // ---- phase A ---------------------------------------------------------
     if (mode & RG_A) {
-    DevImages img;
-    if (io.in_device) {
-        img.I[0] = io.dI[0]; img.I[1] = io.dI[1];
-        img.stride = io.in_stride; img.pitch = io.pitch;
-    } else {
-        // the callers' rows (any stride, pageable) are packed into pinned staging
-        // on the host, then the whole group goes up in one linear DMA
-        for (int32_t j = 0; j < g; j++)
-            for (int k = 0; k < 2; k++) {
-                uint8_t* dst = L.h_img + ((size_t)2 * j + k) * N;
-                const uint8_t* src = io.hI[k][j];
-                if (io.pitch == W) memcpy(dst, src, N);
-                else
-                    for (int32_t v = 0; v < H; v++) memcpy(dst + (size_t)v * W, src + (size_t)v * io.pitch, W);
+        DevImages img;
+        if (io.in_device) {
+            img.I[0] = io.dI[0]; img.I[1] = io.dI[1];
+            img.stride = io.in_stride; img.pitch = io.pitch;
+        } else {
+            // the callers' rows (any stride, pageable) are packed into pinned staging
+            // on the host, then the whole group goes up in one linear DMA
+            for (int32_t j = 0; j < g; j++)
+                for (int k = 0; k < 2; k++) {
+                    uint8_t* dst = L.h_img + ((size_t)2 * j + k) * N;
+                    const uint8_t* src = io.hI[k][j];
+                    if (io.pitch == W) memcpy(dst, src, N);
+                    else
+                        for (int32_t v = 0; v < H; v++) memcpy(dst + (size_t)v * W, src + (size_t)v * io.pitch, W);
+                }
+            HIP_TRY(hipMemcpyAsync(L.img, L.h_img, (size_t)2 * g * N, hipMemcpyHostToDevice, s));
+            img.I[0] = L.img; img.I[1] = L.img + N;
+            img.stride = 2 * N; img.pitch = W;
+        }
+        launch_descriptor(cx, img, g, W, H, p.subsampling, L.desc);
+        launch_support(cx, p, d, g, L.desc, L.dcan);
+        const int sm = g_stage_mode.load();
+        L.resident = !L.force_host && L.stage_ok && (sm == 1 || (sm < 0 && prefer_device));
+        if (!L.resident || tapping)
+            HIP_TRY(hipMemcpyAsync(L.h_dcan, L.dcan, g * nc * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+        if (L.resident) {
+            // ---- E5-E7 on the device, then everything else right behind: no host round trip
+            prior_table(p, L.P, &plane_radius);
+            const float key[5] = {p.beta, p.gamma, p.sigma, p.sradius, (float)p.disp_max};
+            if (memcmp(key, L.P_key, sizeof(key)) != 0) {
+                // (the staging copy is reused right away: wait for it, once per parameter set)
+                memcpy(L.h_prior + L.o_P, L.P.data(), L.P.size() * sizeof(int32_t));
+                HIP_TRY(hipMemcpyAsync(L.prior_dev + L.o_P, L.h_prior + L.o_P, L.P.size() * sizeof(int32_t),
+                                       hipMemcpyHostToDevice, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                memcpy(L.P_key, key, sizeof(key));
             }
-        HIP_TRY(hipMemcpyAsync(L.img, L.h_img, (size_t)2 * g * N, hipMemcpyHostToDevice, s));
-        img.I[0] = L.img; img.I[1] = L.img + N;
-        img.stride = 2 * N; img.pitch = W;
-    }
-    launch_descriptor(cx, img, g, W, H, p.subsampling, L.desc);
-    launch_support(cx, p, d, g, L.desc, L.dcan);
-    HIP_TRY(hipMemcpyAsync(L.h_dcan, L.dcan, g * nc * sizeof(int16_t), hipMemcpyDeviceToHost, s));
-    HP_MARK(HP_ENQ_A);
+            if (tapping) {
+                HIP_TRY(hipStreamSynchronize(s));
+                rc = tap_dev(L, taps, SVH_ELAS_DESC1, L.desc, N * 16); if (rc) return rc;
+                rc = tap_dev(L, taps, SVH_ELAS_DESC2, L.desc + N * 16, N * 16); if (rc) return rc;
+                tap_host(taps, SVH_ELAS_DCAN_RAW, L.h_dcan, nc);
+            }
+            launch_stage_device(cx, p, d, g, L.stg, reinterpret_cast<GroupHdr*>(L.prior_dev),
+                                reinterpret_cast<int32_t*>(L.prior_dev + L.o_sup),
+                                reinterpret_cast<int32_t*>(L.prior_dev + L.o_tri));
+            if (!L.stage_ev) HIP_TRY(hipEventCreateWithFlags(&L.stage_ev, hipEventDisableTiming));
+            HIP_TRY(hipMemcpyAsync(L.h_counts, L.stg.counts, sizeof(StageCounts), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(L.stage_ev, s));
+            if (tapping) {
+                // host copies of the header and the lists the device built (g == 1)
+                HIP_TRY(hipMemcpyAsync(hdr, L.prior_dev, sizeof(GroupHdr), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (hdr->active[0]) {
+                    rc = tap_dev(L, taps, SVH_ELAS_SUPPORT, reinterpret_cast<int32_t*>(L.prior_dev + L.o_sup),
+                                 (size_t)3 * hdr->total_sup); if (rc) return rc;
+                    rc = tap_dev(L, taps, SVH_ELAS_TRI1, reinterpret_cast<int32_t*>(L.prior_dev + L.o_tri),
+                                 (size_t)3 * hdr->tri_end[0]); if (rc) return rc;
+                    rc = tap_dev(L, taps, SVH_ELAS_TRI2,
+                                 reinterpret_cast<int32_t*>(L.prior_dev + L.o_tri) + (size_t)3 * hdr->tri_end[0],
+                                 (size_t)3 * (hdr->tri_end[1] - hdr->tri_end[0])); if (rc) return rc;
+                }
+            }
+            if (!tapping || hdr->active[0]) {
+                // bound of the triangle count for the ownership base: 2 n - 5 per side
+                const int32_t tri_bound = 2 * g * 2 * L.stg.sup_cap;
+                rc = enqueue_phase_b(L.o_P, L.o_sup, L.o_tri, -1, -1, tri_bound);
+                if (rc) return rc;
+            }
+        }
+        HP_MARK(HP_ENQ_A);
     }
     if (!(mode & RG_HOST_B)) return SVH_OK;
+    double t1 = t0, t2 = t0;
+    if (L.resident) {
+        if (!io.out_device) {
+            // host outputs: only maps of pairs that went through may be copied out
+            HIP_TRY(event_wait(L, L.stage_ev));
+            HP_MARK(HP_WAIT);
+            int32_t active[kMaxGroup];
+            for (int32_t j = 0; j < g; j++) active[j] = active_of(j);
+            rc = copy_out(active);
+            if (rc) return rc;
+        }
+        if (g_hostprof) g_hp_pairs += g;
+        HP_MARK(HP_ENQ_B);
+        t1 = t2 = now_ms();
+    } else {
     HIP_TRY(lane_wait(L));
     HIP_TRY(hipGetLastError());
     L.prof.collect();
     HP_MARK(HP_WAIT);
     if (g_hostprof) g_hp_pairs += g;
-    double t1 = now_ms();
-    if (taps && taps->enabled) {
+    t1 = now_ms();
+    if (tapping) {
         rc = tap_dev(L, taps, SVH_ELAS_DESC1, L.desc, N * 16); if (rc) return rc;
         rc = tap_dev(L, taps, SVH_ELAS_DESC2, L.desc + N * 16, N * 16); if (rc) return rc;
         tap_host(taps, SVH_ELAS_DCAN_RAW, L.h_dcan, nc);
     }
 
     // ---- host: lattice filters + Delaunay, then one packed upload ------------
-    GroupHdr* hdr = reinterpret_cast<GroupHdr*>(L.h_prior);
     memset(hdr, 0, sizeof(GroupHdr));
     hdr->npairs = g;
     int32_t total_sup = 0, total_tri = 0, nactive = 0;
@@ -497,14 +782,16 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         }
     }
     hdr->sup_off[g] = total_sup;
-    if (taps && taps->enabled) {
+    hdr->total_sup = total_sup;
+    hdr->total_tri = total_tri;
+    if (tapping) {
         tap_host(taps, SVH_ELAS_SUPPORT, L.hp[0].support.data(), L.hp[0].support.size());
         for (int k = 0; k < 2; k++)
             tap_host(taps, SVH_ELAS_TRI1 + k, L.hp[0].tri[k].data(), L.hp[0].tri[k].size());
     }
     if (nactive == 0) return SVH_OK;   // nothing to match; every status is already set
-    int32_t plane_radius = 2;
     prior_table(p, L.P, &plane_radius);
+    L.P_key[0] = -1;   // this upload overwrites the resident prior table
     size_t off = (sizeof(GroupHdr) + 63) & ~(size_t)63;
     auto put = [&](const void* src, size_t bytes) {
         size_t at = off;
@@ -528,130 +815,29 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
             off += v.size() * sizeof(int32_t);
         }
     if (off > L.prior_cap) return fail(SVH_ERR_BAD_ARG, "prior exceeds staging capacity");
-    double t2 = now_ms();
+    t2 = now_ms();
     HP_MARK(HP_PACK);
 
     // ---- phase B ---------------------------------------------------------
     HIP_TRY(hipMemcpyAsync(L.prior_dev, L.h_prior, off, hipMemcpyHostToDevice, s));
-    GroupDev G;
-    G.hdr = reinterpret_cast<const GroupHdr*>(L.prior_dev);
-    G.P = reinterpret_cast<const int32_t*>(L.prior_dev + o_P);
-    G.support = reinterpret_cast<const int32_t*>(L.prior_dev + o_sup);
-    G.tri = reinterpret_cast<const int32_t*>(L.prior_dev + o_tri);
-    G.raster = L.raster;
-    G.planes = L.planes;
-    G.seed = L.seed;
-    G.mask = L.mask;
-    G.desc = L.desc;
-    G.owner = L.owner;
-    // triangle ownership is stored as owner_base + 1 + index; the base moves above everything
-    // written so far, so the 2 x N x g map is never cleared (one memset when int32 would overflow)
-    if (L.owner_hi + 1 + total_tri >= INT32_MAX) {
-        HIP_TRY(hipMemsetAsync(L.owner, 0, (size_t)2 * L.gcap * N * sizeof(int32_t), s));
-        L.owner_hi = 0;
-    }
-    G.owner_base = (int32_t)L.owner_hi;
-    L.owner_hi += 1 + total_tri;
-    G.Draw = L.Draw;
-    G.plane_radius = plane_radius;
-    G.prior_absmax = 0;
-    for (int32_t dd = 0; dd <= plane_radius && dd < (int32_t)L.P.size(); dd++)
-        G.prior_absmax = std::max(G.prior_absmax, (int32_t)std::min<int64_t>(std::llabs((long long)L.P[dd]), INT32_MAX));
-    launch_prior(cx, p, d, g, total_sup, total_tri, G);
-    if (taps && taps->enabled) {
-        const int32_t n1 = hdr->tri_end[0], n2 = hdr->tri_end[1] - hdr->tri_end[0];
-        rc = tap_dev(L, taps, SVH_ELAS_PLANES1, L.planes, (size_t)6 * n1); if (rc) return rc;
-        rc = tap_dev(L, taps, SVH_ELAS_PLANES2, L.planes + (size_t)6 * n1, (size_t)6 * n2); if (rc) return rc;
-        const size_t words = (size_t)d.gw * d.gh * d.gwords;
-        std::vector<uint32_t> m(2 * words);
-        HIP_TRY(hipMemcpyAsync(m.data(), L.mask, m.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(lane_wait(L));
-        for (int k = 0; k < 2; k++) {
-            std::vector<int32_t> gr;
-            expand_grid(p, d, m.data() + k * words, gr);
-            tap_host(taps, SVH_ELAS_GRID1 + k, gr.data(), gr.size());
-        }
-    }
-    launch_owner(cx, p, d, g, total_tri, G);
-    // when the callers' maps live on the device the post-processing chain runs in
-    // place on them: no final copy
-    DevMaps out;
-    if (io.out_device) {
-        out.D[0] = io.dD[0]; out.D[1] = io.dD[1]; out.stride[0] = out.stride[1] = io.out_stride;
-    } else {
-        out.D[0] = L.D; out.D[1] = L.D + DN; out.stride[0] = out.stride[1] = 2 * DN;
-    }
-    const bool tapping = taps && taps->enabled;
-    const bool tiles = !tapping && post_tiles_ok(p);   // gap + mean (+ speckle mask) tile kernels
-    // the row kernel also applies the L/R check (its inputs are the row it just matched)
-    const bool lr_done = launch_match(cx, p, d, g, G, &out, tapping);
-    // With postprocess_only_left the right map is final once the L/R check is done: its copy to the
-    // caller's host buffer runs on a second stream while the left map is still being post-processed.
-    const bool early_d2 = !io.out_device && lr_done && !tapping && p.postprocess_only_left;
-    if (early_d2) {
-        if (!L.copy_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&L.copy_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&L.match_ev, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&L.copy_ev, hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventRecord(L.match_ev, s));
-    }
-    if (tapping) {
-        rc = tap_dev(L, taps, SVH_ELAS_D1_RAW, L.Draw, DN); if (rc) return rc;
-        rc = tap_dev(L, taps, SVH_ELAS_D2_RAW, L.Draw + DN, DN); if (rc) return rc;
-    }
-    const PostScratch ps = {L.tmp, L.labels, L.counts};
-    const int nside = p.postprocess_only_left ? 1 : 2;
-    if (!lr_done) launch_lr(cx, p, d, g, G, out);
-    if (taps && taps->enabled) {
-        rc = tap_dev(L, taps, SVH_ELAS_D1_LR, out.D[0], DN); if (rc) return rc;
-        rc = tap_dev(L, taps, SVH_ELAS_D2_LR, out.D[1], DN); if (rc) return rc;
-    }
-    launch_segments(cx, p, d, g, nside, G, out, ps, /*mask=*/!tiles);
-    if (taps && taps->enabled) {
-        rc = tap_dev(L, taps, SVH_ELAS_D1_SEG, out.D[0], DN); if (rc) return rc;
-        rc = tap_dev(L, taps, SVH_ELAS_D2_SEG, out.D[1], DN); if (rc) return rc;
-    }
-    if (tiles) {
-        launch_gap_mean_tiles(cx, p, d, g, nside, G, out, ps);   // gap + adaptive mean, two tile kernels
-    } else {
-        launch_gap(cx, p, d, g, nside, G, out, ps);
-        if (taps && taps->enabled) {
-            rc = tap_dev(L, taps, SVH_ELAS_D1_GAP, out.D[0], DN); if (rc) return rc;
-            rc = tap_dev(L, taps, SVH_ELAS_D2_GAP, out.D[1], DN); if (rc) return rc;
-        }
-        if (p.filter_adaptive_mean) launch_adaptive_mean(cx, p, d, g, nside, G, out, ps);
-        if (p.filter_median) launch_median(cx, d, g, nside, G, out, ps);
-    }
-
-    if (!io.out_device) {
-        if (early_d2) {   // (issued after the post-processing launches: a pageable copy blocks this thread)
-            HIP_TRY(hipStreamWaitEvent(L.copy_stream, L.match_ev, 0));
-            for (int32_t j = 0; j < g; j++)
-                if (hdr->active[j])
-                    HIP_TRY(hipMemcpyAsync(io.hD[1][j], L.D + ((size_t)2 * j + 1) * DN, DN * sizeof(float),
-                                           hipMemcpyDeviceToHost, L.copy_stream));
-            HIP_TRY(hipEventRecord(L.copy_ev, L.copy_stream));
-        }
-        for (int32_t j = 0; j < g; j++) {
-            if (!hdr->active[j]) continue;
-            for (int k = 0; k < (early_d2 ? 1 : 2); k++)
-                HIP_TRY(hipMemcpyAsync(io.hD[k][j], L.D + ((size_t)2 * j + k) * DN, DN * sizeof(float),
-                                       hipMemcpyDeviceToHost, s));
-        }
-        if (early_d2) HIP_TRY(hipStreamWaitEvent(s, L.copy_ev, 0));   // the lane's stream ends after both
-    }
+    rc = enqueue_phase_b(o_P, o_sup, o_tri, total_sup, total_tri, total_tri);
+    if (rc) return rc;
+    rc = copy_out(hdr->active);
+    if (rc) return rc;
     HP_MARK(HP_ENQ_B);
+    }
     if (!(mode & RG_FINISH)) return SVH_OK;
-    HIP_TRY(lane_wait(L));
-    HIP_TRY(hipGetLastError());
-    L.prof.collect();
-    HP_MARK(HP_WAIT);
+    rc = finish();
+    if (rc) return rc;
     double t3 = now_ms();
     if (timing) {
         timing->tnames = {"Descriptor+Support Matches (device)", "Filters+Delaunay (host)",
                           "Planes+Grid+Matching+L/R+Segments+Gap+Mean (device)"};
         timing->tms = {(float)(t1 - t0), (float)(t2 - t1), (float)(t3 - t2)};
+        if (L.resident) {
+            timing->tnames = {"enqueue (host)", "whole pipeline incl. Filters+Delaunay (device)"};
+            timing->tms = {(float)(t1 - t0), (float)(t3 - t1)};
+        }
     }
     return SVH_OK;
 }
@@ -868,7 +1054,7 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
         Job pending[2];   // group whose tail is still on slot k's stream
         Job cur = take();
         int k = 0;
-        if (cur.gi >= 0) note(cur, run_group(*slot[0], e->p, dims, cur.io, &st[cur.first], nullptr, nullptr, RG_A));
+        if (cur.gi >= 0) note(cur, run_group(*slot[0], e->p, dims, cur.io, &st[cur.first], nullptr, nullptr, RG_A, true));
         while (cur.gi >= 0) {
             Job nxt = slot[1] ? take() : Job();
             if (nxt.gi >= 0) {
@@ -878,7 +1064,7 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
                                                nullptr, RG_FINISH));
                     pending[o].gi = -1;
                 }
-                note(nxt, run_group(*slot[o], e->p, dims, nxt.io, &st[nxt.first], nullptr, nullptr, RG_A));
+                note(nxt, run_group(*slot[o], e->p, dims, nxt.io, &st[nxt.first], nullptr, nullptr, RG_A, true));
             }
             if (grc[cur.gi] == SVH_OK)
                 note(cur, run_group(*slot[k], e->p, dims, cur.io, &st[cur.first], nullptr, nullptr, RG_HOST_B));
@@ -888,7 +1074,7 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
                 pending[0].gi = -1;
                 nxt = take();
                 if (nxt.gi >= 0)
-                    note(nxt, run_group(*slot[0], e->p, dims, nxt.io, &st[nxt.first], nullptr, nullptr, RG_A));
+                    note(nxt, run_group(*slot[0], e->p, dims, nxt.io, &st[nxt.first], nullptr, nullptr, RG_A, true));
             } else {
                 k = 1 - k;
             }
@@ -973,6 +1159,27 @@ int32_t svh_elas_support_from_candidates(const svh_elas_params* p, int32_t width
     return n;
 }
 
+
+int32_t svh_elas_set_stage(int32_t where) {
+    g_stage_mode.store(where < 0 ? -1 : (where ? 1 : 0));
+    return g_stage_mode.load();
+}
+
+/* debug: phase time stamps of the last group's first slot (not in svh.h) */
+void svh_debug_stage_stamps(int64_t* out32) {
+    Pool* p = pool_for(t_device);
+    std::lock_guard<std::mutex> lk(p->mu);
+    for (Lane* l : p->lanes)
+        if (l->stage_ok) {
+            (void)hipMemcpy(out32, l->stg.counts->dbg, 32 * sizeof(int64_t), hipMemcpyDeviceToHost);
+            return;
+        }
+}
+
+void svh_elas_stage_stats(int64_t* device_groups, int64_t* handed_back) {
+    if (device_groups) *device_groups = g_stage_dev_groups.load();
+    if (handed_back) *handed_back = g_stage_redo_groups.load();
+}
 
 int32_t svh_elas_set_group(int32_t pairs) {
     if (pairs < 1) pairs = 1;

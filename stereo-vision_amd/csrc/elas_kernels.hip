@@ -472,10 +472,13 @@ __device__ bool solve3(double A[3][3], double B[3]) {
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_prior(GroupDev G, int total_tri) {
+__global__ __launch_bounds__(256) void k_prior(GroupDev G, int total_tri_arg) {
     // two lanes per triangle: lane rs = 0 fits the plane in left-image coordinates (t1a..c),
-    // rs = 1 in right-image coordinates (t2a..c); the even lane then builds the raster record
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+    // rs = 1 in right-image coordinates (t2a..c); the even lane then builds the raster record.
+    // total_tri_arg < 0: the header was built on the device and holds the count; the grid is a
+    // bound and blocks stride over the triangles that exist
+    const int total_tri = total_tri_arg >= 0 ? total_tri_arg : G.hdr->total_tri;
+    for (int gid = blockIdx.x * 256 + threadIdx.x; (gid - (int)threadIdx.x) < 2 * total_tri; gid += gridDim.x * 256) {
     const int T = gid >> 1, rs = gid & 1;
     const bool live = T < total_tri;
     const int Tc = live ? T : 0;
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(256) void k_prior(GroupDev G, int total_tri) {
         pl[k] = rs ? other : mine[k];
         pl[3 + k] = rs ? mine[k] : other;
     }
-    if (!live || rs) return;
+    if (!live || rs) continue;
 #pragma unroll
     for (int k = 0; k < 6; k++) G.planes[6 * (size_t)T + k] = pl[k];
 
@@ -560,6 +563,7 @@ __global__ __launch_bounds__(256) void k_prior(GroupDev G, int total_tri) {
     r.first = first;
     r.pad_[0] = 0;
     G.raster[T] = r;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -570,10 +574,10 @@ __global__ __launch_bounds__(256) void k_prior(GroupDev G, int total_tri) {
 // gw+1 .. cells-gw-2 (columns wrap, first/last rows stay empty).  Bit order =
 // ascending disparity = the reference's list order.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_grid_seed(GroupDev G, int total_sup, int gw, int gh,
+__global__ __launch_bounds__(256) void k_grid_seed(GroupDev G, int total_sup_arg, int gw, int gh,
                                                    int gwords, int grid_size, int disp_max) {
-    const int S = blockIdx.x * 256 + threadIdx.x;
-    if (S >= total_sup) return;
+    const int total_sup = total_sup_arg >= 0 ? total_sup_arg : G.hdr->total_sup;
+    for (int S = blockIdx.x * 256 + threadIdx.x; S < total_sup; S += gridDim.x * 256) {
     int pair = 0;
     while (pair < G.hdr->npairs - 1 && S >= G.hdr->sup_off[pair + 1]) pair++;
     const int32_t* s = G.support + 3 * (size_t)S;
@@ -589,6 +593,7 @@ __global__ __launch_bounds__(256) void k_grid_seed(GroupDev G, int total_sup, in
         if (x < 0 || x >= gw || y < 0 || y >= gh) continue;
         uint32_t* cell = G.seed + (((size_t)(2 * pair + side) * cells) + (size_t)y * gw + x) * gwords;
         for (int dd = lo; dd <= hi; dd++) atomicOr(&cell[dd >> 5], 1u << (dd & 31));
+    }
     }
 }
 
@@ -624,10 +629,11 @@ __global__ __launch_bounds__(256) void k_grid_dilate(GroupDev G, int slots, int 
 // ones a lower index won with atomicMax.  Per-pixel atomics are thereby limited
 // to the handful of contested pixels (4-53 per image in the survey's probes).
 template <bool kFix>
-__global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri, int W, int H, int sub) {
-    const int T = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+__global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri_arg, int W, int H, int sub) {
+    const int total_tri = total_tri_arg >= 0 ? total_tri_arg : G.hdr->total_tri;   // see k_prior
     const int lane = threadIdx.x & 63;
-    if (T >= total_tri) return;
+    for (int T = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6)); T < total_tri;
+         T += gridDim.x * 4) {
     const TriRaster tr = G.raster[T];
     const int slot = tr.slot, first = tr.first;
     // stored value = owner_base + 1 + triangle index: everything <= owner_base is a leftover of
@@ -661,6 +667,7 @@ __global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri, int W,
                 }
             }
         }
+    }
     }
 }
 
@@ -1581,9 +1588,13 @@ void launch_prior(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     const int cells = d.gw * d.gh;
     const size_t words = (size_t)2 * g * cells * d.gwords;
     (void)hipMemsetAsync(G.seed, 0, words * sizeof(uint32_t), s);
-    if (total_tri > 0) LAUNCH("k_prior", k_prior, dim3((2 * total_tri + 255) / 256), dim3(256), G, total_tri);
-    if (total_sup > 0)
-        LAUNCH("k_grid_seed", k_grid_seed, dim3((total_sup + 255) / 256), dim3(256), G, total_sup,
+    // device-built header: the launches are sized for a typical count (a lattice at ~15 % density)
+    // and stride over the rest
+    const int sup_bound = std::max(256, g * d.Wc * d.Hc / 6), tri_bound = 4 * sup_bound;
+    const int nt = total_tri >= 0 ? total_tri : tri_bound, ns = total_sup >= 0 ? total_sup : sup_bound;
+    if (nt > 0) LAUNCH("k_prior", k_prior, dim3((2 * nt + 255) / 256), dim3(256), G, total_tri);
+    if (ns > 0)
+        LAUNCH("k_grid_seed", k_grid_seed, dim3((ns + 255) / 256), dim3(256), G, total_sup,
                d.gw, d.gh, d.gwords, p.grid_size, p.disp_max);
     LAUNCH("k_grid_dilate", k_grid_dilate, dim3((unsigned)((words + 255) / 256)), dim3(256), G,
            2 * g, d.gw, d.gh, d.gwords);
@@ -1593,9 +1604,10 @@ void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
                   int32_t total_tri, const GroupDev& G) {
     // no clearing: the engine hands every group a fresh owner_base above all values stored so far
     if (total_tri == 0) return;
-    LAUNCH("k_owner", k_owner<false>, dim3((total_tri + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
+    const int nt = total_tri >= 0 ? total_tri : 4 * std::max(256, g * d.Wc * d.Hc / 6);   // see launch_prior
+    LAUNCH("k_owner", k_owner<false>, dim3((nt + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
            p.subsampling);
-    LAUNCH("k_owner_fix", k_owner<true>, dim3((total_tri + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
+    LAUNCH("k_owner_fix", k_owner<true>, dim3((nt + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
            p.subsampling);
 }
 

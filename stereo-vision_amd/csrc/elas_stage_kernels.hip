@@ -1,0 +1,1093 @@
+// HIP kernels (gfx950) for the stages between the two matching phases of ELAS -- the part that
+// round 1 ran on the host and that bounded throughput per host core:
+//
+//   k_lattice    E5/E6 + list  removeInconsistentSupportPoints, removeRedundantSupportPoints,
+//                              the support list and addCornerSupportPoints
+//                              (libelas/src/elas.cpp:174-318, 495-523)
+//   k_delaunay   E7            Delaunay triangulation of the support points in left and right
+//                              image coordinates with the OUTPUT ORDER of Triangle 1.6 "zQB"
+//                              (libelas/src/triangle.cpp:5446-6230, 7800-7860; elas.cpp:534-600)
+//   k_stage_pack               packed support / triangle lists + the group header the phase-B
+//                              kernels read (what the host used to upload)
+//
+// With these the whole of Elas::process runs on the device without a host round trip in the
+// middle; the host only enqueues.  Everything here is exact integer work.
+//
+// k_lattice.  The consistency filter of the reference scans the lattice u-major IN PLACE: a cell
+// is dropped when fewer than incon_min_support cells of its window are (still) valid and similar,
+// so an earlier drop lowers the count of a later cell.  That recurrence is well-founded (a cell
+// depends on earlier cells only), hence it has exactly one solution, and the solution is the least
+// fixed point of the monotone operator "drop x if (similar valid cells of the window) minus
+// (similar cells EARLIER than x that are dropped) < need".  The kernel iterates that operator in
+// place from "nothing dropped" until nothing changes: every intermediate state is a subset of the
+// true drop set, so any evaluation order (512 lanes at once) converges to the reference's result.
+// The two redundancy passes couple cells of one column (row) only: one lane walks one column (row)
+// in the reference's order.
+//
+// k_delaunay.  Same algorithm as csrc/delaunay.cpp (Guibas-Stolfi divide and conquer, Dwyer's
+// alternating cuts, Triangle's tie rules and record creation order), re-expressed for one
+// workgroup per triangulation:
+//   * ranks instead of sorts: support points are distinct integer points of the image, so the
+//     rank of a point in (x,y) order is (points in lower columns) + (points of its column below
+//     it): two histograms, a scan, and a count inside the column;
+//   * the alternating-cut order by level-synchronous stable partitions (prefix counts);
+//   * the recursion bottom-up by depth: all subproblems of one depth are independent, one lane
+//     each; a subproblem of n vertices owns exactly 2n-2 triangle records, so every lane knows its
+//     record range in advance and the records come out in the sequential creation order;
+//   * a record carries the coordinates of its corners next to their indices, so an orientation /
+//     in-circle test needs no second dependent load; records live in global memory (L2-resident,
+//     ~100 KB per triangulation) -- the walk is latency-bound pointer chasing, one wave of work
+//     next to the streaming kernels of other lanes, and takes no LDS away from them;
+//   * coincident points (possible only for parameter combinations with candidate_stepsize <=
+//     2*lr_threshold) make the survivor depend on the reference's pivot stream: the kernel flags
+//     the pair and the engine reruns that group through the host path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "svh_internal.h"
+
+namespace svh {
+
+namespace {
+
+constexpr int16_t kInv = -32768;   // lattice cell that never held a candidate
+
+// exclusive prefix sum over the block (kT threads); *total = sum of all.  s_tmp: kT/64 + 1 ints
+template <int kT>
+__device__ __forceinline__ int block_excl_scan(int v, int* s_tmp, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();   // s_tmp may still be read from a previous call
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kT / 64; w++) {
+        const int t = s_tmp[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+struct LatticeParams {
+    int W, H, Wc, Hc, step, ws, thr, need, add_corners, sup_cap;
+};
+
+// ---------------------------------------------------------------------------
+// removeInconsistentSupportPoints (elas.cpp:174-209), event driven.  Cell states in val[]:
+// >= 0 valid, kInv never valid, otherwise ~d = dropped (was d).
+//   1. c0(x) = similar valid cells in the window of x on the untouched lattice (what the
+//      reference would count if nothing had been dropped before it reaches x);
+//   2. cells with c0 < need are dropped; every drop of a cell y lowers the count of the similar
+//      cells x of its window that the scan reaches AFTER y (the reference no longer sees y
+//      there), and a count that falls below `need` is the next drop.
+// A count only ever loses cells that the reference's scan has dropped as well, so no cell is
+// dropped early, and at the end every consequence has been propagated: the reference's lattice.
+// Counters are bytes (a window of up to 15 x 15 cells), four to a word, lowered with one atomic.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void lattice_consistency_events(int16_t* val, uint32_t* cntw, int32_t* wl, int nc,
+                                                           const LatticeParams& P, int* s_n) {
+    const int tid = threadIdx.x, Wc = P.Wc, Hc = P.Hc;
+    int32_t* alive = wl;
+    int32_t* fresh[2] = {wl + nc, wl + 2 * (size_t)nc};
+    if (tid < 3) s_n[tid] = 0;
+    for (int i = tid; i < (nc + 3) / 4; i += 512) cntw[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nc; i += 512)
+        if (val[i] >= 0) alive[atomicAdd(&s_n[0], 1)] = i;
+    __syncthreads();
+    const int nalive = s_n[0];
+    for (int k = tid; k < nalive; k += 512) {
+        const int at = alive[k];
+        const int vc = at / Wc, uc = at - vc * Wc, dv = val[at];
+        const int ulo = max(uc - P.ws, 0), uhi = min(uc + P.ws, Wc - 1);
+        const int vlo = max(vc - P.ws, 0), vhi = min(vc + P.ws, Hc - 1);
+        int cnt = 0;
+        for (int v2 = vlo; v2 <= vhi; v2++) {
+            const int16_t* row = val + v2 * Wc;
+            for (int u2 = ulo; u2 <= uhi; u2++) {
+                const int x = row[u2];
+                const int df = x > dv ? x - dv : dv - x;
+                cnt += (x >= 0) & (df <= P.thr);
+            }
+        }
+        atomicAdd(&cntw[at >> 2], (uint32_t)cnt << (8 * (at & 3)));   // bytes of one word: other lanes
+    }
+    __syncthreads();
+    for (int k = tid; k < nalive; k += 512) {
+        const int at = alive[k];
+        const int c0 = (cntw[at >> 2] >> (8 * (at & 3))) & 255;
+        if (c0 < P.need) {
+            val[at] = (int16_t)~val[at];
+            fresh[0][atomicAdd(&s_n[1], 1)] = at;
+        }
+    }
+    __syncthreads();
+    for (int pr = 0;; pr ^= 1) {
+        const int n = s_n[1 + pr];
+        if (n == 0) break;
+        __syncthreads();
+        if (tid == 0) s_n[1 + (pr ^ 1)] = 0;
+        __syncthreads();
+        for (int k = tid; k < n; k += 512) {
+            const int at = fresh[pr][k];
+            const int vy = at / Wc, uy = at - vy * Wc, dy = ~(int)val[at];
+            const int uhi = min(uy + P.ws, Wc - 1);
+            const int vlo = max(vy - P.ws, 0), vhi = min(vy + P.ws, Hc - 1);
+            for (int u2 = uy; u2 <= uhi; u2++)
+                for (int v2 = (u2 == uy ? vy + 1 : vlo); v2 <= vhi; v2++) {
+                    const int x = v2 * Wc + u2, dx = val[x];
+                    const int df = dx > dy ? dx - dy : dy - dx;
+                    if (dx < 0 || df > P.thr) continue;
+                    const uint32_t old = atomicSub(&cntw[x >> 2], 1u << (8 * (x & 3)));
+                    if ((int)((old >> (8 * (x & 3))) & 255) == P.need) {   // this drop takes it below
+                        val[x] = (int16_t)~dx;
+                        fresh[pr ^ 1][atomicAdd(&s_n[1 + (pr ^ 1)], 1)] = x;
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < nc; i += 512)
+        if (val[i] < 0) val[i] = kInv;
+    __syncthreads();
+}
+
+// The same filter for windows of more than 255 cells: sweeps of the monotone operator "drop x if
+// (similar valid cells of the window) minus (similar cells scanned before x that are dropped) <
+// need", in place, until nothing changes (least fixed point = the reference's result).
+__device__ __forceinline__ void lattice_consistency_sweeps(int16_t* val, int nc, const LatticeParams& P) {
+    const int tid = threadIdx.x, Wc = P.Wc, Hc = P.Hc;
+    for (;;) {
+        int changed = 0;
+        for (int i = tid; i < nc; i += 512) {
+            const int uc = i / Hc, vc = i - uc * Hc;   // u-major: a sweep carries drops forward
+            const int at = vc * Wc + uc;
+            const int dv = val[at];
+            if (dv < 0) continue;
+            const int ulo = max(uc - P.ws, 0), uhi = min(uc + P.ws, Wc - 1);
+            const int vlo = max(vc - P.ws, 0), vhi = min(vc + P.ws, Hc - 1);
+            int cnt = 0;
+            for (int v2 = vlo; v2 <= vhi; v2++) {
+                const int16_t* row = val + v2 * Wc;
+                for (int u2 = ulo; u2 <= uhi; u2++) {
+                    const int x = row[u2];
+                    if (x == kInv) continue;
+                    const int dx = x >= 0 ? x : ~x;
+                    const int df = dx > dv ? dx - dv : dv - dx;
+                    const bool earlier = u2 < uc || (u2 == uc && v2 < vc);
+                    cnt += (df <= P.thr) && !(x < 0 && earlier);
+                }
+            }
+            if (cnt < P.need) {
+                val[at] = (int16_t)~dv;
+                changed = 1;
+            }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    for (int i = tid; i < nc; i += 512)
+        if (val[i] < 0) val[i] = kInv;
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// E5 / E6 / list / corners.  One block per pair.  kLds: lattice and counters fit LDS (3 bytes per
+// cell); otherwise the lattice is filtered in place in global memory (very large images).
+// ---------------------------------------------------------------------------
+template <bool kLds>
+__global__ __launch_bounds__(512) void k_lattice(StageDev S, LatticeParams P) {
+    extern __shared__ int16_t s_dyn[];
+    __shared__ int s_scan[512 / 64 + 1];
+    __shared__ int s_n[4];
+    __shared__ unsigned long long s_best[4];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int Wc = P.Wc, Hc = P.Hc, nc = Wc * Hc;
+    int16_t* raw = S.dcan + (size_t)pair * nc;
+    int16_t* val = kLds ? s_dyn : raw;
+    const int ncw = (nc + 3) / 4;
+    uint32_t* cntw = kLds ? reinterpret_cast<uint32_t*>(s_dyn + ((nc + 1) & ~1)) : S.cntw + (size_t)pair * ncw;
+#define STAMP(k) do { if (pair == 0 && tid == 0) S.counts->dbg[k] = wall_clock64(); } while (0)
+    STAMP(0);
+    for (int i = tid; i < nc; i += 512) {
+        const int16_t r = raw[i];
+        val[i] = r < 0 ? kInv : r;
+    }
+    __syncthreads();
+    STAMP(1);
+    if (P.need > 0) {
+        if ((2 * P.ws + 1) * (2 * P.ws + 1) <= 255 && P.need <= 255)
+            lattice_consistency_events(val, cntw, S.wl + (size_t)pair * 3 * nc, nc, P, s_n);
+        else
+            lattice_consistency_sweeps(val, nc, P);
+    }
+    STAMP(2);
+    // ---- removeRedundantSupportPoints (elas.cpp:213-279 as called at :501-502: distance 5,
+    // threshold 1), vertical then horizontal.  A pass couples the cells of one column (row) only:
+    // one lane walks one line in the reference's order with the five cells behind it (as the
+    // pass left them) and the five ahead (untouched) in registers.
+    for (int pass = 0; pass < 2; pass++) {
+        const int lines = pass == 0 ? Wc : Hc, steps = pass == 0 ? Hc : Wc;
+        const int ls = pass == 0 ? 1 : Wc, ss = pass == 0 ? Wc : 1;   // strides: line, step
+        for (int l = tid; l < lines; l += 512) {
+            int16_t* line = val + l * ls;
+            int b[5], a[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                b[j] = kInv;
+                a[j] = 1 + j < steps ? line[(1 + j) * ss] : kInv;
+            }
+            int cur = line[0];
+            for (int t = 0; t < steps; t++) {
+                const int nxt = t + 6 < steps ? line[(t + 6) * ss] : kInv;
+                int dv = cur;
+                if (dv >= 0) {
+                    bool fb = false, fa = false;
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        const int db = b[j] > dv ? b[j] - dv : dv - b[j];
+                        const int da = a[j] > dv ? a[j] - dv : dv - a[j];
+                        fb |= (b[j] >= 0) & (db <= 1);
+                        fa |= (a[j] >= 0) & (da <= 1);
+                    }
+                    if (fb && fa) {
+                        dv = kInv;
+                        line[t * ss] = kInv;
+                    }
+                }
+#pragma unroll
+                for (int j = 4; j > 0; j--) b[j] = b[j - 1];
+                b[0] = dv;
+                cur = a[0];
+#pragma unroll
+                for (int j = 0; j < 4; j++) a[j] = a[j + 1];
+                a[4] = nxt;
+            }
+        }
+        __syncthreads();
+    }
+    STAMP(3);
+    // ---- list, u-major from (1,1) (elas.cpp:505-517)
+    const int Hm = Hc - 1, tot = (Wc - 1) * Hm;
+    const int chunk = (max(tot, 0) + 511) / 512;
+    const int i0 = tid * chunk, i1 = min(tot, i0 + chunk);
+    int mine = 0;
+    for (int i = i0; i < i1; i++) {
+        const int uc = 1 + i / Hm, vc = 1 + i - (uc - 1) * Hm;
+        mine += val[vc * Wc + uc] >= 0;
+    }
+    int n = 0;
+    int pos = block_excl_scan<512>(mine, s_scan, &n);
+    int32_t* sup = S.sup_raw + (size_t)pair * 3 * P.sup_cap;
+    const bool room = n + (P.add_corners ? 6 : 0) <= P.sup_cap;
+    if (room)
+        for (int i = i0; i < i1; i++) {
+            const int uc = 1 + i / Hm, vc = 1 + i - (uc - 1) * Hm;
+            const int dv = val[vc * Wc + uc];
+            if (dv >= 0) {
+                sup[3 * pos] = uc * P.step;
+                sup[3 * pos + 1] = vc * P.step;
+                sup[3 * pos + 2] = dv;
+                pos++;
+            }
+        }
+    // ---- addCornerSupportPoints (elas.cpp:283-318): disparity of the nearest support point
+    // (first one on ties: smallest (distance, index) key)
+    if (P.add_corners && room) {
+        if (tid < 4) s_best[tid] = ~0ull;
+        __syncthreads();   // also makes the list visible
+        const int cu[4] = {0, 0, P.W - 1, P.W - 1};
+        const int cv[4] = {0, P.H - 1, 0, P.H - 1};
+        unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+        for (int j = tid; j < n; j += 512) {
+            const int su = sup[3 * j], sv = sup[3 * j + 1];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const long long du = cu[c] - su, dw = cv[c] - sv;
+                const unsigned long long dist = (unsigned long long)(du * du + dw * dw);
+                if (dist < 10000000ull) {
+                    const unsigned long long key = dist << 32 | (unsigned)j;
+                    best[c] = key < best[c] ? key : best[c];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            if (best[c] != ~0ull) atomicMin(&s_best[c], best[c]);
+        __syncthreads();
+        if (tid == 0) {
+            int cd[4];
+            for (int c = 0; c < 4; c++)
+                cd[c] = s_best[c] == ~0ull ? 0 : sup[3 * (int)(s_best[c] & 0xffffffffu) + 2];
+            for (int c = 0; c < 4; c++) {
+                sup[3 * (n + c)] = cu[c];
+                sup[3 * (n + c) + 1] = cv[c];
+                sup[3 * (n + c) + 2] = cd[c];
+            }
+            for (int c = 2; c < 4; c++) {   // the two right-image corners
+                sup[3 * (n + 2 + c)] = cu[c] + cd[c];
+                sup[3 * (n + 2 + c) + 1] = cv[c];
+                sup[3 * (n + 2 + c) + 2] = cd[c];
+            }
+        }
+        n += 6;
+    }
+    STAMP(4);
+#undef STAMP
+    if (tid == 0) {
+        S.counts->nsup[pair] = room ? n : 0;
+        S.counts->flags[pair] = room ? (n < 3 ? STG_FEW : 0) : STG_OVERFLOW;
+    }
+}
+
+// ===========================================================================
+// Delaunay
+// ===========================================================================
+struct Vtx {
+    int id;   // input index, -1 = the ghost vertex
+    int xy;   // x | y << 16
+};
+__device__ __forceinline__ int vx(const Vtx& v) { return v.xy & 0xffff; }
+__device__ __forceinline__ int vy(const Vtx& v) { return (int)((unsigned)v.xy >> 16); }
+
+// Triangle records of one triangulation; handle = record * 4 + orientation, 0 = "outer space";
+// handle algebra as in csrc/delaunay.cpp.  Two storages with the same interface:
+//   MeshG  global memory (L2-resident): 32-bit fields, the packed coordinates of a corner sit next
+//          to its index, so a predicate needs no second dependent load;
+//   MeshL  LDS: 16-bit fields (record r: slots 3r..3r+2 of ids[] and nbr[]), coordinates through
+//          the vertex table -- a quarter of the latency per hop; used when 28 bytes per point fit.
+struct MeshG {
+    int* ids;
+    int* xys;
+    unsigned* nbr;
+    __device__ __forceinline__ unsigned sym(unsigned h) const { return nbr[h]; }
+    __device__ __forceinline__ Vtx corner(unsigned t4, int k) const {
+        Vtx v;
+        v.id = ids[t4 + k];
+        v.xy = xys[t4 + k];
+        return v;
+    }
+    __device__ __forceinline__ void set_corner(unsigned t4, int k, const Vtx& v) const {
+        ids[t4 + k] = v.id;
+        xys[t4 + k] = v.xy;
+    }
+    __device__ __forceinline__ void bond(unsigned a, unsigned b) const {
+        nbr[a] = b;
+        nbr[b] = a;
+    }
+    __device__ __forceinline__ unsigned make_rec(int t) const {
+        *reinterpret_cast<int4*>(ids + 4 * (size_t)t) = make_int4(-1, -1, -1, 0);
+        *reinterpret_cast<int4*>(xys + 4 * (size_t)t) = make_int4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(nbr + 4 * (size_t)t) = make_uint4(0, 0, 0, 0);
+        return (unsigned)t * 4u;
+    }
+};
+struct MeshL {
+    unsigned short* ids;
+    unsigned short* nbr;
+    const int* vxy;   // packed coordinates by vertex index
+    __device__ __forceinline__ unsigned sym(unsigned h) const { return nbr[h - (h >> 2)]; }
+    __device__ __forceinline__ Vtx corner(unsigned t4, int k) const {
+        const unsigned id = ids[t4 - (t4 >> 2) + k];
+        Vtx v;
+        v.id = id == 0xffffu ? -1 : (int)id;
+        v.xy = id == 0xffffu ? 0 : vxy[id];
+        return v;
+    }
+    __device__ __forceinline__ void set_corner(unsigned t4, int k, const Vtx& v) const {
+        ids[t4 - (t4 >> 2) + k] = (unsigned short)v.id;
+    }
+    __device__ __forceinline__ void bond(unsigned a, unsigned b) const {
+        nbr[a - (a >> 2)] = (unsigned short)b;
+        nbr[b - (b >> 2)] = (unsigned short)a;
+    }
+    __device__ __forceinline__ unsigned make_rec(int t) const {
+        for (int k = 0; k < 3; k++) {
+            ids[3 * t + k] = 0xffffu;
+            nbr[3 * t + k] = 0;
+        }
+        return (unsigned)t * 4u;
+    }
+};
+__device__ __forceinline__ int p1(int o) { return (0x09 >> (2 * o)) & 3; }   // (o + 1) % 3
+__device__ __forceinline__ int p2(int o) { return (0x12 >> (2 * o)) & 3; }   // (o + 2) % 3
+__device__ __forceinline__ unsigned hnext(unsigned h) { return (h & ~3u) | (unsigned)p1(h & 3); }
+__device__ __forceinline__ unsigned hprev(unsigned h) { return (h & ~3u) | (unsigned)p2(h & 3); }
+template <class M> __device__ __forceinline__ unsigned sym(const M& m, unsigned h) { return m.sym(h); }
+template <class M> __device__ __forceinline__ Vtx org(const M& m, unsigned h) { return m.corner(h & ~3u, p1(h & 3)); }
+template <class M> __device__ __forceinline__ Vtx dest(const M& m, unsigned h) { return m.corner(h & ~3u, p2(h & 3)); }
+template <class M> __device__ __forceinline__ Vtx apex(const M& m, unsigned h) { return m.corner(h & ~3u, h & 3); }
+template <class M> __device__ __forceinline__ void set_org(const M& m, unsigned h, const Vtx& v) { m.set_corner(h & ~3u, p1(h & 3), v); }
+template <class M> __device__ __forceinline__ void set_dest(const M& m, unsigned h, const Vtx& v) { m.set_corner(h & ~3u, p2(h & 3), v); }
+template <class M> __device__ __forceinline__ void set_apex(const M& m, unsigned h, const Vtx& v) { m.set_corner(h & ~3u, h & 3, v); }
+template <class M> __device__ __forceinline__ void bond(const M& m, unsigned a, unsigned b) { m.bond(a, b); }
+template <class M> __device__ __forceinline__ unsigned make_rec(const M& m, int t) { return m.make_rec(t); }
+
+// exact predicates: coordinates are integers in [0, 2^14)
+__device__ __forceinline__ int ccw(const Vtx& a, const Vtx& b, const Vtx& c) {
+    const int l = (vx(a) - vx(c)) * (vy(b) - vy(c));
+    const int r = (vy(a) - vy(c)) * (vx(b) - vx(c));
+    return l > r ? 1 : (l < r ? -1 : 0);
+}
+__device__ __forceinline__ int incircle(const Vtx& a, const Vtx& b, const Vtx& c, const Vtx& d) {
+    const int adx = vx(a) - vx(d), ady = vy(a) - vy(d);
+    const int bdx = vx(b) - vx(d), bdy = vy(b) - vy(d);
+    const int cdx = vx(c) - vx(d), cdy = vy(c) - vy(d);
+    const long long al = adx * adx + ady * ady, bl = bdx * bdx + bdy * bdy, cl = cdx * cdx + cdy * cdy;
+    const long long det = al * (long long)(bdx * cdy - cdx * bdy) + bl * (long long)(cdx * ady - adx * cdy) +
+                          cl * (long long)(adx * bdy - bdx * ady);
+    return det > 0 ? 1 : (det < 0 ? -1 : 0);
+}
+const Vtx kGhost = {-1, 0};
+
+// leaves of the recursion (triangle.cpp:5953-6103 / delaunay.cpp recurse, n == 2 and n == 3)
+template <class M>
+__device__ void dt_leaf(const M& m, const int* order, const int* oxy, int s, int n, int ctr, unsigned* farleft,
+                        unsigned* farright) {
+    Vtx a[3];
+    for (int k = 0; k < n; k++) {
+        a[k].id = order[s + k];
+        a[k].xy = oxy[s + k];
+    }
+    if (n == 2) {
+        unsigned L = make_rec(m, ctr), R = make_rec(m, ctr + 1);
+        set_org(m, L, a[0]);
+        set_dest(m, L, a[1]);
+        set_org(m, R, a[1]);
+        set_dest(m, R, a[0]);
+        bond(m, L, R);
+        L = hprev(L); R = hnext(R);
+        bond(m, L, R);
+        L = hprev(L); R = hnext(R);
+        bond(m, L, R);
+        *farright = R;
+        *farleft = hprev(R);
+        return;
+    }
+    unsigned mid = make_rec(m, ctr), t1 = make_rec(m, ctr + 1), t2 = make_rec(m, ctr + 2), t3 = make_rec(m, ctr + 3);
+    const int area = ccw(a[0], a[1], a[2]);
+    if (area == 0) {
+        set_org(m, mid, a[0]); set_dest(m, mid, a[1]);
+        set_org(m, t1, a[1]);  set_dest(m, t1, a[0]);
+        set_org(m, t2, a[2]);  set_dest(m, t2, a[1]);
+        set_org(m, t3, a[1]);  set_dest(m, t3, a[2]);
+        bond(m, mid, t1);
+        bond(m, t2, t3);
+        mid = hnext(mid); t1 = hprev(t1); t2 = hnext(t2); t3 = hprev(t3);
+        bond(m, mid, t3);
+        bond(m, t1, t2);
+        mid = hnext(mid); t1 = hprev(t1); t2 = hnext(t2); t3 = hprev(t3);
+        bond(m, mid, t1);
+        bond(m, t2, t3);
+        *farleft = t1;
+        *farright = t2;
+    } else {
+        const Vtx p = area > 0 ? a[1] : a[2];
+        const Vtx q = area > 0 ? a[2] : a[1];
+        set_org(m, mid, a[0]); set_dest(m, t1, a[0]); set_org(m, t3, a[0]);
+        set_dest(m, mid, p);   set_org(m, t1, p);     set_dest(m, t2, p);
+        set_apex(m, mid, q);   set_org(m, t2, q);     set_dest(m, t3, q);
+        bond(m, mid, t1);
+        mid = hnext(mid);
+        bond(m, mid, t2);
+        mid = hnext(mid);
+        bond(m, mid, t3);
+        t1 = hprev(t1); t2 = hnext(t2);
+        bond(m, t1, t2);
+        t1 = hprev(t1); t3 = hprev(t3);
+        bond(m, t1, t3);
+        t2 = hnext(t2); t3 = hprev(t3);
+        bond(m, t2, t3);
+        *farleft = t1;
+        *farright = area > 0 ? t2 : hnext(t1);
+    }
+}
+
+// merge of two triangulated halves (triangle.cpp:5638-5934 / delaunay.cpp merge); the two seam
+// records are ctr and ctr + 1
+template <class M>
+__device__ void dt_merge(const M& m, unsigned* farleft, unsigned innerleft, unsigned innerright, unsigned* farright,
+                         int axis, int ctr) {
+    Vtx il_dest = dest(m, innerleft), il_apex = apex(m, innerleft);
+    Vtx ir_org = org(m, innerright), ir_apex = apex(m, innerright);
+    if (axis == 1) {
+        // horizontal cut: the extreme handles go from leftmost / rightmost to bottommost / topmost
+        Vtx fl_pt = org(m, *farleft), fl_apex = apex(m, *farleft);
+        Vtx fr_pt = dest(m, *farright);
+        while (vy(fl_apex) < vy(fl_pt)) {
+            *farleft = sym(m, hnext(*farleft));
+            fl_pt = fl_apex;
+            fl_apex = apex(m, *farleft);
+        }
+        unsigned chk = sym(m, innerleft);
+        Vtx cv = apex(m, chk);
+        while (vy(cv) > vy(il_dest)) {
+            innerleft = hnext(chk);
+            il_apex = il_dest;
+            il_dest = cv;
+            chk = sym(m, innerleft);
+            cv = apex(m, chk);
+        }
+        while (vy(ir_apex) < vy(ir_org)) {
+            innerright = sym(m, hnext(innerright));
+            ir_org = ir_apex;
+            ir_apex = apex(m, innerright);
+        }
+        chk = sym(m, *farright);
+        cv = apex(m, chk);
+        while (vy(cv) > vy(fr_pt)) {
+            *farright = hnext(chk);
+            fr_pt = cv;
+            chk = sym(m, *farright);
+            cv = apex(m, chk);
+        }
+    }
+    // lower common tangent
+    bool moved;
+    do {
+        moved = false;
+        if (ccw(il_dest, il_apex, ir_org) > 0) {
+            innerleft = sym(m, hprev(innerleft));
+            il_dest = il_apex;
+            il_apex = apex(m, innerleft);
+            moved = true;
+        }
+        if (ccw(ir_apex, ir_org, il_dest) > 0) {
+            innerright = sym(m, hnext(innerright));
+            ir_org = ir_apex;
+            ir_apex = apex(m, innerright);
+            moved = true;
+        }
+    } while (moved);
+
+    unsigned lcand = sym(m, innerleft), rcand = sym(m, innerright);
+    unsigned base = make_rec(m, ctr);
+    bond(m, base, innerleft);
+    base = hnext(base);
+    bond(m, base, innerright);
+    base = hnext(base);
+    set_org(m, base, ir_org);
+    set_dest(m, base, il_dest);
+    if (il_dest.id == org(m, *farleft).id) *farleft = hnext(base);
+    if (ir_org.id == dest(m, *farright).id) *farright = hprev(base);
+
+    Vtx lowerleft = il_dest, lowerright = ir_org;
+    Vtx upperleft = apex(m, lcand), upperright = apex(m, rcand);
+    for (;;) {
+        const bool leftdone = ccw(upperleft, lowerleft, lowerright) <= 0;
+        const bool rightdone = ccw(upperright, lowerleft, lowerright) <= 0;
+        if (leftdone && rightdone) {
+            unsigned top = make_rec(m, ctr + 1);
+            set_org(m, top, lowerleft);
+            set_dest(m, top, lowerright);
+            bond(m, top, base);
+            top = hnext(top);
+            bond(m, top, rcand);
+            top = hnext(top);
+            bond(m, top, lcand);
+            if (axis == 1) {
+                // back to leftmost / rightmost anchors
+                Vtx fl_pt = org(m, *farleft);
+                Vtx fr_pt = dest(m, *farright), fr_apex = apex(m, *farright);
+                unsigned chk = sym(m, *farleft);
+                Vtx cv = apex(m, chk);
+                while (vx(cv) < vx(fl_pt)) {
+                    *farleft = hprev(chk);
+                    fl_pt = cv;
+                    chk = sym(m, *farleft);
+                    cv = apex(m, chk);
+                }
+                while (vx(fr_apex) > vx(fr_pt)) {
+                    *farright = sym(m, hprev(*farright));
+                    fr_pt = fr_apex;
+                    fr_apex = apex(m, *farright);
+                }
+            }
+            return;
+        }
+        if (!leftdone) {
+            // strip left-side edges that fail the in-circle test (flips in place)
+            unsigned nx = sym(m, hprev(lcand));
+            Vtx nap = apex(m, nx);
+            if (nap.id >= 0) {
+                bool bad = incircle(lowerleft, lowerright, upperleft, nap) > 0;
+                while (bad) {
+                    nx = hnext(nx);
+                    const unsigned topc = sym(m, nx);
+                    nx = hnext(nx);
+                    const unsigned sidec = sym(m, nx);
+                    bond(m, nx, topc);
+                    bond(m, lcand, sidec);
+                    lcand = hnext(lcand);
+                    const unsigned outerc = sym(m, lcand);
+                    nx = hprev(nx);
+                    bond(m, nx, outerc);
+                    set_org(m, lcand, lowerleft);
+                    set_dest(m, lcand, kGhost);
+                    set_apex(m, lcand, nap);
+                    set_org(m, nx, kGhost);
+                    set_dest(m, nx, upperleft);
+                    set_apex(m, nx, nap);
+                    upperleft = nap;
+                    nx = sidec;
+                    nap = apex(m, nx);
+                    bad = nap.id >= 0 && incircle(lowerleft, lowerright, upperleft, nap) > 0;
+                }
+            }
+        }
+        if (!rightdone) {
+            unsigned nx = sym(m, hnext(rcand));
+            Vtx nap = apex(m, nx);
+            if (nap.id >= 0) {
+                bool bad = incircle(lowerleft, lowerright, upperright, nap) > 0;
+                while (bad) {
+                    nx = hprev(nx);
+                    const unsigned topc = sym(m, nx);
+                    nx = hprev(nx);
+                    const unsigned sidec = sym(m, nx);
+                    bond(m, nx, topc);
+                    bond(m, rcand, sidec);
+                    rcand = hprev(rcand);
+                    const unsigned outerc = sym(m, rcand);
+                    nx = hnext(nx);
+                    bond(m, nx, outerc);
+                    set_org(m, rcand, kGhost);
+                    set_dest(m, rcand, lowerright);
+                    set_apex(m, rcand, nap);
+                    set_org(m, nx, upperright);
+                    set_dest(m, nx, kGhost);
+                    set_apex(m, nx, nap);
+                    upperright = nap;
+                    nx = sidec;
+                    nap = apex(m, nx);
+                    bad = nap.id >= 0 && incircle(lowerleft, lowerright, upperright, nap) > 0;
+                }
+            }
+        }
+        if (leftdone || (!rightdone && incircle(upperleft, lowerleft, lowerright, upperright) > 0)) {
+            // new edge lowerleft -> upperright
+            bond(m, base, rcand);
+            base = hprev(rcand);
+            set_dest(m, base, lowerleft);
+            lowerright = upperright;
+            rcand = sym(m, base);
+            upperright = apex(m, rcand);
+        } else {
+            // new edge upperleft -> lowerright (also on a co-circular tie)
+            bond(m, base, lcand);
+            base = hnext(lcand);
+            set_org(m, base, lowerright);
+            lowerleft = upperleft;
+            lcand = sym(m, base);
+            upperleft = apex(m, lcand);
+        }
+    }
+}
+
+struct DtParams {
+    int lds_cap;                  // points whose records fit the block's LDS (28 bytes per point)
+    int xoff;                     // added to x: the left corner points lie at -d in the right image
+    int W, H, sup_cap, rec_cap;   // W: columns the points may use (image width + disp_max: the two
+};                                // right-image corner points of addCornerSupportPoints lie at W-1+d)
+
+// node (s, n) reached from the root (0, m) along the top `depth` bits of `path` (MSB first);
+// returns false when a leaf is met before `depth`.  base = first record of the node.
+__device__ __forceinline__ bool dt_descend(int m, int depth, unsigned path, int* s, int* n, int* base) {
+    int ss = 0, nn = m, bb = 1;
+    for (int k = depth - 1; k >= 0; k--) {
+        if (nn <= 3) return false;
+        const int h = nn >> 1;
+        if ((path >> k) & 1) {
+            bb += 2 * h - 2;
+            ss += h;
+            nn -= h;
+        } else {
+            nn = h;
+        }
+    }
+    *s = ss; *n = nn; *base = bb;
+    return true;
+}
+// segment of position i at `depth` (stops at leaves): start, size
+__device__ __forceinline__ void dt_segment(int m, int depth, int i, int* s, int* n) {
+    int ss = 0, nn = m;
+    for (int k = 0; k < depth && nn > 3; k++) {
+        const int h = nn >> 1;
+        if (i < ss + h) nn = h;
+        else { ss += h; nn -= h; }
+    }
+    *s = ss; *n = nn;
+}
+
+// The recursion of the divide and conquer, bottom-up: all nodes of one depth are independent (one
+// lane each), leaves at `depth` first, the root last.  FL / FR: hull handles (farleft, farright)
+// of the nodes of a depth, by first vertex, two depths alternating.
+template <class M>
+__device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const int* order, const int* oxy,
+                                         unsigned* FL, unsigned* FR, int sup_cap, int64_t* dbg, bool stamp) {
+    const int tid = threadIdx.x;
+    if (tid == 0) make_rec(mesh, 0);   // record 0 = outer space
+    __syncthreads();
+    for (int d = depth; d >= 0; d--) {
+        unsigned* fl = FL + (size_t)(d & 1) * sup_cap;
+        unsigned* fr = FR + (size_t)(d & 1) * sup_cap;
+        const unsigned* cfl = FL + (size_t)((d + 1) & 1) * sup_cap;
+        const unsigned* cfr = FR + (size_t)((d + 1) & 1) * sup_cap;
+        const unsigned tasks = 1u << d;
+        for (unsigned j = tid; j < tasks; j += 256) {
+            int s, n, base;
+            if (!dt_descend(m, d, j, &s, &n, &base)) continue;
+            unsigned a, b;
+            if (n <= 3) {
+                dt_leaf(mesh, order, oxy, s, n, base, &a, &b);
+            } else {
+                const int h = n >> 1;
+                a = cfl[s];
+                b = cfr[s + h];
+                dt_merge(mesh, &a, cfr[s], cfl[s + h], &b, d & 1, base + 2 * n - 4);
+            }
+            fl[s] = a;
+            fr[s] = b;
+        }
+        __syncthreads();
+        if (stamp && tid == 0 && 11 + (depth - d) < 30) dbg[11 + (depth - d)] = wall_clock64();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// One block per (pair, side).  LDS: column / row histograms of the points.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_delaunay(StageDev S, DtParams P) {
+    extern __shared__ int s_hist[];   // [W + 1] column starts, [H + 1] row starts, then two cursors copies
+    __shared__ int s_scan[256 / 64 + 1];
+    const int slot = blockIdx.x, pair = slot >> 1, side = slot & 1, tid = threadIdx.x;
+    const int m = S.counts->nsup[pair];
+    if (m < 3 || (S.counts->flags[pair] & STG_OVERFLOW)) {
+        if (tid == 0) S.counts->ntri[slot] = 0;
+        return;
+    }
+    const size_t so = (size_t)slot * P.sup_cap;
+    const int32_t* sup = S.sup_raw + (size_t)pair * 3 * P.sup_cap;
+    int* pxy = S.pxy + so;
+    int* bx = S.buck + so;
+    int* by = S.buck2 + so;
+    int* byx = S.byx + so;
+    unsigned* lx = S.lx + so;
+    unsigned* ly = S.ly + so;
+    unsigned* tmp = S.tmp + so;
+    unsigned* Pc = S.P + so;
+    int* order = S.order + so;
+    int* oxy = S.oxy + so;
+    int* colstart = s_hist;                  // W + 1
+    int* rowstart = s_hist + P.W + 1;        // H + 1
+    int* curx = rowstart + P.H + 1;          // W
+    int* cury = curx + P.W;                  // H
+    const int nh = 2 * (P.W + P.H) + 2;
+#define STAMP(k) do { if (slot == 0 && tid == 0) S.counts->dbg[k] = wall_clock64(); } while (0)
+    STAMP(8);
+    for (int i = tid; i < nh; i += 256) s_hist[i] = 0;
+    __syncthreads();
+
+    // ---- ranks in (x,y) and (y,x) order
+    int bad = 0;
+    for (int p = tid; p < m; p += 256) {
+        const int x = (side ? sup[3 * p] - sup[3 * p + 2] : sup[3 * p]) + P.xoff, y = sup[3 * p + 1];
+        if (x < 0 || x >= P.W || y < 0 || y >= P.H) {
+            bad = 1;
+            continue;
+        }
+        pxy[p] = x | y << 16;
+        atomicAdd(&colstart[x + 1], 1);
+        atomicAdd(&rowstart[y + 1], 1);
+    }
+    if (__syncthreads_or(bad)) {
+        if (tid == 0) {
+            atomicOr(&S.counts->flags[pair], STG_OVERFLOW);
+            S.counts->ntri[slot] = 0;
+        }
+        return;
+    }
+    // inclusive scans of the two histograms (entry k+1 holds the count of column k)
+    for (int which = 0; which < 2; which++) {
+        int* h = which ? rowstart : colstart;
+        const int len = (which ? P.H : P.W) + 1;
+        const int chunk = (len + 255) / 256, a = tid * chunk, b = min(len, a + chunk);
+        int sum = 0;
+        for (int i = a; i < b; i++) sum += h[i];
+        int tot;
+        int run = block_excl_scan<256>(sum, s_scan, &tot);
+        for (int i = a; i < b; i++) {
+            run += h[i];
+            h[i] = run;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < P.W; i += 256) curx[i] = colstart[i];
+    for (int i = tid; i < P.H; i += 256) cury[i] = rowstart[i];
+    __syncthreads();
+    for (int p = tid; p < m; p += 256) {
+        const int xy = pxy[p], x = xy & 0xffff, y = xy >> 16;
+        bx[atomicAdd(&curx[x], 1)] = p;
+        by[atomicAdd(&cury[y], 1)] = p;
+    }
+    __syncthreads();
+    int dup = 0;
+    for (int p = tid; p < m; p += 256) {
+        const int xy = pxy[p], x = xy & 0xffff, y = xy >> 16;
+        int xr = colstart[x], yr = rowstart[y];
+        for (int k = colstart[x]; k < colstart[x + 1]; k++) {
+            const int q = bx[k], qy = pxy[q] >> 16;
+            xr += qy < y;
+            dup |= (qy == y) & (q != p);
+        }
+        for (int k = rowstart[y]; k < rowstart[y + 1]; k++) yr += (pxy[by[k]] & 0xffff) < x;
+        const unsigned e = (unsigned)xr | (unsigned)yr << 16;
+        lx[xr] = e;
+        ly[yr] = e;
+        byx[xr] = p;
+    }
+    if (__syncthreads_or(dup)) {
+        // coincident points: the survivor depends on Triangle's pivot stream -> host path
+        if (tid == 0) {
+            atomicOr(&S.counts->flags[pair], STG_DUP);
+            S.counts->ntri[slot] = 0;
+        }
+        return;
+    }
+
+    STAMP(9);
+    // ---- alternating-cut order (triangle.cpp:5582-5604): level-synchronous stable partitions.
+    // lx is sorted by x rank, ly by y rank, inside every segment; a cut by axis a takes the lower
+    // half of the a-list and splits the other list the same way, stably.
+    const int chunk = (m + 255) / 256, c0 = tid * chunk, c1 = min(m, c0 + chunk);
+    int depth = 0;
+    for (;; depth++) {
+        const int axis = depth & 1;
+        unsigned* src = axis == 0 ? ly : lx;
+        const unsigned* oth = axis == 0 ? lx : ly;
+        const int sh = axis == 0 ? 0 : 16;      // key of the cut: x rank (low half) or y rank
+        int cnt = 0, split = 0;
+        for (int i = c0; i < c1; i++) {
+            int s, n;
+            dt_segment(m, depth, i, &s, &n);
+            if (n <= 3) continue;
+            split = 1;
+            const unsigned pivot = (oth[s + (n >> 1)] >> sh) & 0xffffu;
+            cnt += ((src[i] >> sh) & 0xffffu) < pivot;
+        }
+        if (!__syncthreads_or(split)) break;
+        int tot;
+        int run = block_excl_scan<256>(cnt, s_scan, &tot);
+        for (int i = c0; i < c1; i++) {
+            int s, n;
+            dt_segment(m, depth, i, &s, &n);
+            unsigned low = 0;
+            if (n > 3) {
+                const unsigned pivot = (oth[s + (n >> 1)] >> sh) & 0xffffu;
+                low = ((src[i] >> sh) & 0xffffu) < pivot;
+            }
+            Pc[i] = (unsigned)run | low << 31;
+            run += (int)low;
+        }
+        __syncthreads();
+        for (int i = c0; i < c1; i++) {
+            int s, n;
+            dt_segment(m, depth, i, &s, &n);
+            int to = i;
+            if (n > 3) {
+                const unsigned pi = Pc[i];
+                const int before = (int)(pi & 0x7fffffffu) - (int)(Pc[s] & 0x7fffffffu);   // lows in [s, i)
+                to = (pi >> 31) ? s + before : s + (n >> 1) + (i - s - before);
+            }
+            tmp[to] = src[i];
+        }
+        __syncthreads();
+        // rotate: the partitioned copy becomes the list
+        if (axis == 0) { unsigned* t = ly; ly = tmp; tmp = t; }
+        else           { unsigned* t = lx; lx = tmp; tmp = t; }
+    }
+    STAMP(10);
+    for (int i = c0; i < c1; i++) {
+        const int p = byx[lx[i] & 0xffffu];
+        order[i] = p;
+        oxy[i] = pxy[p];
+    }
+    // ---- divide and conquer, bottom-up by depth (`depth` is where every node is a leaf), in LDS
+    // when the records of this triangulation fit the block's allocation
+    MeshG mg;
+    mg.ids = S.ids + (size_t)slot * 4 * P.rec_cap;
+    mg.xys = S.xys + (size_t)slot * 4 * P.rec_cap;
+    mg.nbr = S.nbr + (size_t)slot * 4 * P.rec_cap;
+    unsigned* FL = S.fl + (size_t)slot * 2 * P.sup_cap;
+    unsigned* FR = S.fr + (size_t)slot * 2 * P.sup_cap;
+    __syncthreads();   // the histograms are dead: the LDS block is reused for the records
+    if (m <= P.lds_cap) {
+        const int nrec = 2 * m + 2;
+        MeshL ml;
+        ml.ids = reinterpret_cast<unsigned short*>(s_hist);
+        ml.nbr = ml.ids + 3 * nrec;
+        int* vxy = reinterpret_cast<int*>(ml.nbr + 3 * nrec + (nrec & 1));
+        ml.vxy = vxy;
+        for (int p = tid; p < m; p += 256) vxy[p] = pxy[p];
+        dt_build(ml, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0);
+        // corner indices out for k_stage_pack (records 1 .. 2m-2)
+        for (int t = 1 + tid; t < 2 * m - 1; t += 256) {
+            const unsigned a0 = ml.ids[3 * t], a1 = ml.ids[3 * t + 1], a2 = ml.ids[3 * t + 2];
+            *reinterpret_cast<int4*>(mg.ids + 4 * (size_t)t) =
+                make_int4(a0 == 0xffffu ? -1 : (int)a0, a1 == 0xffffu ? -1 : (int)a1, a2 == 0xffffu ? -1 : (int)a2, 0);
+        }
+        __syncthreads();
+    } else {
+        dt_build(mg, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0);
+    }
+    const MeshG& mesh = mg;
+    // ---- surviving records = those without the ghost corner (the hull fan dies,
+    // triangle.cpp:7800-7860); k_stage_pack writes them out in creation order
+    const int nrec = 2 * m - 1;   // records 1 .. 2m-2
+    int live = 0;
+    for (int t = 1 + tid; t < nrec; t += 256) {
+        const int4 v = *reinterpret_cast<const int4*>(mesh.ids + 4 * (size_t)t);
+        live += (v.x >= 0) & (v.y >= 0) & (v.z >= 0);
+    }
+    int tot;
+    block_excl_scan<256>(live, s_scan, &tot);
+    if (tid == 0) S.counts->ntri[slot] = tot;
+    STAMP(30);
+#undef STAMP
+}
+
+// ---------------------------------------------------------------------------
+// Packed lists + group header (what the host used to build and upload).  One block per slot.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stage_pack(StageDev S, DtParams P, int g, GroupHdr* hdr, int32_t* support,
+                                                    int32_t* tri) {
+    __shared__ int s_scan[256 / 64 + 1];
+    const int slot = blockIdx.x, pair = slot >> 1, side = slot & 1, tid = threadIdx.x;
+    // offsets from the counts of all slots (<= 32 values)
+    int sup_off = 0, tri_off = 0, total_sup = 0, total_tri = 0;
+    bool active_me = false;
+    for (int j = 0; j < g; j++) {
+        const bool act = S.counts->nsup[j] >= 3 && !(S.counts->flags[j] & (STG_DUP | STG_OVERFLOW));
+        const int ns = act ? S.counts->nsup[j] : 0;
+        if (j < pair) sup_off += ns;
+        if (j == pair) active_me = act;
+        total_sup += ns;
+        for (int k = 0; k < 2; k++) {
+            const int nt = act ? S.counts->ntri[2 * j + k] : 0;
+            if (2 * j + k < slot) tri_off += nt;
+            total_tri += nt;
+        }
+    }
+    if (slot == 0 && tid == 0) {
+        hdr->npairs = g;
+        int so = 0, te = 0;
+        for (int j = 0; j < g; j++) {
+            const bool act = S.counts->nsup[j] >= 3 && !(S.counts->flags[j] & (STG_DUP | STG_OVERFLOW));
+            hdr->active[j] = act ? 1 : 0;
+            hdr->sup_off[j] = so;
+            so += act ? S.counts->nsup[j] : 0;
+            for (int k = 0; k < 2; k++) {
+                te += act ? S.counts->ntri[2 * j + k] : 0;
+                hdr->tri_end[2 * j + k] = te;
+            }
+        }
+        hdr->sup_off[g] = so;
+        hdr->total_sup = total_sup;
+        hdr->total_tri = total_tri;
+    }
+    if (!active_me) return;
+    const int m = S.counts->nsup[pair];
+    if (side == 0) {
+        const int32_t* src = S.sup_raw + (size_t)pair * 3 * P.sup_cap;
+        int32_t* dst = support + 3 * (size_t)sup_off;
+        for (int i = tid; i < 3 * m; i += 256) dst[i] = src[i];
+    }
+    // ordered compaction of the surviving records: corners (org, dest, apex) of orientation 0
+    const int* ids = S.ids + (size_t)slot * 4 * P.rec_cap;
+    const int nrec = 2 * m - 1;
+    const int chunk = (nrec + 255) / 256, a = max(1, tid * chunk), b = min(nrec, (tid + 1) * chunk);
+    int live = 0;
+    for (int t = a; t < b; t++) {
+        const int4 v = *reinterpret_cast<const int4*>(ids + 4 * (size_t)t);
+        live += (v.x >= 0) & (v.y >= 0) & (v.z >= 0);
+    }
+    int tot;
+    int pos = block_excl_scan<256>(live, s_scan, &tot);
+    int32_t* out = tri + 3 * (size_t)tri_off;
+    for (int t = a; t < b; t++) {
+        const int4 v = *reinterpret_cast<const int4*>(ids + 4 * (size_t)t);
+        if ((v.x >= 0) & (v.y >= 0) & (v.z >= 0)) {
+            out[3 * pos] = v.y;
+            out[3 * pos + 1] = v.z;
+            out[3 * pos + 2] = v.x;
+            pos++;
+        }
+    }
+}
+
+struct Timed {
+    Profiler* p;
+    Timed(const LaunchCtx& cx, const char* name) : p(cx.prof) {
+        if (p) p->begin(name);
+    }
+    ~Timed() {
+        if (p) p->end();
+    }
+};
+
+}  // namespace
+
+// columns the points of a triangulation may use: x + disp_max in [0, W + 2 disp_max] (corner points
+// of addCornerSupportPoints: -d in the right image, W-1+d in the left one)
+static int dt_columns(const svh_elas_params& p, const Dims& d) { return d.W + 2 * std::max(p.disp_max, 0) + 1; }
+static size_t dt_lds_bytes(const svh_elas_params& p, const Dims& d) {
+    return std::max<size_t>(4 * (size_t)(2 * (dt_columns(p, d) + d.H) + 2), 63 * 1024);
+}
+
+bool stage_device_ok(const svh_elas_params& p, const Dims& d) {
+    // LDS of k_delaunay: 2 (columns + rows) + 2 ints; coordinates must stay below 2^14 for the
+    // 64-bit in-circle determinant, ranks are packed in 16 bits
+    const int wx = dt_columns(p, d);
+    return 4 * (size_t)(2 * (wx + d.H) + 2) <= 63 * 1024 && wx < (1 << 14) && d.H < (1 << 14);
+}
+
+void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g, const StageDev& S,
+                         GroupHdr* hdr, int32_t* support, int32_t* tri) {
+    hipStream_t s = (hipStream_t)cx.stream;
+    LatticeParams L;
+    L.W = d.W; L.H = d.H; L.Wc = d.Wc; L.Hc = d.Hc; L.step = d.step;
+    L.ws = p.incon_window_size; L.thr = p.incon_threshold; L.need = p.incon_min_support;
+    L.add_corners = p.add_corners; L.sup_cap = S.sup_cap;
+    const size_t nc = (size_t)d.Wc * d.Hc;
+    const size_t lat_bytes = 2 * ((nc + 1) & ~(size_t)1) + 4 * ((nc + 3) / 4);   // cells + count bytes
+    {
+        Timed t(cx, "k_lattice");
+        if (lat_bytes <= 62 * 1024)
+            hipLaunchKernelGGL(k_lattice<true>, dim3(g), dim3(512), lat_bytes, s, S, L);
+        else
+            hipLaunchKernelGGL(k_lattice<false>, dim3(g), dim3(512), 0, s, S, L);
+    }
+    DtParams D;
+    D.W = dt_columns(p, d); D.H = d.H; D.sup_cap = S.sup_cap; D.rec_cap = S.rec_cap;
+    D.xoff = std::max(p.disp_max, 0);
+    const size_t dt_lds = dt_lds_bytes(p, d);
+    D.lds_cap = (int)std::min<size_t>((dt_lds - 32) / 28 - 1, 8000);   // 16-bit handles: < 8191 points
+    {
+        Timed t(cx, "k_delaunay");
+        hipLaunchKernelGGL(k_delaunay, dim3(2 * g), dim3(256), dt_lds, s, S, D);
+    }
+    {
+        Timed t(cx, "k_stage_pack");
+        hipLaunchKernelGGL(k_stage_pack, dim3(2 * g), dim3(256), 0, s, S, D, g, hdr, support, tri);
+    }
+}
+
+}  // namespace svh

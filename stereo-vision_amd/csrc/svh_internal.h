@@ -27,7 +27,7 @@ Dims make_dims(const svh_elas_params& p, int32_t W, int32_t H);
 // A lane processes a GROUP of up to kMaxGroup independent pairs per kernel
 // launch (blockIdx.z / .y = pair): per-launch work is large enough to fill 256
 // CUs and launch gaps are paid once per group, not once per pair.
-constexpr int kMaxGroup = 16;
+constexpr int kMaxGroup = 32;
 
 // Per-pair header, uploaded with the support points and triangle lists after
 // the host stage.  Triangles of all pairs and both sides are packed in one
@@ -37,6 +37,7 @@ struct GroupHdr {
     int32_t active[kMaxGroup];          // 0: fewer than 3 support points -> outputs untouched
     int32_t sup_off[kMaxGroup + 1];     // support point offsets (points, not ints)
     int32_t tri_end[2 * kMaxGroup];     // cumulative triangle count after (pair, side)
+    int32_t total_sup, total_tri;       // sup_off[npairs], tri_end[2*npairs-1] (device-built headers)
 };
 
 // One rasterisation record per triangle and image side, computed on the device
@@ -76,6 +77,36 @@ void expand_grid(const svh_elas_params& p, const Dims& d, const uint32_t* mask,
 // par_depth > 0: the top `par_depth` levels of the divide-and-conquer run their halves on two
 // threads (2^par_depth threads in all); the output is identical to the sequential run
 int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap, int par_depth = 0);
+
+// ---------------------------------------------------------------- device-side E5-E7
+// The stages between the two matching phases on the GPU (elas_stage_kernels.hip): lattice filters
+// + support list, both Delaunay triangulations, packed lists + header.  Per-lane scratch:
+struct StageCounts {
+    int32_t nsup[kMaxGroup];            // support points per pair (incl. corner points)
+    int32_t ntri[2 * kMaxGroup];        // triangles per (pair, side)
+    int32_t flags[kMaxGroup];           // STG_*
+    int64_t dbg[32];                    // phase time stamps of slot 0 (wall_clock64, 10 ns ticks)
+};
+enum { STG_DUP = 1,        // coincident points in a triangulation: the host path must decide
+       STG_OVERFLOW = 2,   // more support points than the scratch holds / coordinates out of range
+       STG_FEW = 4 };      // fewer than 3 support points (elas.cpp:69-75)
+struct StageDev {
+    int16_t* dcan;          // [g][Wc*Hc] candidate lattice (filtered in place when it does not fit LDS)
+    int32_t* sup_raw;       // [g][3*sup_cap] support list at a fixed stride
+    StageCounts* counts;
+    int32_t* ids;           // [2g][4*rec_cap] triangle records: corner indices,
+    int32_t* xys;           //                  their packed coordinates,
+    uint32_t* nbr;          //                  neighbour handles
+    int32_t *pxy, *buck, *buck2, *byx, *order, *oxy;   // [2g][sup_cap]
+    uint32_t *lx, *ly, *tmp, *P;                        // [2g][sup_cap]
+    uint32_t *fl, *fr;                                  // [2g][2][sup_cap] hull handles per node
+    int32_t* wl;            // [g][3*Wc*Hc] k_lattice: valid cells, two work lists of fresh drops
+    uint32_t* cntw;         // [g][Wc*Hc/4+1] k_lattice count bytes when the lattice does not fit LDS
+    int32_t sup_cap, rec_cap;
+};
+struct LaunchCtx;
+// the image geometry fits the device stage (LDS histograms, 14-bit coordinates)
+bool stage_device_ok(const svh_elas_params& p, const Dims& d);
 
 // ---------------------------------------------------------------- device
 // Kernel launchers (elas_kernels.hip).  LaunchCtx carries the hipStream_t (as
@@ -120,11 +151,18 @@ struct GroupDev {
     int32_t prior_absmax;      // max |P[dd]|, dd <= plane_radius (selects the keyed match kernel)
 };
 
+// k_lattice + k_delaunay + k_stage_pack: from S.dcan to the packed support / triangle lists and
+// the group header in device memory
+void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                         const StageDev& S, GroupHdr* hdr, int32_t* support, int32_t* tri);
+
 void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t g, int32_t W, int32_t H,
                        int32_t half, uint8_t* desc);
 void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                     const uint8_t* desc, int16_t* dcan);
-// planes + raster records + grid bit sets for the whole group
+// planes + raster records + grid bit sets for the whole group.  total_sup / total_tri < 0: the
+// counts are in the device header (device-built), the launch is sized for `tri_bound` triangles
+// and the kernels stride over whatever is there
 void launch_prior(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                   int32_t total_sup, int32_t total_tri, const GroupDev& G);
 void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,

@@ -200,8 +200,20 @@ def set_lanes(n):
 
 
 def set_group(n):
-    """pairs pushed through each kernel launch by one lane (1..16)"""
+    """pairs pushed through each kernel launch by one lane (1..32)"""
     return lib().svh_elas_set_group(n)
+
+
+def set_stage(where):
+    """E5-E7 (lattice filters, support list, Delaunay x2): 1 device, 0 host, -1 automatic"""
+    return lib().svh_elas_set_stage(where)
+
+
+def stage_stats():
+    """(groups through the device stage, groups it handed back to the host path)"""
+    a, b = C.c_int64(0), C.c_int64(0)
+    lib().svh_elas_stage_stats(C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def device_count():

@@ -1,0 +1,146 @@
+"""GPU parity of the device-side stages between the two matching phases (k_lattice, k_delaunay,
+k_stage_pack in csrc/elas_stage_kernels.hip): lattice filters + support list
+(libelas/src/elas.cpp:174-318, 495-523) and the two Delaunay triangulations in Triangle's output
+order (elas.cpp:534-600, triangle.cpp "zQB").
+
+The same stage taps as tests/test_elas_gpu.py -- SUPPORT, TRI1, TRI2 and everything downstream --
+with svh_elas_set_stage(1), against the oracle (whose triangulator is the real Triangle from
+oracle/_ref, or the reference's golden triangle lists) and the reference's goldens; plus the batch
+entry (device stage by default) against the single call (host stage), pair by pair.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from test_elas_gpu import assert_same, oracle_for, product_run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def dev_stage():
+    import svhip as S
+    S.lib()
+    assert S.device_count() > 0, "no HIP device: the product has no CPU fallback"
+    S.set_stage(1)
+    yield S
+    S.set_stage(-1)
+
+
+@pytest.mark.parametrize("case", ["urban3_demo", "urban1_robotics", "urban2_stereomapper", "cones_middlebury"])
+def test_device_stage_on_golden(case, dev_stage, oracle_lib):
+    z = np.load(os.path.join(H.GOLDEN, case + ".npz"))
+    prm = H.ElasParams.from_buffer_copy(z["params"].tobytes())
+    l, r = H.golden_pair(str(z["crop"]))
+    before = dev_stage.stage_stats()
+    got = product_run(dev_stage, prm, l, r)
+    after = dev_stage.stage_stats()
+    assert after[0] == before[0] + 1 and after[1] == before[1]     # device stage, not handed back
+    assert got.status == 0
+    # the reference's own lists first: support points, both triangulations (order included)
+    for s in (H.SUPPORT, H.TRI1, H.TRI2):
+        assert np.array_equal(got[s], z[H.STAGE_NAMES[s]]), H.STAGE_NAMES[s]
+    assert_same(oracle_for(z, prm, l, r), got)
+    assert np.array_equal(got[H.D1_FINAL], z["d1"]) and np.array_equal(got[H.D2_FINAL], z["d2"])
+
+
+@pytest.mark.parametrize("case", ["urban3_kitti", "urban4_kitti"])
+def test_device_stage_on_slim_golden(case, dev_stage):
+    z = np.load(os.path.join(H.GOLDEN, case + ".npz"))
+    prm = H.ElasParams.from_buffer_copy(z["params"].tobytes())
+    l, r = H.golden_pair(str(z["crop"]))
+    got = product_run(dev_stage, prm, l, r)
+    assert got.status == 0
+    for s in (H.SUPPORT, H.TRI1, H.TRI2):
+        assert np.array_equal(got[s], z[H.STAGE_NAMES[s]]), H.STAGE_NAMES[s]
+    assert np.array_equal(got[H.D1_FINAL], z["d1"]) and np.array_equal(got[H.D2_FINAL], z["d2"])
+
+
+@pytest.mark.parametrize("seed,w,h,kw", [
+    (21, 320, 200, {}),
+    (22, 333, 117, {"postprocess_only_left": 0}),
+    (23, 256, 160, {"support_texture": 30, "incon_window_size": 7, "incon_min_support": 7}),
+    (24, 400, 240, {"disp_max": 63, "grid_size": 16, "candidate_stepsize": 4}),
+    (25, 1242, 375, {}),
+    (26, 322, 201, {"subsampling": 1}),
+    (27, 640, 480, {"add_corners": 1, "incon_threshold": 2, "incon_min_support": 3}),
+    (28, 200, 90, {"incon_window_size": 9, "incon_min_support": 12}),      # window > 15 cells wide
+    (29, 96, 64, {}),                                                       # very few support points
+])
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
+def test_device_stage_synthetic(seed, w, h, kw, dev_stage, oracle_lib):
+    l, r = H.synth_pair(w, h, seed, dmax=min(48, kw.get("disp_max", 255) - 8, w // 4))
+    prm = H.robotics(**kw)
+    got = product_run(dev_stage, prm, l, r)
+    want = H.oracle_elas_run(prm, l, r)
+    assert got.status == want.status
+    if want.status == 0:
+        assert_same(want, got)
+
+
+FUZZ_SHAPES = [(320, 200), (401, 177), (512, 160), (288, 240)]
+
+
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref")
+@pytest.mark.parametrize("seed", range(300, 330))
+def test_device_stage_param_fuzz(seed, dev_stage, oracle_lib):
+    """every field of Elas::parameters moves; small candidate steps with a wide L/R threshold
+    produce coincident right-image points, which the device hands back to the host path"""
+    prm = H.fuzz_elas_params(seed)
+    w, h = FUZZ_SHAPES[seed % 4]
+    l, r = H.synth_pair(w, h, seed, dmax=min(48, prm.disp_max - 8))
+    got = product_run(dev_stage, prm, l, r)
+    want = H.oracle_elas_run(prm, l, r)
+    assert got.status == want.status
+    if want.status == 0:
+        assert_same(want, got)
+
+
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref")
+def test_batch_device_stage_equals_single_host_stage(dev_stage, capfd):
+    """svh_elas_process_batch (groups of pairs through the device stage) against
+    svh_elas_process with the host stage, pair by pair; a flat pair in the middle of a group keeps
+    the reference's error behaviour (status 1, message, outputs untouched: elas.cpp:69-75)"""
+    S = dev_stage
+    S.set_stage(-1)     # automatic: the batch takes the device stage, the single call the host
+    w, h = 400, 240
+    pairs = [H.synth_pair(w, h, 700 + i, dmax=40) for i in range(13)]
+    flat = np.full((h, w), 90, np.uint8)
+    pairs[5] = (flat, flat)
+    prm = H.robotics()
+    st, D1, D2 = S.Elas(prm).process_batch(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs]))
+    assert st == [0] * 5 + [1] + [0] * 7
+    assert np.all(D1[5] == 0) and np.all(D2[5] == 0)          # process_batch hands in zeroed maps
+    S.set_stage(0)
+    for i, (l, r) in enumerate(pairs):
+        if i == 5:
+            continue
+        rc, A1, A2 = S.Elas(prm).process(l, r)
+        assert rc == 0
+        assert np.array_equal(A1, D1[i]) and np.array_equal(A2, D2[i]), i
+    out = capfd.readouterr().out
+    assert out.count("Need at least 3 support points") == 1
+
+
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref")
+def test_coincident_points_fall_back_to_host(dev_stage, oracle_lib):
+    """candidate_stepsize 2 with lr_threshold 3: two support points of one row may land on the same
+    right-image pixel; Triangle keeps the one its randomised quicksort puts first.  The device stage
+    flags such pairs and the engine reruns them on the host -- the results still equal the oracle's"""
+    seen = 0
+    for seed in range(40, 46):
+        prm = H.robotics(candidate_stepsize=2, lr_threshold=3, incon_min_support=3, support_threshold=0.95)
+        l, r = H.synth_pair(240, 120, seed, dmax=30, noise=6)
+        want = H.oracle_elas_run(prm, l, r)
+        if want.status != 0:
+            continue
+        sup = want[H.SUPPORT].reshape(-1, 3)
+        key = (sup[:, 0] - sup[:, 2]).astype(np.int64) * 4096 + sup[:, 1]
+        seen += len(np.unique(key)) < len(key)
+        got = product_run(dev_stage, prm, l, r)
+        assert got.status == 0
+        assert_same(want, got)
+    assert seen > 0, "no case with coincident right-image points was generated"
+    assert dev_stage.stage_stats()[1] >= seen     # those pairs did come back from the device
