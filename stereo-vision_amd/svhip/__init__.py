@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libsvhip.so")
+# SVH_LIB: another build of the library (A/B measurements of kernel changes)
+LIB_PATH = os.environ.get("SVH_LIB") or os.path.join(os.path.dirname(_HERE), "libsvhip.so")
 
 OK, ERR_FEW_SUPPORT, ERR_BAD_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = 0, 1, -1, -2, -3, -4
 ROBOTICS, MIDDLEBURY = 0, 1

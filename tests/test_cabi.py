@@ -228,3 +228,19 @@ def test_parallel_delaunay_is_identical(S):
             tri = np.zeros((2 * len(pts) + 16) * 3, np.int32)
             nt = lib.svh_delaunay_mt(H._p(pts), len(pts), H._p(tri), 2 * len(pts) + 16, depth)
             assert nt == len(want) and np.array_equal(tri[:3 * nt].reshape(-1, 3), want), (trial, depth)
+
+
+def test_matrix_call_sites_match_reference():
+    """tests/cxx/matrix_dropin.cpp replays the stereomapper call sites that use Matrix next to
+    the path (stereothread.cpp:303-307, maindialog.cpp:396-406, view3d.cpp:93,
+    planeestimation.cpp:98-117) and every other public member.  Built with only include/ on the
+    path, its output equals -- bit for bit, hex doubles -- that of the same file built against
+    the reference's matrix.h + matrix.cpp (golden: tests/golden/matrix_dropin.txt; live when
+    oracle/_ref holds the reference build)."""
+    subprocess.check_call(["make", "-C", os.path.join(H.ROOT, "tests", "cxx"), "matrix_dropin"],
+                          stdout=subprocess.DEVNULL)
+    ours = subprocess.check_output([os.path.join(H.ROOT, "tests", "cxx", "matrix_dropin")]).decode()
+    assert ours == open(os.path.join(H.GOLDEN, "matrix_dropin.txt")).read()
+    ref = os.path.join(H.ROOT, "oracle", "_ref", "matrix_dropin_ref")
+    if os.path.exists(ref):
+        assert ours == subprocess.check_output([ref]).decode()
