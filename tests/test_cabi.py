@@ -4,6 +4,7 @@ match the oracle / the real Triangle, and it refuses to run without a GPU."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
