@@ -111,6 +111,12 @@ int32_t svh_elas_process_batch_device(svh_elas* e, int32_t n,
                                       float* dD1, float* dD2, size_t out_stride,
                                       const int32_t* dims, int32_t* status);
 
+/* Device buffers, pinned staging, streams and events live in a per-device pool of "lanes" that
+ * outlives the svh_elas handles (callers build an Elas per frame).  svh_elas_trim() releases
+ * every lane that is not in use at the moment -- e.g. after one large batch in a long-lived
+ * process -- and returns how many it released; the pool regrows on demand. */
+int64_t svh_elas_trim(void);
+
 /* number of batch workers the engine runs per device (each is double-buffered: two HIP streams
  * and buffer sets, the host stage of one group overlaps the device stages of the next) */
 int32_t svh_elas_set_lanes(int32_t lanes);

@@ -182,6 +182,24 @@ struct Lane {
         W = H = 0;
     }
 
+    // everything the lane holds, streams and events included (svh_elas_trim)
+    void destroy() {
+        if (!stream) return;
+        (void)hipSetDevice(device);
+        release();
+        for (hipEvent_t* e : {&wait_ev, &match_ev, &copy_ev, &stage_ev})
+            if (*e) {
+                (void)hipEventDestroy(*e);
+                *e = nullptr;
+            }
+        for (hipEvent_t e : prof.ev) (void)hipEventDestroy(e);
+        prof.ev.clear();
+        prof.names.clear();
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        (void)hipStreamDestroy(stream);
+        copy_stream = stream = nullptr;
+    }
+
     int ensure(const svh_elas_params& p, int32_t w, int32_t h, int32_t g) {
         if (!stream) {
             HIP_TRY(hipSetDevice(device));
@@ -900,6 +918,32 @@ int32_t svh_profile_get(int32_t index, const char** name, double* total_ms, int6
         }
     }
     return SVH_ERR_BAD_ARG;
+}
+
+int64_t svh_elas_trim(void) {
+    // lanes that are not borrowed right now give back their device and pinned memory, streams and
+    // events; lanes in use are left alone and the pool regrows on demand
+    int64_t freed = 0;
+    std::vector<Pool*> pools;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto& kv : g_pools) pools.push_back(kv.second);
+    }
+    for (Pool* p : pools) {
+        std::vector<Lane*> idle;
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            idle.swap(p->free_list);
+            for (Lane* l : idle) p->lanes.erase(std::find(p->lanes.begin(), p->lanes.end(), l));
+        }
+        for (Lane* l : idle) {
+            l->destroy();
+            delete l;
+            freed++;
+        }
+        p->cv.notify_all();
+    }
+    return freed;
 }
 
 int32_t svh_elas_set_lanes(int32_t lanes) {

@@ -1634,13 +1634,18 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     // rows up to 1920 px (77 KB with the raw-disparity rows) still take the keyed kernel: two blocks
     // per CU, measured 2-5 % ahead of the ordered fallback on 1920x1080 since the kernel got leaner
     constexpr size_t keyed_lds_max = 96 * 1024;
-    if (keyed_ok && lds2 <= keyed_lds_max) {
-        if (lds2 > 64 * 1024) {   // opt in on whichever device is current (a few us, wide rows only)
-            (void)hipFuncSetAttribute((const void*)k_match_keyed<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)keyed_lds_max);
-            (void)hipFuncSetAttribute((const void*)k_match_keyed<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)keyed_lds_max);
-        }
+    constexpr size_t kStaticLds = 64 * sizeof(int);   // s_P of both match kernels counts against the limit
+    bool use_keyed = keyed_ok && lds2 + kStaticLds <= keyed_lds_max;
+    if (use_keyed && lds2 + kStaticLds > 64 * 1024) {
+        // opt in on whichever device is current (a few us, wide rows only); a refusal sends the
+        // launch down the ordered path instead of failing later as a launch error
+        use_keyed = hipFuncSetAttribute((const void*)k_match_keyed<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)keyed_lds_max) == hipSuccess &&
+                    hipFuncSetAttribute((const void*)k_match_keyed<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)keyed_lds_max) == hipSuccess;
+        if (!use_keyed) (void)hipGetLastError();
+    }
+    if (use_keyed) {
         Timed timed_(cx, "k_match");
         // threads per map and row block: the row is covered in `iters` equal passes with little idle tail
         static const int mt = getenv("SVH_MATCH_THREADS") ? atoi(getenv("SVH_MATCH_THREADS")) : 256;
@@ -1655,7 +1660,7 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
         }
         DevMaps none{};
         hipLaunchKernelGGL(k_match_keyed<false>, grid, block, lds2, s, G, P, none, 1, 0.f);
-    } else if (lds <= 64 * 1024) {
+    } else if (lds + kStaticLds <= 64 * 1024) {
         Timed timed_(cx, "k_match");
         static const int mt = getenv("SVH_MATCH_THREADS") ? atoi(getenv("SVH_MATCH_THREADS")) : 256;
         const int iters = (d.DW + mt - 1) / mt;

@@ -117,6 +117,8 @@ int32_t png_decode(const std::vector<uint8_t>& file, PngInfo& info, std::vector<
         default: return SVH_ERR_UNSUPPORTED;   // palette
     }
     if (info.depth != 8 && info.depth != 16) return SVH_ERR_UNSUPPORTED;
+    // a corrupt or crafted header must not size the buffers: 2^28 pixels is far beyond any camera frame
+    if ((uint64_t)info.w * (uint64_t)info.h > (1ull << 28)) return SVH_ERR_BAD_ARG;
     const size_t bpp = (size_t)info.channels * info.depth / 8, stride = bpp * info.w;
     std::vector<uint8_t> flat((stride + 1) * info.h);
     uLongf got = (uLongf)flat.size();
@@ -176,6 +178,7 @@ struct svh_kitti_seq {
 extern "C" {
 
 int32_t svh_kitti_read_cam_to_cam(const char* path, svh_kitti_calib* out) {
+    try {
     if (!path || !out) return SVH_ERR_BAD_ARG;
     std::vector<std::string> lines;
     if (!read_lines(path, lines)) return SVH_ERR_BAD_ARG;
@@ -205,9 +208,13 @@ int32_t svh_kitti_read_cam_to_cam(const char* path, svh_kitti_calib* out) {
     out->cv = out->P_rect[0][6];
     out->base = -out->P_rect[1][3] / out->P_rect[1][0];
     return SVH_OK;
+    } catch (...) {   // std::bad_alloc etc. must not cross the C boundary
+        return SVH_ERR_BAD_ARG;
+    }
 }
 
 int32_t svh_png_read_gray(const char* path, uint8_t* buf, size_t cap, int32_t* width, int32_t* height) {
+    try {
     if (!path || !width || !height) return SVH_ERR_BAD_ARG;
     std::vector<uint8_t> file, raw;
     if (!read_file(path, file)) return SVH_ERR_BAD_ARG;
@@ -230,9 +237,13 @@ int32_t svh_png_read_gray(const char* path, uint8_t* buf, size_t cap, int32_t* w
         }
     }
     return SVH_OK;
+    } catch (...) {   // std::bad_alloc etc. must not cross the C boundary
+        return SVH_ERR_BAD_ARG;
+    }
 }
 
 svh_kitti_seq* svh_kitti_seq_open(const char* drive_dir) {
+    try {
     if (!drive_dir) return nullptr;
     svh_kitti_seq* s = new svh_kitti_seq();
     for (int k = 0; k < 2; k++) {
@@ -254,6 +265,9 @@ svh_kitti_seq* svh_kitti_seq_open(const char* drive_dir) {
         return nullptr;
     }
     return s;
+    } catch (...) {   // std::bad_alloc etc. must not cross the C boundary
+        return nullptr;
+    }
 }
 
 void svh_kitti_seq_close(svh_kitti_seq* s) { delete s; }
@@ -267,6 +281,7 @@ int32_t svh_kitti_seq_seek(svh_kitti_seq* s, int32_t frame) {
 }
 
 int32_t svh_kitti_seq_next(svh_kitti_seq* s, uint8_t* I1, uint8_t* I2, size_t cap, int32_t* dims, int64_t* tv) {
+    try {
     if (!s || !I1 || !I2 || !dims) return SVH_ERR_BAD_ARG;
     if (s->next >= (int32_t)s->stamps[0].size()) return 1;
     const int32_t idx = s->next++;
@@ -289,6 +304,9 @@ int32_t svh_kitti_seq_next(svh_kitti_seq* s, uint8_t* I1, uint8_t* I2, size_t ca
     dims[1] = h[0];
     dims[2] = w[0];
     return SVH_OK;
+    } catch (...) {   // std::bad_alloc etc. must not cross the C boundary
+        return SVH_ERR_BAD_ARG;
+    }
 }
 
 }  // extern "C"

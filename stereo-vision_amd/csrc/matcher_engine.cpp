@@ -212,7 +212,9 @@ static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* 
     double tf[6] = {0, 0, 0, 0, 0, 0};
     auto ftick = [&](int i) { if (g_mtiming) tf[i] = mnow_ms(); };
     ftick(0);
-    V.host.resize(fn);
+    // one zero row past the image: getGain clamps its window to [0,H] INCLUSIVE like the
+    // reference (matcher.cpp:362-371), whose read of row H is out of bounds; here it reads zeros
+    V.host.assign(fn + V.bpl, 0);
     for (int32_t v = 0; v < V.h; v++) {
         uint8_t* row = stage + (size_t)v * V.bpl;
         memcpy(row, src + (size_t)v * pitch, V.w);
@@ -701,11 +703,14 @@ float svh_matcher_get_gain(svh_matcher* m, const int32_t* inliers, int32_t n) {
     for (int32_t q = 0; q < n; q++) {
         if (inliers[q] >= (int32_t)m->m2.size()) continue;
         const svh_p_match& it = m->m2[inliers[q]];
-        const int32_t W = m->dims_p[0], H = m->dims_p[1];
+        // (the reference clamps both windows with dims_p; the views here are indexed by their
+        // own geometry, so the bound of a view is never exceeded when the two frames differ)
+        const int32_t W = std::min(m->dims_p[0], m->prev[0].bpl - 1), H = std::min(m->dims_p[1], m->prev[0].h);
+        const int32_t Wc = std::min(m->dims_p[0], m->cur[0].bpl - 1), Hc = std::min(m->dims_p[1], m->cur[0].h);
         const float mp = meanf(m->prev[0], cl((int32_t)it.u1p - 3, W), cl((int32_t)it.u1p + 3, W),
                                cl((int32_t)it.v1p - 3, H), cl((int32_t)it.v1p + 3, H));
-        const float mc = meanf(m->cur[0], cl((int32_t)it.u1c - 3, W), cl((int32_t)it.u1c + 3, W),
-                               cl((int32_t)it.v1c - 3, H), cl((int32_t)it.v1c + 3, H));
+        const float mc = meanf(m->cur[0], cl((int32_t)it.u1c - 3, Wc), cl((int32_t)it.u1c + 3, Wc),
+                               cl((int32_t)it.v1c - 3, Hc), cl((int32_t)it.v1c + 3, Hc));
         if (mp > 10) {
             gain += mc / mp;
             num++;

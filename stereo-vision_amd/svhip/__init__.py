@@ -129,15 +129,23 @@ class Elas:
         I1 = np.asarray(I1, np.uint8)
         I2 = np.asarray(I2, np.uint8)
         assert I1.shape == I2.shape and I1.ndim == 2
-        if I1.strides[1] != 1 or I2.strides != I1.strides:
+        h, w = I1.shape
+        # dims[2] is a forward pitch >= width: anything else (reversed / broadcast / column views)
+        # is copied first
+        if I1.strides[1] != 1 or I2.strides != I1.strides or I1.strides[0] < w:
             I1 = np.ascontiguousarray(I1)
             I2 = np.ascontiguousarray(I2)
-        h, w = I1.shape
         dims = (C.c_int32 * 3)(w, h, I1.strides[0])
         if D1 is None:
             D1 = np.zeros(self._dshape(h, w), np.float32)
         if D2 is None:
             D2 = np.zeros(self._dshape(h, w), np.float32)
+        for name, D in (("D1", D1), ("D2", D2)):
+            # the library writes h*w packed float32 through the raw pointer
+            if not (isinstance(D, np.ndarray) and D.dtype == np.float32 and D.flags.c_contiguous
+                    and D.flags.writeable and D.shape == self._dshape(h, w)):
+                raise ValueError("%s must be a writable C-contiguous float32 array of shape %s"
+                                 % (name, (self._dshape(h, w),)))
         rc = lib().svh_elas_process(self._h, I1.ctypes.data, I2.ctypes.data, D1.ctypes.data,
                                     D2.ctypes.data, dims)
         if rc < 0:
@@ -208,6 +216,12 @@ def set_group(n):
 def set_stage(where):
     """E5-E7 (lattice filters, support list, Delaunay x2): 1 device, 0 host, -1 automatic"""
     return lib().svh_elas_set_stage(where)
+
+
+def trim():
+    """release the pooled lanes that are idle (device + pinned memory, streams); returns the count"""
+    lib().svh_elas_trim.restype = C.c_int64
+    return lib().svh_elas_trim()
 
 
 def stage_stats():

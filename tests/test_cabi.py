@@ -245,3 +245,17 @@ def test_matrix_call_sites_match_reference():
     ref = os.path.join(H.ROOT, "oracle", "_ref", "matrix_dropin_ref")
     if os.path.exists(ref):
         assert ours == subprocess.check_output([ref]).decode()
+
+
+def test_python_binding_validates_output_arrays():
+    """Elas.process hands raw pointers to the library: wrong dtype / shape / layout of D1, D2 is
+    refused before the call instead of corrupting the heap"""
+    import svhip
+    e = svhip.Elas(H.robotics())
+    I = np.zeros((40, 64), np.uint8)
+    for bad in (np.zeros((40, 64), np.float64), np.zeros((40, 63), np.float32),
+                np.zeros((40, 128), np.float32)[:, ::2], np.zeros((64, 40), np.float32).T):
+        with pytest.raises(ValueError):
+            e.process(I, I, bad, np.zeros((40, 64), np.float32))
+        with pytest.raises(ValueError):
+            e.process(I, I, np.zeros((40, 64), np.float32), bad)

@@ -104,6 +104,21 @@ def test_stages_match_oracle_synthetic(seed, w, h, kw, svhip, oracle_lib):
     assert_same(want, got)
 
 
+@pytest.mark.parametrize("w,h", [(1636, 48), (1920, 40), (4096, 36)])
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
+def test_row_widths_at_the_lds_limits(w, h, svhip, oracle_lib):
+    """launch_match picks its kernel by the LDS a row needs: 40 B per pixel cross 64 KB (the opt-in
+    threshold, static s_P included) at W = 1633..1638, 1920 takes the opt-in, and 16 B per pixel of
+    the ordered kernel reach 64 KB at W = 4096 (global-memory fallback)"""
+    l, r = H.synth_pair(w, h, 77, dmax=40)
+    prm = H.robotics()
+    got = product_run(svhip, prm, l, r)
+    want = H.oracle_elas_run(prm, l, r)
+    assert got.status == want.status
+    if want.status == 0:
+        assert_same(want, got)
+
+
 @pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref")
 def test_matches_reference_process(svhip):
     """the real reference's Elas::process on the same input"""

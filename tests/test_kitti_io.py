@@ -247,3 +247,17 @@ def test_sharded_load_covers_the_drive_once(K, tmp_path):
             assert np.array_equal(a[i], imgs[0][lo + i]) and np.array_equal(b[i], imgs[1][lo + i])
             seen.append(lo + i)
     assert seen == list(range(7))
+
+
+def test_png_with_absurd_header_is_refused(K, tmp_path):
+    """IHDR dimensions are not trusted: a crafted 2^31-1 x 2^31-1 header returns an error code
+    (no allocation of that size, no exception across the C boundary)"""
+    S = __import__("svhip")
+    for w, h in ((0x7fffffff, 0x7fffffff), (1 << 20, 1 << 20), (70000, 70000)):
+        png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) + \
+            chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+        path = str(tmp_path / "huge.png")
+        open(path, "wb").write(png)
+        with pytest.raises(S.SvhError) as ei:
+            K.read_png_gray(path)
+        assert ei.value.code == S.ERR_BAD_ARG

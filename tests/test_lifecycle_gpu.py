@@ -51,3 +51,32 @@ def test_create_destroy_cycles_do_not_leak():
         cycle()
     after = free_bytes()
     assert before - after < 8 << 20, "device memory shrank by %.1f MB over 25 cycles" % ((before - after) / 2**20)
+
+
+@pytest.mark.gpu
+def test_trim_releases_the_idle_lanes():
+    """svh_elas_trim(): a long-lived process gets the lane pool's memory back after a large batch
+    (each lane holds device buffers for a whole group of pairs plus pinned staging)"""
+    import svhip as S
+    w, h = 640, 240
+    l, r = H.golden_pair("urban3_640x240")
+    e = S.Elas(H.robotics())
+    n = 48
+    S.set_lanes(6)
+    S.set_group(4)
+    try:
+        e.process_batch(np.stack([l] * n), np.stack([r] * n))     # warm: code objects, runtime pools
+        S.trim()
+        base = free_bytes()
+        st, A1, A2 = e.process_batch(np.stack([l] * n), np.stack([r] * n))
+        assert st == [0] * n
+        held = base - free_bytes()
+        assert held > 64 << 20                       # the pool keeps its lanes ...
+        assert S.trim() >= 6                         # ... until it is told to let go
+        assert base - free_bytes() < held // 8
+        st, B1, B2 = e.process_batch(np.stack([l] * 4), np.stack([r] * 4))   # and regrows on demand
+        assert st == [0] * 4 and np.array_equal(A1[0], B1[0]) and np.array_equal(A2[3], B2[3])
+    finally:
+        S.set_lanes(8)
+        S.set_group(16)
+        S.trim()
