@@ -407,6 +407,12 @@ def main():
         # (k_lattice, k_delaunay) are latency-bound single-workgroup jobs -- 32 pairs share one launch
         args.group = 1 if args.workload == "hd1080" else 32
 
+    # The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4)
+    # and kernels of one hardware queue run one after the other: with the latency-bound stage
+    # kernels (k_delaunay: one workgroup per triangulation, ~1 ms) sharing queues with the
+    # streaming kernels, 8 queues measured +4 % pairs/s; more than 8 did not help.  Must be set
+    # before the runtime starts; an explicit setting of the caller wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
 
@@ -447,8 +453,10 @@ def main():
     # core keeps the cores busy with the host stage
     avail = _cpu_quota() or (os.cpu_count() or 8)
     cores_per_rank = avail / max(world, 1)
-    # (with the device stage the workers only enqueue and sleep: 12 keep 24 streams busy)
-    lanes = args.lanes or int(max(2, min(12 if args.stage != "host" else 24, round(1.5 * cores_per_rank))))
+    # (with the device stage the workers only enqueue and sleep: 6 of them, 12 streams, already
+    # saturate the device; more only stretches every kernel's in-run duration)
+    dev_stage = args.stage != "host" and args.workload != "hd1080"
+    lanes = args.lanes or int(max(2, min(6 if dev_stage else 24, round(1.5 * cores_per_rank))))
     S.set_lanes(lanes)
     group = S.set_group(args.group)
 
@@ -675,6 +683,7 @@ def main():
                        "host_cpu_quota": _cpu_quota(), "host_cores_per_rank": round(cores_per_rank, 2),
                        "dist_backend": args.dist_backend if world > 1 else None,
                        "gpus_visible": ndev, "build": build, "stage": args.stage,
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "stage_groups_device_handed_back": list(S.stage_stats()),
                        "d1_valid_fraction": round(valid, 4)},
             "ranks": ranks,

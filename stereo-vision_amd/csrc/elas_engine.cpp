@@ -690,7 +690,8 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         launch_descriptor(cx, img, g, W, H, p.subsampling, L.desc);
         launch_support(cx, p, d, g, L.desc, L.dcan);
         const int sm = g_stage_mode.load();
-        L.resident = !L.force_host && L.stage_ok && (sm == 1 || (sm < 0 && prefer_device));
+        L.resident = !L.force_host && L.stage_ok &&
+                     (sm == 1 || (sm < 0 && prefer_device && stage_device_preferred(p, d)));
         if (!L.resident || tapping)
             HIP_TRY(hipMemcpyAsync(L.h_dcan, L.dcan, g * nc * sizeof(int16_t), hipMemcpyDeviceToHost, s));
         if (L.resident) {

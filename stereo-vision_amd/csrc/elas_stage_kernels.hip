@@ -581,7 +581,19 @@ __device__ void dt_merge(const M& m, unsigned* farleft, unsigned innerleft, unsi
 
     Vtx lowerleft = il_dest, lowerright = ir_org;
     Vtx upperleft = apex(m, lcand), upperright = apex(m, rcand);
+    // The walk is a chain of dependent loads (handle -> neighbour handle -> its apex -> its
+    // coordinates).  The triangle behind each candidate edge (nx*, its apex nap*) is therefore
+    // fetched for BOTH sides at once and kept while that side stands still: the two hulls are
+    // disjoint records, and a new seam edge on one side touches nothing the other side has cached.
+    unsigned nxL = 0, nxR = 0;
+    Vtx napL = kGhost, napR = kGhost;
+    bool haveL = false, haveR = false;
     for (;;) {
+        if (!haveL) nxL = sym(m, hprev(lcand));
+        if (!haveR) nxR = sym(m, hnext(rcand));
+        if (!haveL) napL = apex(m, nxL);
+        if (!haveR) napR = apex(m, nxR);
+        haveL = haveR = true;
         const bool leftdone = ccw(upperleft, lowerleft, lowerright) <= 0;
         const bool rightdone = ccw(upperright, lowerleft, lowerright) <= 0;
         if (leftdone && rightdone) {
@@ -613,63 +625,55 @@ __device__ void dt_merge(const M& m, unsigned* farleft, unsigned innerleft, unsi
             }
             return;
         }
-        if (!leftdone) {
+        if (!leftdone && napL.id >= 0) {
             // strip left-side edges that fail the in-circle test (flips in place)
-            unsigned nx = sym(m, hprev(lcand));
-            Vtx nap = apex(m, nx);
-            if (nap.id >= 0) {
-                bool bad = incircle(lowerleft, lowerright, upperleft, nap) > 0;
-                while (bad) {
-                    nx = hnext(nx);
-                    const unsigned topc = sym(m, nx);
-                    nx = hnext(nx);
-                    const unsigned sidec = sym(m, nx);
-                    bond(m, nx, topc);
-                    bond(m, lcand, sidec);
-                    lcand = hnext(lcand);
-                    const unsigned outerc = sym(m, lcand);
-                    nx = hprev(nx);
-                    bond(m, nx, outerc);
-                    set_org(m, lcand, lowerleft);
-                    set_dest(m, lcand, kGhost);
-                    set_apex(m, lcand, nap);
-                    set_org(m, nx, kGhost);
-                    set_dest(m, nx, upperleft);
-                    set_apex(m, nx, nap);
-                    upperleft = nap;
-                    nx = sidec;
-                    nap = apex(m, nx);
-                    bad = nap.id >= 0 && incircle(lowerleft, lowerright, upperleft, nap) > 0;
-                }
+            bool bad = incircle(lowerleft, lowerright, upperleft, napL) > 0;
+            while (bad) {
+                unsigned nx = hnext(nxL);
+                const unsigned topc = sym(m, nx);
+                nx = hnext(nx);
+                const unsigned sidec = sym(m, nx);
+                bond(m, nx, topc);
+                bond(m, lcand, sidec);
+                lcand = hnext(lcand);
+                const unsigned outerc = sym(m, lcand);   // (after the bonds: tiny hulls share several edges)
+                nx = hprev(nx);
+                bond(m, nx, outerc);
+                set_org(m, lcand, lowerleft);
+                set_dest(m, lcand, kGhost);
+                set_apex(m, lcand, napL);
+                set_org(m, nx, kGhost);
+                set_dest(m, nx, upperleft);
+                set_apex(m, nx, napL);
+                upperleft = napL;
+                nxL = sidec;
+                napL = apex(m, nxL);
+                bad = napL.id >= 0 && incircle(lowerleft, lowerright, upperleft, napL) > 0;
             }
         }
-        if (!rightdone) {
-            unsigned nx = sym(m, hnext(rcand));
-            Vtx nap = apex(m, nx);
-            if (nap.id >= 0) {
-                bool bad = incircle(lowerleft, lowerright, upperright, nap) > 0;
-                while (bad) {
-                    nx = hprev(nx);
-                    const unsigned topc = sym(m, nx);
-                    nx = hprev(nx);
-                    const unsigned sidec = sym(m, nx);
-                    bond(m, nx, topc);
-                    bond(m, rcand, sidec);
-                    rcand = hprev(rcand);
-                    const unsigned outerc = sym(m, rcand);
-                    nx = hnext(nx);
-                    bond(m, nx, outerc);
-                    set_org(m, rcand, kGhost);
-                    set_dest(m, rcand, lowerright);
-                    set_apex(m, rcand, nap);
-                    set_org(m, nx, upperright);
-                    set_dest(m, nx, kGhost);
-                    set_apex(m, nx, nap);
-                    upperright = nap;
-                    nx = sidec;
-                    nap = apex(m, nx);
-                    bad = nap.id >= 0 && incircle(lowerleft, lowerright, upperright, nap) > 0;
-                }
+        if (!rightdone && napR.id >= 0) {
+            bool bad = incircle(lowerleft, lowerright, upperright, napR) > 0;
+            while (bad) {
+                unsigned nx = hprev(nxR);
+                const unsigned topc = sym(m, nx);
+                nx = hprev(nx);
+                const unsigned sidec = sym(m, nx);
+                bond(m, nx, topc);
+                bond(m, rcand, sidec);
+                rcand = hprev(rcand);
+                const unsigned outerc = sym(m, rcand);
+                nx = hnext(nx);
+                bond(m, nx, outerc);
+                set_org(m, rcand, kGhost);
+                set_dest(m, rcand, lowerright);
+                set_apex(m, rcand, napR);
+                set_org(m, nx, upperright);
+                set_dest(m, nx, kGhost);
+                set_apex(m, nx, napR);
+                upperright = napR;
+                nxR = sidec;
+                napR = apex(m, nxR);
+                bad = napR.id >= 0 && incircle(lowerleft, lowerright, upperright, napR) > 0;
             }
         }
         if (leftdone || (!rightdone && incircle(upperleft, lowerleft, lowerright, upperright) > 0)) {
@@ -680,6 +684,7 @@ __device__ void dt_merge(const M& m, unsigned* farleft, unsigned innerleft, unsi
             lowerright = upperright;
             rcand = sym(m, base);
             upperright = apex(m, rcand);
+            haveR = false;
         } else {
             // new edge upperleft -> lowerright (also on a co-circular tie)
             bond(m, base, lcand);
@@ -688,6 +693,7 @@ __device__ void dt_merge(const M& m, unsigned* farleft, unsigned innerleft, unsi
             lowerleft = upperleft;
             lcand = sym(m, base);
             upperleft = apex(m, lcand);
+            haveL = false;
         }
     }
 }
@@ -1057,6 +1063,14 @@ bool stage_device_ok(const svh_elas_params& p, const Dims& d) {
     // 64-bit in-circle determinant, ranks are packed in 16 bits
     const int wx = dt_columns(p, d);
     return 4 * (size_t)(2 * (wx + d.H) + 2) <= 63 * 1024 && wx < (1 << 14) && d.H < (1 << 14);
+}
+
+// automatic mode takes the device stage only where it is the faster one: lattices that k_lattice
+// holds in LDS (up to ~20 k cells: KITTI-size images).  On 1920x1080 pairs (83 k cells, 5-8 k
+// support points: records in L2 instead of LDS) the two host threads per pair are still ahead.
+bool stage_device_preferred(const svh_elas_params& p, const Dims& d) {
+    const size_t nc = (size_t)d.Wc * d.Hc;
+    return stage_device_ok(p, d) && 2 * ((nc + 1) & ~(size_t)1) + 4 * ((nc + 3) / 4) <= 62 * 1024;
 }
 
 void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g, const StageDev& S,

@@ -107,6 +107,8 @@ struct StageDev {
 struct LaunchCtx;
 // the image geometry fits the device stage (LDS histograms, 14-bit coordinates)
 bool stage_device_ok(const svh_elas_params& p, const Dims& d);
+// ... and it is expected to beat the host stage there (what automatic mode asks)
+bool stage_device_preferred(const svh_elas_params& p, const Dims& d);
 
 // ---------------------------------------------------------------- device
 // Kernel launchers (elas_kernels.hip).  LaunchCtx carries the hipStream_t (as
