@@ -406,24 +406,48 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
     // half of its neighbour; support_match_rows assigns the disparities of a trip to the lanes of a
     // row so that lane position p always reads a slot congruent to p modulo 16, in the forward and
     // in the backward search alike: every phase covers the 16 slots of the bank array once.
-    static_assert(kST / kWave == 8, "rows of a wave take candidates 8 apart");
+    static_assert(kST / kWave == 8 && kSB == 32, "one row of 16 lanes per candidate, 8 waves");
     const int grp = lane >> 4;
     const int gl = lane & 15;
-    for (int c0 = wave; c0 < ncand; c0 += 4 * (kST / kWave)) {
-        const int c = c0 + grp * (kST / kWave);
+    // forward search: every candidate of the block (row 4*wave' .. of the block's 32 rows)
+    __shared__ int16_t s_fwd[kSB];     // forward disparity per candidate, -1 = none
+    __shared__ uint8_t s_todo[kSB];    // candidates that need the backward search, compacted
+    __shared__ int s_ntodo;
+    {
+        const int c = wave + grp * (kST / kWave);
         const bool have = c < ncand;
         const int uc = uc0 + (have ? c : 0), u = uc * P.step;
-        const bool act = have && uc > 0;
-        const bool in = act && u >= 5 && u <= P.W - 6;
+        const bool in = have && uc > 0 && u >= 5 && u <= P.W - 6;
         const uint4 c1 = in ? d1[(size_t)v * P.W + u] : make_uint4(0, 0, 0, 0);
         const int d = support_match_rows(L, R, c1, u, false, in, P, gl);
-        const bool fwd = d >= 0;
-        const int ub = fwd ? u - d : 5;   // >= 5 because d <= u-5
-        const uint4 c2 = fwd ? d2[(size_t)v * P.W + ub] : make_uint4(0, 0, 0, 0);
-        const int dd = support_match_rows(R, L, c2, ub, true, fwd, P, gl);
+        if (gl == 0 && c < kSB) s_fwd[c] = (int16_t)(have ? d : -1);
+    }
+    __syncthreads();
+    // Only the candidates whose forward search produced a disparity (about half of them) are
+    // searched backwards.  They are compacted first, so that the backward searches fill whole
+    // waves and the remaining waves retire instead of idling through the trips of their neighbours.
+    if (wave == 0) {
+        const int mine = lane < kSB ? (int)s_fwd[lane] : -1;
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(mine >= 0);
+        if (mine >= 0) s_todo[__builtin_popcountll(mask & ((1ull << lane) - 1))] = (uint8_t)lane;
+        if (lane == 0) s_ntodo = __builtin_popcountll(mask);
+        // everything else is settled now: column 0 stays at calloc's 0, no forward match -> -1
+        if (lane < ncand && mine < 0) dcan[lane] = (int16_t)((uc0 + lane) > 0 ? -1 : 0);
+    }
+    __syncthreads();
+    const int ntodo = s_ntodo;
+    if (4 * wave >= ntodo) return;
+    {
+        const int t = 4 * wave + grp;
+        const bool have = t < ntodo;
+        const int c = have ? (int)s_todo[t] : 0;
+        const int d = have ? (int)s_fwd[c] : 0;
+        const int uc = uc0 + c, u = uc * P.step;
+        const int ub = have ? u - d : 5;   // >= 5 because d <= u-5
+        const uint4 c2 = have ? d2[(size_t)v * P.W + ub] : make_uint4(0, 0, 0, 0);
+        const int dd = support_match_rows(R, L, c2, ub, true, have, P, gl);
         const int diff = d > dd ? d - dd : dd - d;
-        // column 0 stays at calloc's 0
-        const int out = uc > 0 ? ((fwd && dd >= 0 && diff <= P.lr_threshold) ? d : -1) : 0;
+        const int out = (dd >= 0 && diff <= P.lr_threshold) ? d : -1;
         if (have && gl == 0) dcan[c] = (int16_t)out;
     }
 }
