@@ -101,8 +101,16 @@ __device__ __forceinline__ void lattice_consistency_events(int16_t* val, uint32_
     if (tid < 3) s_n[tid] = 0;
     for (int i = tid; i < (nc + 3) / 4; i += 512) cntw[i] = 0;
     __syncthreads();
-    for (int i = tid; i < nc; i += 512)
-        if (val[i] >= 0) alive[atomicAdd(&s_n[0], 1)] = i;
+    // (one LDS atomic per wave, not per lane: lanes of a wave append behind a common base)
+    for (int i0 = 0; i0 < nc; i0 += 512) {
+        const int i = i0 + tid;
+        const bool on = i < nc && val[i] >= 0;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(on);
+        int base = 0;
+        if ((tid & 63) == 0 && m) base = atomicAdd(&s_n[0], __builtin_popcountll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (on) alive[base + __builtin_popcountll(m & ((1ull << (tid & 63)) - 1))] = i;
+    }
     __syncthreads();
     const int nalive = s_n[0];
     for (int k = tid; k < nalive; k += 512) {

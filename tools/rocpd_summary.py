@@ -33,6 +33,28 @@ def main(path):
             cur_e = e
     if cur_e is not None:
         busy += cur_e - cur_s
+    # steady state: the same sweep over the middle of the run only (from the 30th to the 95th
+    # percentile of the library's own kernel launches -- before that the lanes are still being
+    # allocated and warmed, after it the pipeline drains)
+    lib = db.execute("select start, end from kernels where name like '%k\\_%' escape '\\' order by start").fetchall()
+    if len(lib) > 100:
+        t0, t1 = lib[int(0.30 * len(lib))][0], lib[int(0.95 * len(lib))][0]
+        b2, cs, ce, tot2 = 0, None, None, 0
+        for s_, e_ in iv:
+            s2, e2 = max(s_, t0), min(e_, t1)
+            if e2 <= s2:
+                continue
+            tot2 += e2 - s2
+            if ce is None or s2 > ce:
+                if ce is not None:
+                    b2 += ce - cs
+                cs, ce = s2, e2
+            elif e2 > ce:
+                ce = e2
+        if ce is not None:
+            b2 += ce - cs
+        print("\nsteady state (%.1f ms window inside the run): some kernel running during %.1f %% of it, "
+              "%.2f kernels in flight on average" % ((t1 - t0) / 1e6, 100.0 * b2 / (t1 - t0), tot2 / (t1 - t0)))
     span = db.execute("select min(start), max(end) from kernels").fetchone()
     if span and span[0] is not None:
         print("\nkernel time %.3f ms over a %.3f ms span (sum/span = %.2f: >1 means kernels from "
