@@ -673,17 +673,36 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
             img.I[0] = io.dI[0]; img.I[1] = io.dI[1];
             img.stride = io.in_stride; img.pitch = io.pitch;
         } else {
-            // the callers' rows (any stride, pageable) are packed into pinned staging
-            // on the host, then the whole group goes up in one linear DMA
-            for (int32_t j = 0; j < g; j++)
-                for (int k = 0; k < 2; k++) {
-                    uint8_t* dst = L.h_img + ((size_t)2 * j + k) * N;
-                    const uint8_t* src = io.hI[k][j];
-                    if (io.pitch == W) memcpy(dst, src, N);
-                    else
-                        for (int32_t v = 0; v < H; v++) memcpy(dst + (size_t)v * W, src + (size_t)v * io.pitch, W);
+            // Images in pinned (page-locked) host memory go up straight from the caller's buffers,
+            // one DMA per image.  Pageable rows (any stride) are packed into the lane's pinned
+            // staging on the host first, then the whole group goes up in one linear DMA.
+            bool pinned = true;
+            for (int32_t j = 0; j < g && pinned; j++)
+                for (int k = 0; k < 2 && pinned; k++) {
+                    hipPointerAttribute_t at;
+                    pinned = hipPointerGetAttributes(&at, io.hI[k][j]) == hipSuccess && at.type == hipMemoryTypeHost;
                 }
-            HIP_TRY(hipMemcpyAsync(L.img, L.h_img, (size_t)2 * g * N, hipMemcpyHostToDevice, s));
+            (void)hipGetLastError();   // a pageable pointer makes the query fail: not an error here
+            if (pinned) {
+                for (int32_t j = 0; j < g; j++)
+                    for (int k = 0; k < 2; k++) {
+                        uint8_t* dst = L.img + ((size_t)2 * j + k) * N;
+                        if (io.pitch == W)
+                            HIP_TRY(hipMemcpyAsync(dst, io.hI[k][j], N, hipMemcpyHostToDevice, s));
+                        else
+                            HIP_TRY(hipMemcpy2DAsync(dst, W, io.hI[k][j], io.pitch, W, H, hipMemcpyHostToDevice, s));
+                    }
+            } else {
+                for (int32_t j = 0; j < g; j++)
+                    for (int k = 0; k < 2; k++) {
+                        uint8_t* dst = L.h_img + ((size_t)2 * j + k) * N;
+                        const uint8_t* src = io.hI[k][j];
+                        if (io.pitch == W) memcpy(dst, src, N);
+                        else
+                            for (int32_t v = 0; v < H; v++) memcpy(dst + (size_t)v * W, src + (size_t)v * io.pitch, W);
+                    }
+                HIP_TRY(hipMemcpyAsync(L.img, L.h_img, (size_t)2 * g * N, hipMemcpyHostToDevice, s));
+            }
             img.I[0] = L.img; img.I[1] = L.img + N;
             img.stride = 2 * N; img.pitch = W;
         }
