@@ -1,0 +1,23 @@
+"""The secondary legs of bench.py on their own (Matcher, visual odometry, map fusion), so that a
+rocprofv3 kernel trace of this script shows their kernels only:
+    rocprofv3 --kernel-trace --stats -- python tools/gpu_legs.py [matcher|vo|map]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402,F401  (HIP runtime of the torch wheel first)
+
+torch.cuda.init()
+import bench  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+out = {}
+if which in ("matcher", "all"):
+    out["matcher"] = bench.matcher_bench(iters=60)
+if which in ("vo", "all"):
+    out["visual_odometry"] = bench.vo_bench(iters=60)
+if which in ("map", "all"):
+    out["map_fusion"] = bench.map_bench(iters=40)
+print(json.dumps(out))
