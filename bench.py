@@ -596,6 +596,22 @@ def main():
                     roofline["traffic_source"] = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate " \
                                                  "passes), read = 2*FETCH_SIZE*1024 (gfx950), scaled to pairs " \
                                                  "per launch" % pmc["traffic_file"]
+            # The two matching kernels are integer-SAD work: what bounds them is VALU issue, not HBM
+            # (SURVEY 8d "reality check").  Issue-slot view of the same launches: wave-level VALU
+            # instructions of one launch (SQ_INSTS_VALU of the isolated PMC pass, scaled to the pairs
+            # per launch) against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction.
+            if iss and args.workload != "hd1080":
+                alias_back = {"k_support": "k_support_lds", "k_match": "k_match_keyed", "k_descriptor": "k_descriptor_stream"}
+                kk = iss["kernels"].get(alias_back.get(dom, dom))
+                if kk:
+                    peak = 1024 * 2.4e9 / 4
+                    instr = kk["valu_wave_instr"] * min(group, B) / float(tr["pairs_per_launch"] if tr else 4)
+                    roofline["valu_issue_dominant_kernel"] = {
+                        "wave_instr_per_launch": round(instr), "peak_wave_instr_per_s": peak,
+                        "frac_in_run": round(instr / avg_s / peak, 3),
+                        "frac_isolated": round(kk["valu_wave_instr"] / (kk["launch_us_under_pmc"] * 1e-6) / peak, 3),
+                        "note": "in run the launch shares the device with ~5 other kernels in flight, which "
+                                "stretches its duration; isolated = the PMC pass, one kernel at a time"}
             # whole-path view: staged-model bytes of all pairs / wall time
             e2e = ALG_BYTES_PER_PIXEL_PAIR * N_PIX * B * args.steps / elapsed_local / 1e9
             roofline["end_to_end"] = {"alg_bytes_per_pair": ALG_BYTES_PER_PIXEL_PAIR * N_PIX,
