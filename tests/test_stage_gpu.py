@@ -80,6 +80,23 @@ def test_device_stage_synthetic(seed, w, h, kw, dev_stage, oracle_lib):
         assert_same(want, got)
 
 
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
+def test_device_stage_large_image_takes_the_global_memory_forms(dev_stage, oracle_lib):
+    """1920x600: the lattice (384 x 120 cells) does not fit k_lattice's LDS and the ~4 k support
+    points exceed the LDS record capacity of k_delaunay, so the in-place global-memory lattice filter
+    and the 32-bit L2 triangle records run (automatic mode would pick the host stage here)"""
+    l, r = H.synth_pair(1920, 600, 31, dmax=120, planes=8)
+    prm = H.robotics()
+    before = dev_stage.stage_stats()
+    got = product_run(dev_stage, prm, l, r)
+    after = dev_stage.stage_stats()
+    assert after[0] == before[0] + 1 and after[1] == before[1]
+    want = H.oracle_elas_run(prm, l, r)
+    assert got.status == want.status == 0
+    assert len(want[H.SUPPORT]) // 3 > 2400          # beyond the LDS record capacity (2 339 points)
+    assert_same(want, got)
+
+
 FUZZ_SHAPES = [(320, 200), (401, 177), (512, 160), (288, 240)]
 
 
