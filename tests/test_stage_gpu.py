@@ -161,3 +161,42 @@ def test_coincident_points_fall_back_to_host(dev_stage, oracle_lib):
         assert_same(want, got)
     assert seen > 0, "no case with coincident right-image points was generated"
     assert dev_stage.stage_stats()[1] >= seen     # those pairs did come back from the device
+
+
+def test_device_resident_batch_keeps_failed_pairs_untouched(dev_stage, capfd):
+    """svh_elas_process_batch_device (what bench.py calls): maps of a pair with fewer than 3 support
+    points keep their previous contents, its status is 1, the others equal the host-buffer batch.
+    (Device memory straight from the HIP runtime the library links: torch's own copy of the runtime
+    must not be brought up after libsvhip, see INTEGRATION.md.)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    S = dev_stage
+    S.set_stage(-1)
+    w, h = 400, 240
+    pairs = [H.synth_pair(w, h, 800 + i, dmax=40) for i in range(5)]
+    flat = np.full((h, w), 33, np.uint8)
+    pairs[2] = (flat, flat)
+    I1 = np.ascontiguousarray(np.stack([p[0] for p in pairs]))
+    I2 = np.ascontiguousarray(np.stack([p[1] for p in pairs]))
+    prm = H.robotics()
+    st_h, H1, H2 = S.Elas(prm).process_batch(I1, I2)
+    D0 = np.full((5, h, w), -7.0, np.float32)
+
+    def to_device(a):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(a.nbytes)) == 0
+        assert hip.hipMemcpy(p, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), 1) == 0   # H2D
+        return p
+    dI1, dI2, dD1, dD2 = to_device(I1), to_device(I2), to_device(D0), to_device(D0)
+    try:
+        st = S.Elas(prm).process_batch_device(5, dI1, dI2, w * h, dD1, dD2, w * h * 4, w, h, w)
+        assert st == st_h == [0, 0, 1, 0, 0]
+        D1, D2 = np.empty_like(D0), np.empty_like(D0)
+        assert hip.hipMemcpy(C.c_void_p(D1.ctypes.data), dD1, C.c_size_t(D1.nbytes), 2) == 0   # D2H
+        assert hip.hipMemcpy(C.c_void_p(D2.ctypes.data), dD2, C.c_size_t(D2.nbytes), 2) == 0
+    finally:
+        for p in (dI1, dI2, dD1, dD2):
+            hip.hipFree(p)
+    assert np.all(D1[2] == -7.0) and np.all(D2[2] == -7.0)
+    for i in (0, 1, 3, 4):
+        assert np.array_equal(D1[i], H1[i]) and np.array_equal(D2[i], H2[i])
