@@ -29,6 +29,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <algorithm>
 #include <map>
@@ -882,6 +883,50 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
 
 }  // namespace svh
 
+// Parked worker threads for the batch entries: grown on demand, never torn down (they sleep on
+// a condition variable between batches).
+namespace {
+class Crew {
+public:
+    void post(std::function<void()> job) {
+        std::unique_lock<std::mutex> lk(mu_);
+        jobs_.push_back(std::move(job));
+        if (idle_ < (int)jobs_.size()) {
+            std::thread(&Crew::run, this).detach();
+        }
+        lk.unlock();
+        cv_.notify_one();
+    }
+    // the caller's jobs count `left` down; it sleeps in short naps (the jobs run for milliseconds)
+    void wait(std::atomic<int>& left) {
+        while (left.load(std::memory_order_acquire) > 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+
+private:
+    void run() {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            idle_++;
+            cv_.wait(lk, [&] { return !jobs_.empty(); });
+            idle_--;
+            std::function<void()> job = std::move(jobs_.front());
+            jobs_.pop_front();
+            lk.unlock();
+            job();
+            lk.lock();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> jobs_;
+    int idle_ = 0;
+};
+Crew& crew() {
+    static Crew* c = new Crew();   // leaked on purpose: its threads outlive static destruction
+    return *c;
+}
+}  // namespace
+
 // ===========================================================================
 // C-ABI
 // ===========================================================================
@@ -1157,9 +1202,19 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
     if (lanes <= 1) {
         worker(0);
     } else {
-        std::vector<std::thread> th;
-        for (int w = 0; w < lanes; w++) th.emplace_back(worker, w);
-        for (auto& t : th) t.join();
+        // the workers are parked threads of a process-wide crew (a batch call used to create and
+        // join `lanes` threads); worker 0 runs on the calling thread.  The thread-local error text
+        // and device binding of a crew thread are set by the job itself.
+        std::atomic<int> left{lanes - 1};
+        const int dev = e->device;
+        for (int w = 1; w < lanes; w++)
+            crew().post([&, w, dev]() {
+                t_device = dev;
+                worker(w);
+                left.fetch_sub(1, std::memory_order_release);
+            });
+        worker(0);
+        crew().wait(left);
     }
     int32_t first_bad = SVH_OK;
     for (int32_t gi = 0; gi < ngroups; gi++)
