@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256) void k_delaunay(StageDev S, DtParams P) {
         MeshL ml;
         ml.ids = reinterpret_cast<unsigned short*>(s_hist);
         ml.nbr = ml.ids + 3 * nrec;
-        int* vxy = reinterpret_cast<int*>(ml.nbr + 3 * nrec + (nrec & 1));
+        int* vxy = reinterpret_cast<int*>(ml.nbr + 3 * nrec);   // 12 * nrec bytes in: 4-byte aligned
         ml.vxy = vxy;
         for (int p = tid; p < m; p += 256) vxy[p] = pxy[p];
         dt_build(ml, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0);
