@@ -120,7 +120,8 @@ int64_t svh_elas_trim(void);
 /* number of batch workers the engine runs per device (each is double-buffered: two HIP streams
  * and buffer sets, the host stage of one group overlaps the device stages of the next) */
 int32_t svh_elas_set_lanes(int32_t lanes);
-/* pairs a lane pushes through each kernel launch (1..32, default 16): batches are cut into
+/* pairs a lane pushes through each kernel launch (1..32; default 16 for images up to ~0.5
+ * Mpixel, proportionally fewer for larger ones until this is called): batches are cut into
  * groups of this many consecutive pairs */
 int32_t svh_elas_set_group(int32_t pairs);
 

@@ -327,6 +327,14 @@ static std::mutex g_mu;
 static std::map<int, Pool*> g_pools;
 static std::atomic<int> g_lanes{8};
 static std::atomic<int> g_group{16};
+static std::atomic<bool> g_group_set{false};   // svh_elas_set_group was called: take the value as is
+// pairs per launch for an image of N pixels: the default (16) is meant for KITTI-size pairs, whose
+// group holds ~0.75 GB of lane buffers; larger images get proportionally smaller groups
+static int group_for(size_t N) {
+    const int g = std::max(1, std::min(g_group.load(), kMaxGroup));
+    if (g_group_set.load()) return g;
+    return (int)std::max<size_t>(1, std::min<size_t>(g, (size_t)8 * 1024 * 1024 / std::max<size_t>(N, 1)));
+}
 
 static Pool* pool_for(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -494,7 +502,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     if (rc) return rc;
     if (g < 1 || g > kMaxGroup) return fail(SVH_ERR_BAD_ARG, "bad group size");
     HIP_TRY(hipSetDevice(L.device));
-    rc = L.ensure(p, W, H, std::max(g, std::min(g_group.load(), kMaxGroup)));
+    rc = L.ensure(p, W, H, std::max(g, group_for((size_t)W * H)));
     if (rc) return rc;
     if (g > 1) taps = nullptr;
     const Dims& d = L.d;
@@ -1116,7 +1124,7 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
     if (rc) return rc;
     rc = check_params(e->p, dims[0], dims[1]);
     if (rc) return rc;
-    const int32_t G = std::max(1, std::min(g_group.load(), kMaxGroup));
+    const int32_t G = group_for((size_t)dims[0] * dims[1]);
     const int32_t ngroups = (n + G - 1) / G;
     const int lanes = std::min<int>(g_lanes.load(), ngroups);
     std::vector<int32_t> st(n, SVH_OK);
@@ -1304,6 +1312,7 @@ int32_t svh_elas_set_group(int32_t pairs) {
     if (pairs < 1) pairs = 1;
     if (pairs > kMaxGroup) pairs = kMaxGroup;
     g_group.store(pairs);
+    g_group_set.store(true);
     return pairs;
 }
 
