@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void k_grid_dilate(GroupDev G, int slots, int 
 // ones a lower index won with atomicMax.  Per-pixel atomics are thereby limited
 // to the handful of contested pixels (4-53 per image in the survey's probes).
 template <bool kFix>
-__global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri_arg, int W, int H, int sub) {
+__global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri_arg, int W, int H, int sub, int fix_all) {
     const int total_tri = total_tri_arg >= 0 ? total_tri_arg : G.hdr->total_tri;   // see k_prior
     const int lane = threadIdx.x & 63;
     for (int T = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6)); T < total_tri;
@@ -685,15 +685,31 @@ __global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri_arg, in
             int va = v1 < v2 ? v1 : v2, vb = v1 < v2 ? v2 : v1;
             va = va > 0 ? va : 0;
             vb = vb < H ? vb : H;
-            for (int v = va + rp; v < vb; v += 4) {
-                if (sub && (v & 1)) continue;
-                int32_t* px = &owner[(size_t)v * W + u];
-                if (kFix) {
+            if (kFix && !fix_all) {
+                // Only the ends of a column span can be contested.  The triangles partition the
+                // plane, so on the line x = u their exact spans [a, b] touch at most in a point; a
+                // rasterised span is [floor(a + e1), floor(b + e2)) with |e| << 1 from the float edge
+                // lines, hence two spans can share at most the one row in which an integer falls
+                // between two evaluations of the same boundary: the last row of the lower span, the
+                // first of the upper one.  The pass re-checks the two first and two last rows of
+                // every span (one row of margin): rows va, va+1, vb-2, vb-1 on the four row phases.
+                const int v = rp < 2 ? va + rp : vb - 4 + rp;
+                const bool mine = v >= va && v < vb && (rp < 2 || v >= va + 2);
+                if (mine && !(sub && (v & 1))) {
+                    int32_t* px = &owner[(size_t)v * W + u];
                     // a plain (possibly L1-stale) read is enough: owners only grow, so a stale
                     // value can only trigger a redundant atomicMax, never suppress a needed one
                     if (*px < t) atomicMax(px, t);
-                } else {
-                    *px = t;
+                }
+            } else {
+                for (int v = va + rp; v < vb; v += 4) {
+                    if (sub && (v & 1)) continue;
+                    int32_t* px = &owner[(size_t)v * W + u];
+                    if (kFix) {   // SVH_OWNER_FIX_ALL: every pixel of the span (the exhaustive form, for tests)
+                        if (*px < t) atomicMax(px, t);
+                    } else {
+                        *px = t;
+                    }
                 }
             }
         }
@@ -1635,10 +1651,11 @@ void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     // no clearing: the engine hands every group a fresh owner_base above all values stored so far
     if (total_tri == 0) return;
     const int nt = total_tri >= 0 ? total_tri : 4 * std::max(256, g * d.Wc * d.Hc / 6);   // see launch_prior
+    const int fix_all = getenv("SVH_OWNER_FIX_ALL") ? atoi(getenv("SVH_OWNER_FIX_ALL")) : 0;   // read per launch: tests toggle it
     LAUNCH("k_owner", k_owner<false>, dim3((nt + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
-           p.subsampling);
+           p.subsampling, 0);
     LAUNCH("k_owner_fix", k_owner<true>, dim3((nt + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
-           p.subsampling);
+           p.subsampling, fix_all);
 }
 
 bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,

@@ -414,3 +414,27 @@ def test_descriptor_strips_and_segments(w, h, sub, svhip, oracle_lib):
         oracle_lib.orc_descriptor(H._p(img), w, h, w, sub, H._p(want))
         got = e.stage(stage, np.uint8).reshape(h, w, 16)
         assert np.array_equal(got, want), (w, h, sub, np.argwhere(got != want)[:5])
+
+
+def test_owner_fix_pass_at_span_ends_equals_the_exhaustive_pass(svhip, monkeypatch):
+    """k_owner<true> re-checks only the two first and two last rows of every column span of a
+    triangle (contested pixels can only be there, see the kernel); SVH_OWNER_FIX_ALL=1 re-checks
+    every pixel.  Raw and final maps of both forms on the goldens' inputs and a set of synthetic
+    pairs (thin slanted planes make many small triangles) must be identical."""
+    cases = [(H.golden_pair(n), H.robotics()) for n in
+             ("urban1_1242x375", "urban2_1242x375", "urban3_1242x375", "urban4_1242x375")]
+    cases.append((H.golden_pair("cones_640x480"), H.middlebury()))
+    for seed in range(60, 72):
+        w, h = [(320, 200), (401, 177), (512, 160), (640, 480)][seed % 4]
+        cases.append((H.synth_pair(w, h, seed, dmax=48, planes=12), H.robotics(subsampling=seed % 5 == 0)))
+    for (l, r), prm in cases:
+        outs = []
+        for mode in ("0", "1"):
+            monkeypatch.setenv("SVH_OWNER_FIX_ALL", mode)
+            e = svhip.Elas(prm)
+            e.set_taps(True)
+            rc, D1, D2 = e.process(l, r)
+            assert rc == 0
+            outs.append((e.stage(H.D1_RAW, np.float32).copy(), e.stage(H.D2_RAW, np.float32).copy(), D1, D2))
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
