@@ -16,11 +16,13 @@ def shard_range(n_items, rank, world):
     return lo, hi
 
 
-def gather_records(record, dist=None, device=None):
-    """all-gather one small float64 record per rank; returns [world, len(record)]"""
+def gather_records(record, dist=None, device=None, force=False):
+    """all-gather one small float64 record per rank; returns [world, len(record)].
+    force: run the collective even in a world of one (bench.py --force-dist: one execution of the
+    RCCL path on a 1-GPU box)"""
     import torch
     rec = torch.as_tensor(np.asarray(record, np.float64), device=device)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return rec.cpu().numpy()[None, :]
     out = [torch.zeros_like(rec) for _ in range(dist.get_world_size())]
     dist.all_gather(out, rec)

@@ -41,8 +41,10 @@ CASES = {
     "cones_middlebury": ("cones_640x480", H.middlebury()),
     "urban3_kitti": ("urban3_1242x375", H.robotics()),
     "urban4_kitti": ("urban4_1242x375", H.robotics()),
+    # the bench's second pair with the bench's parameters (urban2_stereomapper is support_texture=30)
+    "urban2_kitti": ("urban2_1242x375", H.robotics()),
 }
-SLIM = {"urban3_kitti", "urban4_kitti"}   # support, triangles and final maps only
+SLIM = {"urban2_kitti", "urban3_kitti", "urban4_kitti"}   # support, triangles and final maps only
 
 INT_STAGES = [H.D1_RAW, H.D2_RAW, H.D1_LR, H.D2_LR, H.D1_SEG, H.D2_SEG]   # integer valued
 

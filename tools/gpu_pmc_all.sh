@@ -18,7 +18,7 @@ pmc() {  # name counters...
   find /tmp/pmc_$name -name "*.db" | head -1
 }
 A=$(pmc a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS)
-B=$(pmc b SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE)
+B=$(pmc b SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE)
 python $R/tools/pmc_issue.py $A $B > $O/pmc_issue$SUF.json
 F=$(pmc fetch FETCH_SIZE)
 W=$(pmc write WRITE_SIZE)
@@ -30,7 +30,7 @@ print(d.get("build"))
 tot=0
 for k,v in sorted(d["kernels"].items(), key=lambda kv:-kv[1]["valu_wave_instr"]):
     tot+=v["valu_wave_instr"]
-    print("%-22s us %7.1f valu %9d busy %.2f lds %.2f w/simd %s parked %s stalled %s conf %s" % (k, v["launch_us_under_pmc"], v["valu_wave_instr"], v["valu_busy"], v["lds_busy"], v["waves_per_simd"], v["parked"], v["stalled"], v["lds_bank_conflict_cycles"]))
+    print("%-22s us %7.1f valu %9d busy(model) %.2f active(meas) %s cyc/valu %s salu %s lds %.2f w/simd %s parked %s stalled %s conf %s" % (k, v["launch_us_under_pmc"], v["valu_wave_instr"], v["valu_busy"], v.get("valu_active"), v.get("cyc_per_valu"), v.get("salu_cycles"), v["lds_busy"], v["waves_per_simd"], v["parked"], v["stalled"], v["lds_bank_conflict_cycles"]))
 print("valu per pair", tot/4)
 alias={"k_support_lds":"k_support","k_match_keyed":"k_match"}
 for k,v in t["kernels"].items():

@@ -7,8 +7,14 @@ of each kernel are used (the full G-pair groups; single-pair latency calls are e
 
 Derived per launch (MI355X: 256 CUs, 4 SIMDs per CU, 8 XCDs):
   cycles            GRBM_GUI_ACTIVE summed over the 8 XCD instances / 8
-  valu_busy         SQ_INSTS_VALU * 4 / (1024 * cycles)   (a wave64 VALU op holds its SIMD for 4
-                    cycles: tools/microbench_valu.hip measures 4.1-4.3 for v_sad_u8 / v_min_u32)
+  valu_busy         SQ_INSTS_VALU * 4 / (1024 * cycles)   (MODEL: a wave64 VALU op of the classes these
+                    kernels are made of holds its SIMD for 4 cycles -- profiles/r03_microbench_valu.txt:
+                    v_sad_u8 / min / max / VOP3 / DPP / compares 4.2-4.5, add / and / or / xor / fp32 fma 2.4-2.6)
+  valu_active       SQ_ACTIVE_INST_VALU * 4 / (1024 * cycles)   (MEASURED: quad-cycles waves spent
+                    executing VALU instructions, over the SIMD-cycles of the launch)
+  cyc_per_valu      SQ_ACTIVE_INST_VALU * 4 / SQ_INSTS_VALU     (measured cycles per wave-level VALU op)
+  sq_busy           SQ_BUSY_CYCLES / (8 XCDs x cycles) as reported (any wave resident)
+  salu_cycles       SQ_INST_CYCLES_SALU * 4 / (1024 * cycles)
   salu_per_valu     SQ_INSTS_SALU / SQ_INSTS_VALU
   lds_busy          SQ_LDS_IDX_ACTIVE / (256 * cycles)
   waves_per_simd    SQ_WAVE_CYCLES * 4 / (1024 * cycles)  (SQ_WAVE_CYCLES counts quad-cycles)
@@ -71,6 +77,11 @@ def main(paths):
             "salu_wave_instr": round(c.get("SQ_INSTS_SALU", 0)),
             "lds_wave_instr": round(c.get("SQ_INSTS_LDS", 0)),
             "valu_busy": round(c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc), 3),
+            "valu_active": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cyc), 3) if "SQ_ACTIVE_INST_VALU" in c else None,
+            "cyc_per_valu": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / max(c["SQ_INSTS_VALU"], 1), 2) if "SQ_ACTIVE_INST_VALU" in c else None,
+            "sq_busy_cycles": round(c["SQ_BUSY_CYCLES"]) if "SQ_BUSY_CYCLES" in c else None,
+            "salu_cycles": round(c["SQ_INST_CYCLES_SALU"] * 4.0 / (1024.0 * cyc), 3) if "SQ_INST_CYCLES_SALU" in c else None,
+            "any_active": round(c["SQ_ACTIVE_INST_ANY"] / wc, 3) if (wc and "SQ_ACTIVE_INST_ANY" in c) else None,
             "salu_per_valu": round(c.get("SQ_INSTS_SALU", 0) / max(c["SQ_INSTS_VALU"], 1), 3),
             "lds_busy": round(c.get("SQ_LDS_IDX_ACTIVE", 0) / (256.0 * cyc), 3),
             "lds_bank_conflict_cycles": round(c.get("SQ_LDS_BANK_CONFLICT", 0)),
