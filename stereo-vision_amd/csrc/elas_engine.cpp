@@ -553,12 +553,8 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         G.Draw = L.Draw;
         G.plane_radius = plane_radius;
         G.prior_absmax = 0;
-        G.prior_max = INT32_MIN;
-        for (int32_t dd = 0; dd <= plane_radius && dd < (int32_t)L.P.size(); dd++) {
+        for (int32_t dd = 0; dd <= plane_radius && dd < (int32_t)L.P.size(); dd++)
             G.prior_absmax = std::max(G.prior_absmax, (int32_t)std::min<int64_t>(std::llabs((long long)L.P[dd]), INT32_MAX));
-            G.prior_max = std::max(G.prior_max, (int32_t)L.P[dd]);
-        }
-        if (plane_radius >= (int32_t)L.P.size()) G.prior_max = std::max(G.prior_max, 0);   // (steps beyond the table)
         launch_prior(cx, p, d, g, total_sup, total_tri, G);
         if (tapping) {
             const int32_t n1 = hdr->tri_end[0], n2 = hdr->tri_end[1] - hdr->tri_end[0];

@@ -1011,14 +1011,12 @@ __global__ __launch_bounds__(1024) void k_match_keyed(GroupDev G, MatchParams P,
             if ((int)texture16(own) >= P.match_texture) {
                 const float4 pl = *reinterpret_cast<const float4*>(G.raster + tri0 + t);
                 const uint32_t* bits = row_bits + __umulhi((uint32_t)u, P.grid_magic) * (uint32_t)P.gwords;
-                if (write_raw & 2) out = pl.x + (float)bits[0];   // timing experiment only (SVH_KEYED_DBG)
-                else
                 out = wave_inner
                           ? match_pixel_keyed<false>(own, pl, u, v, pos, oth_row, bits, s_P, G.P, P)
                           : match_pixel_keyed<true>(own, pl, u, v, pos, oth_row, bits, s_P, G.P, P);
             }
         }
-        if (!kLr || (write_raw & 1)) out_row[x] = out;
+        if (!kLr || write_raw) out_row[x] = out;
         if (kLr) s_raw[side * P.DW + x] = out;
     }
     if (!kLr) return;
@@ -1034,529 +1032,6 @@ __global__ __launch_bounds__(1024) void k_match_keyed(GroupDev G, MatchParams P,
         const float uw = side ? fx + step : fx - step;
         float o = -10.f;
         if (d >= 0 && uw >= 0 && uw < (float)P.DW)
-            if (!(fabsf(other[(int)uw] - d) > lr_threshold)) o = d;
-        D[x] = o;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// E11, cell-uniform variant (round 3; the default when it applies).  The candidate list of
-// findMatch (elas.cpp:868-902) belongs to the 20x20 GRID CELL, not to the pixel: every pixel of a
-// cell scans the same disparities.  k_match_keyed maps a wave to 64 consecutive pixels of a row
-// (3-5 cells): every lane decodes its own bit set (ctz / clear / range test per candidate, ~19
-// VALU operations of which 4 are the SAD) and the wave pays for the longest list among its lanes
-// (measured on the urban crops: 1.44x the candidates that are actually due).  Here a wave takes
-// ONE cell x kCellRows (3) image rows = 60 pixels that share one list, so
-//  * the list is decoded ONCE per wave on the scalar unit (s_ff1_i32_b32 on the cell's words held
-//    in SGPRs), the candidate disparity is wave-uniform: LDS address = v_add(lane base, SGPR),
-//    key = v_lshl_add_u32(sad, 10, SGPR) -- 1 + 4 (v_sad_u8) + 1 + 1/2 (v_min3_u32) VALU
-//    operations per candidate;
-//  * nothing is evaluated for a neighbour cell's list (idle lanes: 60 of 64, dead pixels).
-// Per-pixel exclusions are the exception, not the rule:
-//  * candidates inside the pixel's plane band [d_plane-r, d_plane+r] belong to the band pass
-//    (elas.cpp:886, 905-953).  When every prior of the band is negative (always, for the
-//    reference's table: -log(gamma+exp(..))+log(gamma) < 0) and the pixel's triangle is valid,
-//    scanning such a candidate here as well is harmless: its band twin costs at least 1 less and
-//    wins, with the same disparity.  Only waves holding a pixel of an INVALID triangle (prior 0)
-//    or a table with a non-negative entry take the masked loop, which tests the lane's own
-//    exclusion bit per candidate (v_bfe_i32 + v_or: excluded keys become 0xFFFFFFFF);
-//  * pixels whose warp u -/+ d may leave [2, W-2) (waves near the image border) clear the
-//    disparities beyond their limit from the same per-lane words.
-// The band pass walks k = -r..r wave-uniformly (d = d_plane + k per lane); the prior of step k
-// is an SGPR that seeds the v_sad_u8 accumulator, the scan rank 512 + (k + r) is an SGPR too.
-// Keys are unsigned: (cost << 10) + rank + bias, bias = 1024 * max|prior| (costs with a negative
-// prior stay non-negative); first-minimum order as in k_match_keyed.
-// A block = one (pair, side, group of 3 rows inside one cell row); the three rows of the OTHER
-// image are staged in LDS (60 KB at W = 1242, two blocks per CU), own descriptors / owner ids /
-// plane records of the next cell are fetched while the current one is scanned.  The row stride is
-// 4 (mod 16) slots: with lane = 20*row + column the four 16-lane phases of a ds_read_b128 then
-// cover the 64 banks exactly once.  Raw maps go to G.Draw; the L/R check is k_lr.
-// Needs: no subsampling, 16 <= grid_size <= 21, disp_max <= 255, plane_radius <= 15.
-// ---------------------------------------------------------------------------
-constexpr int kCellRows = 3;
-constexpr int kCellPad = 256;     // LDS slots in front of / behind the rows: u -/+ d of a masked lane stays inside
-
-template <bool kMasked, bool kClamp = false>
-__device__ __forceinline__ uint32_t cell_key(int b, int base, int sgn, uint32_t posb, const uint4& own,
-                                             const unsigned char* lds, uint32_t nk, uint32_t bias, uint32_t maxb = 0u) {
-    const int d = base + b;
-    int off = sgn * (d << 4);
-    asm volatile("" : "+s"(off));   // the byte offset stays on the scalar unit: one v_add_u32 per address
-    uint32_t a = posb + (uint32_t)off;
-    if (kClamp) a = a < maxb ? a : maxb;   // (lanes whose warp leaves the row: their key is masked, the read stays in LDS)
-    const uint4 o = *reinterpret_cast<const uint4*>(lds + a);
-    uint32_t k = (sad16(own, o) << 10) + (bias + (uint32_t)d);
-    if (kMasked) k |= (uint32_t)__builtin_amdgcn_sbfe((int)nk, (uint32_t)b, 1u);   // excluded: 0xFFFFFFFF
-    return k;
-}
-
-template <bool kMasked, bool kClamp = false>
-__device__ __forceinline__ void scan_cell_word(uint32_t sw, int base, int sgn, uint32_t posb, const uint4& own,
-                                               const unsigned char* lds, uint32_t nk, uint32_t bias,
-                                               uint32_t& best, uint32_t maxb = 0u) {
-    // sw, base, sgn, bias are wave-uniform (SGPRs); posb / own / nk / best per lane.  An odd candidate
-    // first, then two per trip in straight-line code (two LDS reads in flight, one v_min3_u32).
-    if (__builtin_popcount(sw) & 1) {
-        const int b0 = __builtin_ctz(sw);
-        sw &= sw - 1;
-        const uint32_t k0 = cell_key<kMasked, kClamp>(b0, base, sgn, posb, own, lds, nk, bias, maxb);
-        best = k0 < best ? k0 : best;
-    }
-    while (sw) {
-        const int b0 = __builtin_ctz(sw);
-        sw &= sw - 1;
-        const int b1 = __builtin_ctz(sw);
-        sw &= sw - 1;
-        const uint32_t k0 = cell_key<kMasked, kClamp>(b0, base, sgn, posb, own, lds, nk, bias, maxb);
-        const uint32_t k1 = cell_key<kMasked, kClamp>(b1, base, sgn, posb, own, lds, nk, bias, maxb);
-        const uint32_t k = k0 < k1 ? k0 : k1;
-        best = k < best ? k : best;
-    }
-}
-
-// kRad > 0: plane_radius known at compile time (band loop unrolled, priors in SGPRs); 0: runtime radius,
-// priors from an LDS table.  kSide: 0 = left map (warp u - d), 1 = right map (u + d).
-template <int kRad, int kSide>
-__device__ __forceinline__ void match_cell_body(const GroupDev& G, const MatchParams& P, int ngroups, int stride,
-                                                int prior_neg, uint32_t bias, int bid, int dbg) {
-    extern __shared__ uint4 s_oth[];   // [kCellPad] [kCellRows][stride] [kCellPad]
-    __shared__ int s_P[16];
-    const int gs = P.grid_size;
-    const int grp = bid % ngroups; bid /= ngroups;
-    const int gy = bid % P.gh;
-    const int pair = bid / P.gh;
-    if (!G.hdr->active[pair]) return;
-    const int v0 = gy * gs + kCellRows * grp;
-    int vend = (gy + 1) * gs;
-    vend = vend < P.H ? vend : P.H;
-    if (v0 >= vend) return;
-    constexpr int side = kSide, sgn = kSide ? 1 : -1;
-    const int R = kRad > 0 ? kRad : P.plane_radius;
-    if (threadIdx.x < 16) s_P[threadIdx.x] = ((int)threadIdx.x <= R && (int)threadIdx.x <= P.disp_max) ? G.P[threadIdx.x] : 0;
-    const int z = 2 * pair + side;
-    const size_t N = (size_t)P.W * P.H;
-    const uint4* desc_own = reinterpret_cast<const uint4*>(G.desc + (size_t)z * N * 16);
-    {
-        const uint4* desc_oth = reinterpret_cast<const uint4*>(G.desc + (size_t)(z ^ 1) * N * 16);
-#pragma unroll
-        for (int r = 0; r < kCellRows; r++) {
-            int line = v0 + r < P.H - 3 ? v0 + r : P.H - 3;      // elas.cpp:803
-            line = line > 2 ? line : 2;
-            const uint4* src = desc_oth + (size_t)line * P.W;
-            uint4* dst = s_oth + kCellPad + r * stride;
-            if (!(dbg & 2)) for (int i = threadIdx.x; i < P.W; i += blockDim.x) dst[i] = src[i];
-        }
-    }
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nwaves = (int)(blockDim.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int r = (lane >= gs) + (lane >= 2 * gs);
-    const int c = lane - r * gs;
-    const int v = v0 + r;
-    const bool rowok = lane < kCellRows * gs && v < vend;
-    int line = v < P.H - 3 ? v : P.H - 3;
-    line = line > 2 ? line : 2;
-    const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
-    const int32_t* own_t = G.owner + (size_t)z * N + (size_t)v * P.W;
-    const uint4* own_d = desc_own + (size_t)line * P.W;
-    const uint32_t* row_bits = G.mask + ((size_t)z * P.gw * P.gh + (size_t)gy * P.gw) * P.gwords;
-    float* out_row = G.Draw + (size_t)z * N + (size_t)v * P.W;      // DW == W, DH == H here
-    const unsigned char* lds = reinterpret_cast<const unsigned char*>(s_oth);
-    const uint32_t rowb = (uint32_t)(kCellPad + (r < kCellRows ? r : 0) * stride) << 4;
-    const int owner_base = G.owner_base;
-    // priors of the band steps as wave-uniform values
-    int pk_s[kRad > 0 ? kRad + 1 : 1];
-    if (kRad > 0) {
-#pragma unroll
-        for (int k = 0; k <= kRad; k++) pk_s[k] = __builtin_amdgcn_readfirstlane(s_P[k]);
-    }
-
-    // Software pipeline over the wave's cells: owner ids are fetched two cells ahead, own descriptors
-    // and the cell's bit set one cell ahead, the plane record (which needs the owner id) one cell ahead
-    // as well, from the middle of the current cell's scan -- no load is waited for right after its issue.
-    const float4* rast = reinterpret_cast<const float4*>(G.raster + tri0);   // 64-byte records, plane in the first 16 B
-    auto in_row = [&](int cxx) { return rowok && cxx * gs + c < P.W; };
-    auto fetch_t = [&](int cxx) -> int {
-        return (cxx < P.gw && in_row(cxx)) ? own_t[cxx * gs + c] - owner_base - 1 : -1;
-    };
-    auto is_live = [&](int cxx, int tt) {
-        const int uu = cxx * gs + c;
-        return tt >= 0 && uu >= 2 && uu < P.W - 2;
-    };
-    int cx = wave;
-    int t_c = fetch_t(cx), t_n = fetch_t(cx + nwaves);
-    uint4 own_c = make_uint4(0, 0, 0, 0);
-    uint32_t w_c = 0;
-    float4 pl_c = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cx < P.gw) {
-        if (in_row(cx)) own_c = own_d[cx * gs + c];
-        w_c = lane < P.gwords ? row_bits[(size_t)cx * P.gwords + lane] : 0u;
-        if (is_live(cx, t_c)) pl_c = rast[4 * t_c];
-    }
-    for (; cx < P.gw; cx += nwaves) {
-        const int u = cx * gs + c;
-        const bool inb = in_row(cx);
-        const int t = t_c;
-        const uint4 own = own_c;
-        const uint32_t wv = w_c;
-        const float4 pl = pl_c;
-        const bool live = inb && is_live(cx, t);
-        const bool act = live && (int)texture16(own) >= P.match_texture;
-        // next cell (descriptor, bit set) and the owner ids of the one after
-        const int cn = cx + nwaves;
-        uint4 own_n = make_uint4(0, 0, 0, 0);
-        uint32_t w_n = 0;
-        if (cn < P.gw) {
-            if (in_row(cn)) own_n = own_d[cn * gs + c];
-            w_n = lane < P.gwords ? row_bits[(size_t)cn * P.gwords + lane] : 0u;
-        }
-        const int t_nn = fetch_t(cn + nwaves);
-        float4 pl_n = make_float4(0.f, 0.f, 0.f, 0.f);
-        float out = -10.f;
-        if (dbg & 1) out = pl.x + (float)own.x;
-        else if (__builtin_amdgcn_ballot_w64(act) != 0) {
-            const int valid = __float_as_int(pl.w);
-            int d_plane =
-                (int)__fadd_rn(__fadd_rn(__fmul_rn(pl.x, (float)u), __fmul_rn(pl.y, (float)v)), pl.z);
-            // any plane value outside [-R, disp_max + R] means "empty band"; the clamp keeps the integer
-            // arithmetic below away from overflow without changing that
-            d_plane = d_plane < -64 ? -64 : (d_plane > 1024 ? 1024 : d_plane);
-            // band limits in steps k = d - d_plane, clipped to [0, disp_max] and to the warp range
-            const int dlim = side ? P.W - 3 - u : u - 2;              // largest d with u -/+ d in [2, W-2)
-            const int dtop = P.disp_max < dlim ? P.disp_max : dlim;
-            const int klo = -d_plane > -R ? -d_plane : -R;            // d >= 0
-            const int khi = dtop - d_plane < R ? dtop - d_plane : R;  // d <= dtop       (klo > khi: empty band)
-            const bool inner = side ? u + P.disp_max < P.W - 2 : u - P.disp_max >= 2;
-            const bool wave_inner = __builtin_amdgcn_ballot_w64(act && !inner) == 0;
-            // masked loop: some pixel must keep a candidate out of the cell pass
-            const bool need_band_mask = !prior_neg || __builtin_amdgcn_ballot_w64(act && !valid) != 0;
-            const bool masked = need_band_mask || !wave_inner;
-            const int ua = u < P.W - 1 ? u : P.W - 1;                  // (lanes beyond the row: stay inside the LDS rows)
-            const uint32_t posb = rowb + ((uint32_t)ua << 4);
-            uint32_t best = 0xFFFFFFFFu;
-            if (!masked) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const uint32_t sw = (uint32_t)__builtin_amdgcn_readlane((int)wv, q);
-                    if (sw) scan_cell_word<false>(sw, q * 32, sgn, posb, own, lds, 0u, bias, best);
-                }
-            } else {
-                // per-lane exclusion words: the band (when it must be kept out) and everything beyond dlim
-                const int dlo = d_plane + klo, dhi = d_plane + khi;
-                const int len = dhi - dlo + 1;
-                int wlo = -9;
-                uint32_t x0 = 0u, x1 = 0u;                             // excluded bits of words wlo, wlo+1
-                if (need_band_mask && len > 0) {
-                    const uint32_t bm = len >= 32 ? ~0u : (1u << len) - 1u;
-                    const int sh = dlo & 31;
-                    wlo = dlo >> 5;
-                    x0 = bm << sh;
-                    x1 = sh ? bm >> (32 - sh) : 0u;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const uint32_t sw = (uint32_t)__builtin_amdgcn_readlane((int)wv, q);
-                    if (!sw) continue;
-                    uint32_t nk = q == wlo ? x0 : (q == wlo + 1 ? x1 : 0u);
-                    const int lim = dlim - q * 32;                      // bits above lim leave the image
-                    nk |= lim < 0 ? ~0u : (lim >= 31 ? 0u : ~((2u << lim) - 1u));
-                    if (!act) nk = 0u;                                  // (idle lanes: their keys are never used)
-                    if (__builtin_amdgcn_ballot_w64(nk != 0u) == 0)
-                        scan_cell_word<false>(sw, q * 32, sgn, posb, own, lds, 0u, bias, best);
-                    else
-                        scan_cell_word<true>(sw, q * 32, sgn, posb, own, lds, nk, bias, best);
-                }
-            }
-            if (is_live(cn, t_n) && cn < P.gw && in_row(cn)) pl_n = rast[4 * t_n];   // next cell's plane records
-            // the band, k ascending = d ascending, rank 512 + (k + R)
-            {
-                const uint32_t vmask = valid ? ~0u : 0u;   // planes of invalid triangles carry no prior (elas.cpp:921-927)
-                const uint32_t pos2 = posb + (uint32_t)(sgn * (d_plane << 4));
-                const bool full = klo == -R && khi == R;
-                if (__builtin_amdgcn_ballot_w64(act && !full) == 0) {
-                    if (kRad > 0) {
-#pragma unroll
-                        for (int k = -kRad; k <= kRad; k++) {
-                            const int pk = pk_s[k < 0 ? -k : k];
-                            const uint4 o = *reinterpret_cast<const uint4*>(lds + (pos2 + (uint32_t)(sgn * (k << 4))));
-                            const uint32_t s = sad16_acc(own, o, (uint32_t)pk & vmask);
-                            const uint32_t key = (s << 10) + (bias + 512u + (uint32_t)(k + kRad));
-                            best = key < best ? key : best;
-                        }
-                    } else {
-                        for (int k = -R; k <= R; k++) {
-                            const int pk = s_P[k < 0 ? -k : k];
-                            const uint4 o = *reinterpret_cast<const uint4*>(lds + (pos2 + (uint32_t)(sgn * (k << 4))));
-                            const uint32_t s = sad16_acc(own, o, (uint32_t)pk & vmask);
-                            const uint32_t key = (s << 10) + (bias + 512u + (uint32_t)(k + R));
-                            best = key < best ? key : best;
-                        }
-                    }
-                } else {
-                    const uint32_t maxb = (uint32_t)(2 * kCellPad + kCellRows * stride - 1) << 4;
-                    for (int k = -R; k <= R; k++) {
-                        const int pk = s_P[k < 0 ? -k : k];
-                        uint32_t a = pos2 + (uint32_t)(sgn * (k << 4));
-                        const bool ok = k >= klo && k <= khi;
-                        a = ok ? a : 0u;
-                        a = a < maxb ? a : maxb;
-                        const uint4 o = *reinterpret_cast<const uint4*>(lds + a);
-                        const uint32_t s = sad16_acc(own, o, (uint32_t)pk & vmask);
-                        uint32_t key = (s << 10) + (bias + 512u + (uint32_t)(k + R));
-                        key = ok ? key : 0xFFFFFFFFu;
-                        best = key < best ? key : best;
-                    }
-                }
-            }
-            if (act) {
-                const int rank = (int)(best & 1023u);
-                const int dd = rank < 512 ? rank : d_plane + rank - 512 - R;
-                out = best != 0xFFFFFFFFu ? (float)dd : -1.f;
-            }
-        }
-        else if (is_live(cn, t_n) && cn < P.gw && in_row(cn)) pl_n = rast[4 * t_n];
-        if (inb) out_row[u] = out;
-        t_c = t_n; t_n = t_nn; own_c = own_n; w_c = w_n; pl_c = pl_n;
-    }
-}
-
-template <int kRad>
-__global__ __launch_bounds__(1024) void k_match_cell(GroupDev G, MatchParams P, int ngroups, int stride,
-                                                    int prior_neg, uint32_t bias, int nitems, int dbg) {
-    // Workgroups go to the 8 XCDs round-robin by id.  The left-map block of a row group stages the
-    // image-2 rows and reads its own descriptors (image 1) from memory, the right-map block the other
-    // way round: ids are laid out so that the two run on the SAME XCD at about the same time
-    // (id = 16 * (item / 8) + 8 * side + item % 8) and the second reader of a row is served by that L2.
-    const int b = blockIdx.x;
-    const int bid = (b >> 4) * 8 + (b & 7);      // item = (pair * gh + cell row) * ngroups + row group
-    if (bid >= nitems) return;
-    if (b & 8) match_cell_body<kRad, 1>(G, P, ngroups, stride, prior_neg, bias, bid, dbg);
-    else match_cell_body<kRad, 0>(G, P, ngroups, stride, prior_neg, bias, bid, dbg);
-}
-
-// ---------------------------------------------------------------------------
-// E11 + E12, row kernel with wave-uniform candidates (round 3; the default when it applies).
-// Block structure of k_match_keyed -- one image row of one pair, both maps, the two descriptor rows
-// staged in LDS once (own and other row of both passes), raw disparities of the row kept in LDS and
-// the L/R check run in the same block -- with the candidate machinery of k_match_cell: a wave takes
-// `cpw` = 64 / grid_size whole cells of the row (3 cells = 60 pixels at grid_size 20) and scans the
-// UNION of their candidate sets wave-uniformly (decoded once on the scalar unit; 1.47x the
-// candidates due on the urban crops, against 1.44x for the per-lane loops of k_match_keyed, at 8.5
-// instead of ~19 VALU operations each); a lane keeps a candidate iff its own cell has it, it lies
-// outside the lane's plane band and its warp stays inside the row (one exclusion word per lane and
-// 32 disparities, tested with v_bfe_i32 + v_or).  Words on which every lane agrees with the union
-// take the unmasked loop.  Band pass, keys and the argument for scanning in-band candidates of
-// valid-plane pixels twice: see k_match_cell.
-// ---------------------------------------------------------------------------
-template <int kRad, bool kLr>
-__global__ __launch_bounds__(1024) void k_match_row(GroupDev G, MatchParams P, DevMaps out, int write_raw,
-                                                   float lr_threshold, int prior_neg, uint32_t bias, int dbg) {
-    extern __shared__ uint4 s_rows[];   // [2][W] descriptor rows of image 1 / 2; [2][W] owner ids, then raw disparities; [2][gw][8] cell bit sets
-    __shared__ int s_P[16];
-    const int row_id = blockIdx.x;      // (pair, image row)
-    const int pair = row_id / P.H, v = row_id - pair * P.H;
-    if (!G.hdr->active[pair]) return;
-    const int R = kRad > 0 ? kRad : P.plane_radius;
-    if (threadIdx.x < 16) s_P[threadIdx.x] = ((int)threadIdx.x <= R && (int)threadIdx.x <= P.disp_max) ? G.P[threadIdx.x] : 0;
-    const size_t N = (size_t)P.W * P.H;
-    const int gs = P.grid_size;
-    int line = v < P.H - 3 ? v : P.H - 3;
-    line = line > 2 ? line : 2;
-    float* s_raw = reinterpret_cast<float*>(s_rows + 2 * P.W);          // [2][W]
-    int32_t* s_own = reinterpret_cast<int32_t*>(s_raw);                  // the same words, before a pixel is matched
-    uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_raw + 2 * P.W);     // [2][gw][8]
-    {
-        // Everything a pixel of this row needs, fetched with full-width coalesced loads before the first
-        // SAD: nothing inside the task loop waits for memory except the plane records (prefetched).
-        const uint4* l1 = reinterpret_cast<const uint4*>(G.desc + (size_t)(2 * pair) * N * 16) + (size_t)line * P.W;
-        const uint4* l2 = l1 + N;
-        for (int i = threadIdx.x; i < 2 * P.W; i += blockDim.x) s_rows[i] = i < P.W ? l1[i] : l2[i - P.W];
-        const int32_t* o1 = G.owner + (size_t)(2 * pair) * N + (size_t)v * P.W;
-        const int32_t* o2 = o1 + N;
-        for (int i = threadIdx.x; i < 2 * P.W; i += blockDim.x)
-            s_own[i] = (i < P.W ? o1[i] : o2[i - P.W]) - G.owner_base - 1;   // < 0: no triangle of this group
-        const uint32_t* b1 = G.mask + ((size_t)(2 * pair) * P.gw * P.gh + (size_t)(v / gs) * P.gw) * P.gwords;
-        const uint32_t* b2 = b1 + (size_t)P.gw * P.gh * P.gwords;
-        for (int i = threadIdx.x; i < 2 * P.gw * 8; i += blockDim.x) {
-            const int sd = i >= P.gw * 8, rem = i - sd * P.gw * 8, cellc = rem >> 3, q = rem & 7;
-            s_bits[i] = q < P.gwords ? (sd ? b2 : b1)[(size_t)cellc * P.gwords + q] : 0u;
-        }
-    }
-    __syncthreads();
-    const int half = blockDim.x >> 1;
-    const int side = __builtin_amdgcn_readfirstlane((int)threadIdx.x >= half);   // half is a multiple of 64
-    const int sgn = side ? 1 : -1;
-    const int z = 2 * pair + side;
-    const int wave = __builtin_amdgcn_readfirstlane((int)((threadIdx.x - side * half) >> 6));
-    const int nwaves = half >> 6;
-    const int lane = threadIdx.x & 63;
-    const int cpw = 64 / gs, span = cpw * gs;             // whole cells per wave
-    const int ntasks = (P.W + span - 1) / span;
-    const unsigned char* lds = reinterpret_cast<const unsigned char*>(s_rows);
-    const uint32_t othb = (uint32_t)((1 - side) * P.W) << 4;          // byte offset of the other image's row
-    const uint4* own_row = s_rows + side * P.W;
-    const uint32_t maxb = (uint32_t)(2 * P.W - 1) << 4;
-    const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
-    const float4* rast = reinterpret_cast<const float4*>(G.raster + tri0);   // 64-byte records, plane in the first 16 B
-    float* out_row = G.Draw + (size_t)z * N + (size_t)v * P.W;
-    int pk_s[kRad > 0 ? kRad + 1 : 1];
-    if (kRad > 0) {
-#pragma unroll
-        for (int k = 0; k <= kRad; k++) pk_s[k] = __builtin_amdgcn_readfirstlane(s_P[k]);
-    }
-    const int cell_l = lane / gs < cpw ? lane / gs : cpw - 1;         // this lane's cell inside the wave's span
-    const uint4* bits_side = reinterpret_cast<const uint4*>(s_bits + side * P.gw * 8);
-
-    // owner id and plane record of a task's pixel (the plane gather is the one global access left)
-    auto fetch = [&](int task, int& t_out, float4& pl_out) {
-        const int uu = task * span + lane;
-        int tt = -1;
-        if (task < ntasks && lane < span && uu < P.W) tt = s_own[side * P.W + uu];
-        if (!(uu >= 2 && uu < P.W - 2)) tt = -1;                       // elas.cpp:799: no match this close to the border
-        t_out = tt;
-        pl_out = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tt >= 0) pl_out = rast[4 * tt];
-    };
-    int t_c;
-    float4 pl_c;
-    fetch(wave, t_c, pl_c);
-    for (int task = wave; task < ntasks; task += nwaves) {
-        const int u = task * span + lane;
-        const bool inb = lane < span && u < P.W;
-        const int t = t_c;
-        const float4 pl = pl_c;
-        fetch(task + nwaves, t_c, pl_c);                  // next task of this wave: in flight during this one
-        const int ua = u < P.W - 1 ? u : P.W - 1;
-        const uint4 own = own_row[ua];
-        // this lane's cell: its candidate words (cells beyond the row: none)
-        const int cell = task * cpw + cell_l;
-        uint32_t wq[8];
-        {
-            const uint4* bits = bits_side + 2 * (cell < P.gw ? cell : P.gw - 1);
-            const uint4 lo4 = bits[0], hi4 = bits[1];
-            const bool has = cell < P.gw;
-            wq[0] = has ? lo4.x : 0u; wq[1] = has ? lo4.y : 0u; wq[2] = has ? lo4.z : 0u; wq[3] = has ? lo4.w : 0u;
-            wq[4] = has ? hi4.x : 0u; wq[5] = has ? hi4.y : 0u; wq[6] = has ? hi4.z : 0u; wq[7] = has ? hi4.w : 0u;
-        }
-        const bool live = t >= 0;
-        const bool act = live && (int)texture16(own) >= P.match_texture;
-        float outv = -10.f;
-        if (__builtin_amdgcn_ballot_w64(act) != 0) {
-            const int valid = __float_as_int(pl.w);
-            int d_plane =
-                (int)__fadd_rn(__fadd_rn(__fmul_rn(pl.x, (float)u), __fmul_rn(pl.y, (float)v)), pl.z);
-            d_plane = d_plane < -64 ? -64 : (d_plane > 1024 ? 1024 : d_plane);   // (see k_match_cell)
-            const int dlim = side ? P.W - 3 - u : u - 2;              // largest d with u -/+ d in [2, W-2)
-            const int dtop = P.disp_max < dlim ? P.disp_max : dlim;
-            const int klo = -d_plane > -R ? -d_plane : -R;
-            const int khi = dtop - d_plane < R ? dtop - d_plane : R;
-            const bool inner = side ? u + P.disp_max < P.W - 2 : u - P.disp_max >= 2;
-            // every lane of the wave (idle ones included) reads inside the two rows for any d <= disp_max?
-            const bool wave_inner = __builtin_amdgcn_ballot_w64(!inner && u < P.W) == 0;
-            const bool need_band_mask = !prior_neg || __builtin_amdgcn_ballot_w64(act && !valid) != 0;
-            const uint32_t posb = othb + ((uint32_t)ua << 4);
-            uint32_t best = 0xFFFFFFFFu;
-            // exclusion words of the lane: not in its cell / inside its band (when that matters) / beyond dlim
-            const int dlo = d_plane + klo, dhi = d_plane + khi;
-            const int len = dhi - dlo + 1;
-            int wlo = -9;
-            uint32_t x0 = 0u, x1 = 0u;
-            if (need_band_mask && len > 0) {
-                const uint32_t bm = len >= 32 ? ~0u : (1u << len) - 1u;
-                const int sh = dlo & 31;
-                wlo = dlo >> 5;
-                x0 = bm << sh;
-                x1 = sh ? bm >> (32 - sh) : 0u;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                if (dbg & 1) break;
-                // union of the wave's cells for this word (wave-uniform)
-                uint32_t uq = 0u;
-                for (int k = 0; k < cpw; k++) uq |= (uint32_t)__builtin_amdgcn_readlane((int)wq[q], k * gs);
-                if (!uq) continue;
-                uint32_t nk = ~wq[q] | (q == wlo ? x0 : (q == wlo + 1 ? x1 : 0u));
-                if (!wave_inner) {
-                    const int lim = dlim - q * 32;                      // bits above lim leave the image
-                    nk |= lim < 0 ? ~0u : (lim >= 31 ? 0u : ~((2u << lim) - 1u));
-                }
-                nk &= uq;                                               // (only bits that are scanned matter)
-                if (!act) nk = 0u;                                      // idle lanes: their keys are never used
-                if (__builtin_amdgcn_ballot_w64(nk != 0u) == 0)
-                    scan_cell_word<false, false>(uq, q * 32, sgn, posb, own, lds, 0u, bias, best);
-                else if (wave_inner)
-                    scan_cell_word<true, false>(uq, q * 32, sgn, posb, own, lds, nk, bias, best);
-                else
-                    scan_cell_word<true, true>(uq, q * 32, sgn, posb, own, lds, nk, bias, best, maxb);
-            }
-            // the band, k ascending = d ascending, rank 512 + (k + R)
-            if (!(dbg & 2)) {
-                const uint32_t vmask = valid ? ~0u : 0u;   // planes of invalid triangles carry no prior (elas.cpp:921-927)
-                const uint32_t pos2 = posb + (uint32_t)(sgn * (d_plane << 4));
-                const bool full = klo == -R && khi == R;
-                if (__builtin_amdgcn_ballot_w64(act && !full) == 0 && wave_inner) {
-                    if (kRad > 0) {
-#pragma unroll
-                        for (int k = -kRad; k <= kRad; k++) {
-                            const int pk = pk_s[k < 0 ? -k : k];
-                            int off = sgn * (k << 4);
-                            asm volatile("" : "+s"(off));
-                            uint32_t a = pos2 + (uint32_t)off;
-                            if (!act) a = posb;                    // (idle lanes: any address inside the rows)
-                            const uint4 o = *reinterpret_cast<const uint4*>(lds + a);
-                            const uint32_t sd = sad16_acc(own, o, (uint32_t)pk & vmask);
-                            const uint32_t key = (sd << 10) + (bias + 512u + (uint32_t)(k + kRad));
-                            best = key < best ? key : best;
-                        }
-                    } else {
-                        for (int k = -R; k <= R; k++) {
-                            const int pk = s_P[k < 0 ? -k : k];
-                            uint32_t a = pos2 + (uint32_t)(sgn * (k << 4));
-                            if (!act) a = posb;
-                            const uint4 o = *reinterpret_cast<const uint4*>(lds + a);
-                            const uint32_t sd = sad16_acc(own, o, (uint32_t)pk & vmask);
-                            const uint32_t key = (sd << 10) + (bias + 512u + (uint32_t)(k + R));
-                            best = key < best ? key : best;
-                        }
-                    }
-                } else {
-                    for (int k = -R; k <= R; k++) {
-                        const int pk = s_P[k < 0 ? -k : k];
-                        uint32_t a = pos2 + (uint32_t)(sgn * (k << 4));
-                        const bool ok = act && k >= klo && k <= khi;
-                        a = ok ? a : posb;
-                        const uint4 o = *reinterpret_cast<const uint4*>(lds + a);
-                        const uint32_t sd = sad16_acc(own, o, (uint32_t)pk & vmask);
-                        uint32_t key = (sd << 10) + (bias + 512u + (uint32_t)(k + R));
-                        key = ok ? key : 0xFFFFFFFFu;
-                        best = key < best ? key : best;
-                    }
-                }
-            }
-            if (act) {
-                const int rank = (int)(best & 1023u);
-                const int dd = rank < 512 ? rank : d_plane + rank - 512 - R;
-                outv = best != 0xFFFFFFFFu ? (float)dd : -1.f;
-            }
-        }
-        if (inb) {
-            if (!kLr || write_raw) out_row[u] = outv;
-            if (kLr) s_raw[side * P.W + u] = outv;
-        }
-    }
-    if (!kLr) return;
-    __syncthreads();
-    // E12: keep d iff the other map, at the warped position, agrees within lr_threshold
-    float* D = out.D[side] + (size_t)pair * out.stride[side] + (size_t)v * P.W;
-    const float* mine = s_raw + side * P.W;
-    const float* other = s_raw + (1 - side) * P.W;
-    for (int x = (int)threadIdx.x - side * half; x < P.W; x += half) {
-        const float d = mine[x];
-        const float fx = (float)x;
-        const float uw = side ? fx + d : fx - d;
-        float o = -10.f;
-        if (d >= 0 && uw >= 0 && uw < (float)P.W)
             if (!(fabsf(other[(int)uw] - d) > lr_threshold)) o = d;
         D[x] = o;
     }
@@ -2196,7 +1671,6 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     static const bool ordered = getenv("SVH_MATCH_ORDERED") != nullptr;
     const bool keyed_ok = !ordered && G.prior_absmax < (1 << 19) && p.disp_max < 512 &&
                           G.plane_radius <= 15 && d.W < 65536 && p.grid_size > 1;
-    constexpr size_t keyed_lds_max0 = 96 * 1024;
     const size_t lds2 = 2 * lds + (lr_out ? (size_t)2 * d.DW * sizeof(float) : 0);
     // rows up to 1920 px (77 KB with the raw-disparity rows) still take the keyed kernel: two blocks
     // per CU, measured 2-5 % ahead of the ordered fallback on 1920x1080 since the kernel got leaner
@@ -2212,77 +1686,6 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
                                         (int)keyed_lds_max) == hipSuccess;
         if (!use_keyed) (void)hipGetLastError();
     }
-    // 0 = k_match_keyed, 1 = k_match_cell (+ k_lr), 2 = k_match_row (default)
-    static const int match_mode = getenv("SVH_MATCH_MODE") ? atoi(getenv("SVH_MATCH_MODE")) : 2;
-    const size_t lds_row = 2 * lds + (size_t)2 * d.W * sizeof(float) + (size_t)2 * d.gw * 8 * sizeof(uint32_t);
-    if (match_mode == 2 && keyed_ok && !p.subsampling && p.grid_size >= 8 && p.grid_size <= 64 && d.gwords <= 8 &&
-        G.plane_radius >= 1 && lds_row + 256 <= keyed_lds_max0) {
-        bool ok = true;
-        const int rsel = G.plane_radius == 2 ? 2 : (G.plane_radius == 3 ? 3 : 0);
-        if (lds_row + 256 > 48 * 1024) {
-            const void* fns[2] = {nullptr, nullptr};
-            if (rsel == 2) { fns[0] = (const void*)k_match_row<2, true>; fns[1] = (const void*)k_match_row<2, false>; }
-            else if (rsel == 3) { fns[0] = (const void*)k_match_row<3, true>; fns[1] = (const void*)k_match_row<3, false>; }
-            else { fns[0] = (const void*)k_match_row<0, true>; fns[1] = (const void*)k_match_row<0, false>; }
-            for (int k = 0; k < 2 && ok; k++)
-                ok = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)keyed_lds_max0) == hipSuccess;
-            if (!ok) (void)hipGetLastError();
-        }
-        if (ok) {
-            Timed timed_(cx, "k_match");
-            static const int rdbg = getenv("SVH_ROW_DBG") ? atoi(getenv("SVH_ROW_DBG")) : 0;   // timing experiments only
-            static const int rt = getenv("SVH_ROW_THREADS") ? atoi(getenv("SVH_ROW_THREADS")) : 512;
-            const dim3 grid((unsigned)(d.H * g)), block(rt);
-            const int prior_neg = G.prior_max < 0;
-            const uint32_t bias = (uint32_t)G.prior_absmax << 10;
-            hipStream_t s = (hipStream_t)cx.stream;
-            DevMaps none{};
-            const DevMaps& o = lr_out ? *lr_out : none;
-            const int wr = lr_out ? (write_raw ? 1 : 0) : 1;
-            const float thr = (float)p.lr_threshold;
-#define SVH_ROW_LAUNCH(RAD)                                                                                         \
-            if (lr_out) hipLaunchKernelGGL((k_match_row<RAD, true>), grid, block, lds_row, s, G, P, o, wr, thr, prior_neg, bias, rdbg); \
-            else hipLaunchKernelGGL((k_match_row<RAD, false>), grid, block, lds_row, s, G, P, o, wr, thr, prior_neg, bias, rdbg)
-            if (rsel == 2) { SVH_ROW_LAUNCH(2); }
-            else if (rsel == 3) { SVH_ROW_LAUNCH(3); }
-            else { SVH_ROW_LAUNCH(0); }
-#undef SVH_ROW_LAUNCH
-            return lr_out != nullptr;
-        }
-    }
-    // cell-uniform kernel (see k_match_cell): raw maps only, the caller follows up with k_lr
-    const int cell_mode = match_mode == 1;
-    if (cell_mode && keyed_ok && !p.subsampling && p.grid_size >= 16 && p.grid_size * kCellRows <= 64 &&
-        d.gwords <= 8 && G.plane_radius >= 1) {
-        const int stride = ((d.W + 15) & ~15) + 4;
-        const size_t lds_cell = (size_t)(2 * kCellPad + kCellRows * stride) * sizeof(uint4);
-        const void* fn = G.plane_radius == 2   ? (const void*)k_match_cell<2>
-                         : G.plane_radius == 3 ? (const void*)k_match_cell<3>
-                                               : (const void*)k_match_cell<0>;
-        bool ok = lds_cell + 256 <= 160 * 1024;
-        if (ok && lds_cell > 48 * 1024) {
-            ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cell) == hipSuccess;
-            if (!ok) (void)hipGetLastError();
-        }
-        if (ok) {
-            Timed timed_(cx, "k_match");
-            const int ngroups = (p.grid_size + kCellRows - 1) / kCellRows;
-            static const int ct = getenv("SVH_CELL_THREADS") ? atoi(getenv("SVH_CELL_THREADS")) : 1024;
-            const int nitems = g * d.gh * ngroups;
-            static const int dbg = getenv("SVH_CELL_DBG") ? atoi(getenv("SVH_CELL_DBG")) : 0;   // timing experiments only
-            const dim3 grid((unsigned)(((nitems + 7) / 8) * 16)), block(ct);
-            const int prior_neg = G.prior_max < 0;
-            const uint32_t bias = (uint32_t)G.prior_absmax << 10;
-            hipStream_t s = (hipStream_t)cx.stream;
-            if (G.plane_radius == 2)
-                hipLaunchKernelGGL(k_match_cell<2>, grid, block, lds_cell, s, G, P, ngroups, stride, prior_neg, bias, nitems, dbg);
-            else if (G.plane_radius == 3)
-                hipLaunchKernelGGL(k_match_cell<3>, grid, block, lds_cell, s, G, P, ngroups, stride, prior_neg, bias, nitems, dbg);
-            else
-                hipLaunchKernelGGL(k_match_cell<0>, grid, block, lds_cell, s, G, P, ngroups, stride, prior_neg, bias, nitems, dbg);
-            return false;
-        }
-    }
     if (use_keyed) {
         Timed timed_(cx, "k_match");
         // threads per map and row block: the row is covered in `iters` equal passes with little idle tail
@@ -2292,8 +1695,7 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
         const dim3 grid((unsigned)(d.DH * g)), block(2 * half);
         hipStream_t s = (hipStream_t)cx.stream;
         if (lr_out) {
-            static const int kdbg = getenv("SVH_KEYED_DBG") ? 2 : 0;
-            hipLaunchKernelGGL(k_match_keyed<true>, grid, block, lds2, s, G, P, *lr_out, (write_raw ? 1 : 0) | kdbg,
+            hipLaunchKernelGGL(k_match_keyed<true>, grid, block, lds2, s, G, P, *lr_out, write_raw ? 1 : 0,
                                (float)p.lr_threshold);
             return true;   // the L/R check is done
         }

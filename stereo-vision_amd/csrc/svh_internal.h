@@ -151,7 +151,6 @@ struct GroupDev {
     int32_t plane_radius;
     int32_t owner_base;        // owner[] holds owner_base + 1 + triangle; values <= owner_base are stale
     int32_t prior_absmax;      // max |P[dd]|, dd <= plane_radius (selects the keyed match kernel)
-    int32_t prior_max;         // max P[dd], dd <= plane_radius (< 0: every band step carries a bonus)
 };
 
 // k_lattice + k_delaunay + k_stage_pack: from S.dcan to the packed support / triangle lists and
