@@ -481,7 +481,15 @@ static HostProfDump g_hp_dump;
 
 // where E5-E7 run: -1 = auto (batches on the device, single calls on the host: two host threads
 // are the lower latency for one pair), 0 = host, 1 = device.  SVH_STAGE=host|device, svh_elas_set_stage()
-static std::atomic<int> g_stage_mode{getenv("SVH_STAGE") ? (strcmp(getenv("SVH_STAGE"), "device") == 0 ? 1 : 0) : -1};
+static int stage_mode_from_env() {
+    const char* e = getenv("SVH_STAGE");
+    if (!e || !*e || !strcmp(e, "auto") || !strcmp(e, "-1")) return -1;
+    if (!strcmp(e, "host") || !strcmp(e, "0")) return 0;
+    if (!strcmp(e, "device") || !strcmp(e, "1")) return 1;
+    fprintf(stderr, "svhip: SVH_STAGE=%s is not one of auto|-1, host|0, device|1: using auto\n", e);
+    return -1;
+}
+static std::atomic<int> g_stage_mode{stage_mode_from_env()};
 
 static std::atomic<int64_t> g_stage_dev_groups{0}, g_stage_redo_groups{0};
 
@@ -502,7 +510,9 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     if (rc) return rc;
     if (g < 1 || g > kMaxGroup) return fail(SVH_ERR_BAD_ARG, "bad group size");
     HIP_TRY(hipSetDevice(L.device));
-    rc = L.ensure(p, W, H, std::max(g, group_for((size_t)W * H)));
+    // lanes are sized for the group at hand: a single Elas::process call holds buffers for one pair
+    // (41 MB at KITTI size), not for the batch default; batch workers size theirs up front
+    rc = L.ensure(p, W, H, g);
     if (rc) return rc;
     if (g > 1) taps = nullptr;
     const Dims& d = L.d;
@@ -646,10 +656,22 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         if (!L.resident) return SVH_OK;
         g_stage_dev_groups++;
         bool redo = false;
+        for (int32_t j = 0; j < g; j++) redo = redo || (L.h_counts->flags[j] & (STG_DUP | STG_OVERFLOW)) != 0;
+        if (redo) {
+            // coincident support points (or more points than the scratch holds): which duplicate
+            // survives is decided by Triangle's pivot stream -- the host path reproduces that.  The whole
+            // group goes through it again (rare: not with the reference's presets); its statuses and its
+            // "need at least 3 support points" messages -- one per pair, as in the reference -- are the
+            // ones the caller gets, so nothing is printed for this group here.
+            g_stage_redo_groups++;
+            L.resident = false;
+            L.force_host = true;
+            rc = run_group(L, p, dims, io, status, taps, timing, RG_ALL, false);
+            L.force_host = false;
+            return rc;
+        }
         for (int32_t j = 0; j < g; j++) {
-            if (L.h_counts->flags[j] & (STG_DUP | STG_OVERFLOW)) {
-                redo = true;
-            } else if (L.h_counts->nsup[j] < 3) {
+            if (L.h_counts->nsup[j] < 3) {
                 // elas.cpp:69-75: message on stdout, outputs untouched
                 printf("ERROR: Need at least 3 support points!\n");
                 fflush(stdout);
@@ -657,19 +679,6 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
             } else {
                 status[j] = SVH_OK;
             }
-        }
-        if (redo) {
-            // coincident support points (or more points than the scratch holds): which duplicate
-            // survives is decided by Triangle's pivot stream -- the host path reproduces that
-            g_stage_redo_groups++;
-            L.resident = false;
-            L.force_host = true;
-            std::vector<int32_t> st2(g, SVH_OK);
-            rc = run_group(L, p, dims, io, st2.data(), taps, timing, RG_ALL, false);
-            L.force_host = false;
-            if (rc) return rc;
-            for (int32_t j = 0; j < g; j++)
-                if (L.h_counts->flags[j] & (STG_DUP | STG_OVERFLOW)) status[j] = st2[j];
         }
         return SVH_OK;
     };

@@ -107,6 +107,26 @@ __device__ __forceinline__ int tri_slot(const GroupHdr* __restrict__ h, int T, i
     return s;
 }
 
+// Global -> LDS staging of n 16-byte slots by a whole block.  A plain "dst[i] = src(i)" loop compiles to
+// load, wait, store, next load: every pass over the block pays a full memory round trip.  Here kUn loads
+// of a thread are in flight before the first is stored.
+template <int kUn, typename F>
+__device__ __forceinline__ void stage_slots(uint4* dst, int n, int tid, int nthreads, F src_of) {
+    for (int i0 = tid; i0 < n; i0 += kUn * nthreads) {
+        uint4 v[kUn];
+#pragma unroll
+        for (int k = 0; k < kUn; k++) {
+            const int i = i0 + k * nthreads;
+            if (i < n) v[k] = src_of(i);
+        }
+#pragma unroll
+        for (int k = 0; k < kUn; k++) {
+            const int i = i0 + k * nthreads;
+            if (i < n) dst[i] = v[k];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // E1+E2  3x3 Sobel + 16-byte descriptor, fused, streaming: no LDS, no barriers.
 //   filter::sobel3x3          libelas/src/filter.cpp:408-416 (+372-405, 227-267, 176-222)
@@ -390,14 +410,13 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
     const int wl = xl1 - xl0 + 1, wr = xr1 - xr0 + 1;
     uint4* sL = s_strip;
     uint4* sR = s_strip + 2 * wl;
-    for (int i = threadIdx.x; i < 2 * wl; i += kST) {
-        const int row = i >= wl, x = i - row * wl;
-        sL[i] = d1[(size_t)(v + (row ? 2 : -2)) * P.W + xl0 + x];
-    }
-    for (int i = threadIdx.x; i < 2 * wr; i += kST) {
-        const int row = i >= wr, x = i - row * wr;
-        sR[i] = d2[(size_t)(v + (row ? 2 : -2)) * P.W + xr0 + x];
-    }
+    // (sL and sR are adjacent: one pass over both strips, up to six loads per thread in flight)
+    stage_slots<6>(s_strip, 2 * (wl + wr), (int)threadIdx.x, kST, [&](int i) {
+        const bool rgt = i >= 2 * wl;
+        const int j = rgt ? i - 2 * wl : i, w = rgt ? wr : wl;
+        const int row = j >= w, x = j - row * w;
+        return (rgt ? d2 : d1)[(size_t)(v + (row ? 2 : -2)) * P.W + (rgt ? xr0 : xl0) + x];
+    });
     __syncthreads();
     const StripView L = {sL, xl0, wl}, R = {sR, xr0, wr};
     // Four candidates per wave, one per row of 16 lanes (rows 2k and 2k+1 take candidates 8 apart).
@@ -960,7 +979,7 @@ __device__ __forceinline__ float match_pixel_keyed(const uint4& own, const float
 // left and right disparities of that same row, which this block has just produced: they stay
 // in LDS, and the checked maps go straight to `out` -- no raw-map round trip, no k_lr launch.
 template <bool kLr>
-__global__ __launch_bounds__(1024) void k_match_keyed(GroupDev G, MatchParams P, DevMaps out, int write_raw,
+__global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P, DevMaps out, int write_raw,
                                                      float lr_threshold) {
     // One block = one image row of one pair, BOTH disparity maps: the left-map pass compares
     // L[row] with R[row], the right-map pass R[row] with L[row], so the two descriptor rows
@@ -983,8 +1002,8 @@ __global__ __launch_bounds__(1024) void k_match_keyed(GroupDev G, MatchParams P,
         // the image-2 row is stored REVERSED: a left-map candidate u - d is then slot (W-1-u) + d, a
         // right-map candidate u + d slot u + d of the image-1 row -- position + disparity on both
         // sides, one v_lshl_add per address
-        for (int i = threadIdx.x; i < 2 * P.W; i += blockDim.x)
-            s_rows[i] = i < P.W ? l1[i] : l2[2 * P.W - 1 - i];
+        stage_slots<5>(s_rows, 2 * P.W, (int)threadIdx.x, (int)blockDim.x,
+                       [&](int i) { return i < P.W ? l1[i] : l2[2 * P.W - 1 - i]; });
     }
     __syncthreads();
     const int half = blockDim.x >> 1;
@@ -1175,11 +1194,16 @@ __global__ __launch_bounds__(256) void k_seg_tile(GroupDev G, DevMaps m, PostScr
     const int tx = threadIdx.x;   // lane: a wave owns whole tile rows ty = threadIdx.y + 4k
     // step 1: horizontal runs per row with one ballot; label = first pixel of the run
     int len[CY / 4];
+    float dk[CY / 4];
+#pragma unroll
+    for (int k = 0; k < CY / 4; k++) {   // the four rows of this thread: all loads in flight before the first use
+        const int gx = x0 + tx, gy = y0 + (int)threadIdx.y + 4 * k;
+        dk[k] = (gx < DW && gy < DH) ? D[gy * DW + gx] : -10.f;
+    }
 #pragma unroll
     for (int k = 0; k < CY / 4; k++) {
         const int ty = threadIdx.y + 4 * k;
-        const int gx = x0 + tx, gy = y0 + ty;
-        const float d = (gx < DW && gy < DH) ? D[gy * DW + gx] : -10.f;
+        const float d = dk[k];
         const bool valid = d >= 0;
         const float dl = __shfl_up(d, 1, kWave);
         const bool start = valid && (tx == 0 || !seg_joined(d, dl, thr));
@@ -1651,7 +1675,12 @@ void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     // no clearing: the engine hands every group a fresh owner_base above all values stored so far
     if (total_tri == 0) return;
     const int nt = total_tri >= 0 ? total_tri : 4 * std::max(256, g * d.Wc * d.Hc / 6);   // see launch_prior
-    const int fix_all = getenv("SVH_OWNER_FIX_ALL") ? atoi(getenv("SVH_OWNER_FIX_ALL")) : 0;   // read per launch: tests toggle it
+    // The span-ends form of the fix pass relies on two float evaluations a*u + b of one triangle edge
+    // differing by less than one row (see k_owner).  |a*u| can reach H * (W + 2*disp_max) for an edge that
+    // climbs the whole image within one column; beyond 2^22 one ulp of that product is half a row and the
+    // margin is gone, so such geometries (not 1920x1080 at disp_max 255: 2.6e6) take the exhaustive pass.
+    const bool wide = (double)d.H * ((double)d.W + 2.0 * p.disp_max) > 4194304.0;
+    const int fix_all = getenv("SVH_OWNER_FIX_ALL") ? atoi(getenv("SVH_OWNER_FIX_ALL")) : (wide ? 1 : 0);   // read per launch: tests toggle it
     LAUNCH("k_owner", k_owner<false>, dim3((nt + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
            p.subsampling, 0);
     LAUNCH("k_owner_fix", k_owner<true>, dim3((nt + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
@@ -1689,9 +1718,10 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     if (use_keyed) {
         Timed timed_(cx, "k_match");
         // threads per map and row block: the row is covered in `iters` equal passes with little idle tail
-        static const int mt = getenv("SVH_MATCH_THREADS") ? atoi(getenv("SVH_MATCH_THREADS")) : 256;
+        // threads per map (64..256; 256 measured best: isolated 32-pair launch 359 us vs 450 at 512 and 526 at 128)
+        static const int mt = std::min(256, std::max(64, getenv("SVH_MATCH_THREADS") ? atoi(getenv("SVH_MATCH_THREADS")) : 256));
         const int iters = (d.DW + mt - 1) / mt;
-        const int half = std::min(512, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
+        const int half = std::min(256, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
         const dim3 grid((unsigned)(d.DH * g)), block(2 * half);
         hipStream_t s = (hipStream_t)cx.stream;
         if (lr_out) {
@@ -1909,15 +1939,27 @@ __global__ __launch_bounds__(256) void k_mean_tile(GroupDev G, DevMaps m, PostSc
     const int x0 = blockIdx.x * QX, y0 = blockIdx.y * QY;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     constexpr int AW = QX + HL + HR, AH = QY + HL + HR;
-    for (int i = tid; i < AH * AW; i += 256) {
-        const int r = i / AW, c = i - r * AW;
-        const int gy = y0 - HL + r, gx = x0 - HL + c;
-        float val = -10.f;
-        if (gy >= 0 && gy < DH && gx >= 0 && gx < DW) {
-            val = in[(size_t)gy * DW + gx];
-            if (val < 0) val = -10.f;     // D_copy initialisation (elas.cpp:1553-1560)
+    {
+        // all of a thread's tile entries are requested before the first one is used (a plain
+        // load / clamp / store loop waits for memory once per entry: 11 round trips per thread)
+        constexpr int NE = (AH * AW + 255) / 256;
+        float val[NE];
+#pragma unroll
+        for (int k = 0; k < NE; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / AW, c = i - r * AW;
+            const int gy = y0 - HL + r, gx = x0 - HL + c;
+            const bool inside = i < AH * AW && gy >= 0 && gy < DH && gx >= 0 && gx < DW;
+            val[k] = inside ? in[(size_t)gy * DW + gx] : -10.f;
         }
-        sA[r][c] = val;
+#pragma unroll
+        for (int k = 0; k < NE; k++) {
+            const int i = tid + 256 * k;
+            if (i < AH * AW) {
+                const int r = i / AW, c = i - r * AW;
+                sA[r][c] = val[k] < 0 ? -10.f : val[k];     // D_copy initialisation (elas.cpp:1553-1560)
+            }
+        }
     }
     __syncthreads();
     // horizontal pass -> D_tmp: -10 where the input is invalid, 0 where valid but never written

@@ -427,6 +427,10 @@ def test_owner_fix_pass_at_span_ends_equals_the_exhaustive_pass(svhip, monkeypat
     for seed in range(60, 72):
         w, h = [(320, 200), (401, 177), (512, 160), (640, 480)][seed % 4]
         cases.append((H.synth_pair(w, h, seed, dmax=48, planes=12), H.robotics(subsampling=seed % 5 == 0)))
+    # 1920x1080 with large disparities: the longest edge lines and the largest |a*u + b| cancellation the
+    # span-ends argument has to survive (right-image triangles reach u = -disp_max)
+    for seed in (72, 73):
+        cases.append((H.synth_pair(1920, 1080, seed, dmax=230, planes=14), H.robotics()))
     for (l, r), prm in cases:
         outs = []
         for mode in ("0", "1"):
