@@ -232,6 +232,50 @@ def vo_bench(iters=40):
     return out
 
 
+def vo_replicas_bench(ks=(1, 4, 16), frames=40):
+    """the Matcher / visual odometry chain frames of ONE sequence (ring buffer, Tr_delta), so
+    it does not shard; what scales is the number of independent sequences.  K VisualOdometryStereo
+    objects (own streams, own ring buffers), one host thread each, all on this GPU: aggregate stereo
+    frames/s.  (libc rand() is shared by the threads, as it would be for K reference objects in one
+    process: the RANSAC sample streams interleave, throughput is what is measured here.)"""
+    import threading
+    import helpers as Hh
+    im = [Hh.read_pgm(os.path.join(Hh.GOLDEN, "viso_%s.pgm" % k)) for k in ("I1p", "I2p", "I1c", "I2c")]
+    prm = Hh.vo_defaults()
+    out = []
+    for K in ks:
+        vos = [Hh.ProductVo(prm) for _ in range(K)]
+        for vo in vos:                      # first frames: allocations, bootstrap
+            vo.process(im[0], im[1])
+            vo.process(im[2], im[3])
+        ok = [0] * K
+        go = threading.Barrier(K + 1)
+
+        def worker(j):
+            vo = vos[j]
+            go.wait()
+            for i in range(frames):
+                a, b = (im[0], im[1]) if i % 2 == 0 else (im[2], im[3])
+                ok[j] += vo.process(a, b) == 1
+        th = [threading.Thread(target=worker, args=(j,)) for j in range(K)]
+        for t in th:
+            t.start()
+        import resource
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
+        go.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        cpu = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
+        out.append({"replicas": K, "frames_per_s": K * frames / dt, "frame_ms_per_replica": 1e3 * dt / frames,
+                    "frames_ok": int(sum(ok)), "frames": K * frames, "host_cores_used": round(cpu / dt, 2)})
+        del vos
+    return {"workload": "K independent VisualOdometryStereo objects on one GPU, libviso2/img quad 1344x391 "
+                        "alternating, one host thread per object", "runs": out}
+
+
 def map_bench(iters=30):
     """3-D reprojection + map fusion of one 1242x375 frame (createCurrentMap +
     addDisparityMapToReconstruction), device vs the CPU restatement (oracle, "port": the reference's
@@ -827,6 +871,7 @@ def main():
             out["matcher"] = matcher_bench()     # before the CPU leg: the GPU is still at its clocks
             out["visual_odometry"] = vo_bench()
             out["map_fusion"] = map_bench()
+            out["visual_odometry"]["replicas"] = vo_replicas_bench()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(I1, I2, params, what, budget_s=args.cpu_budget,
                                                workers=int(avail) if args.workload == "kitti" else 0)

@@ -504,7 +504,7 @@ static hipError_t event_wait(Lane& L, hipEvent_t ev) {
 }
 
 static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, const GroupIO& io,
-                     int32_t* status, Taps* taps, svh_elas* timing, int mode = RG_ALL, bool prefer_device = false) {
+                     int32_t* status, Taps* taps, svh_elas* timing, int mode = RG_ALL, int prefer_device = 0) {
     const int32_t W = dims[0], H = dims[1], g = io.g;
     int rc = check_params(p, W, H);
     if (rc) return rc;
@@ -666,7 +666,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
             g_stage_redo_groups++;
             L.resident = false;
             L.force_host = true;
-            rc = run_group(L, p, dims, io, status, taps, timing, RG_ALL, false);
+            rc = run_group(L, p, dims, io, status, taps, timing, RG_ALL, 0);
             L.force_host = false;
             return rc;
         }
@@ -728,7 +728,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         launch_support(cx, p, d, g, L.desc, L.dcan);
         const int sm = g_stage_mode.load();
         L.resident = !L.force_host && L.stage_ok &&
-                     (sm == 1 || (sm < 0 && prefer_device && stage_device_preferred(p, d)));
+                     (sm == 1 || (sm < 0 && prefer_device && stage_device_preferred(p, d, prefer_device > 1)));
         if (!L.resident || tapping)
             HIP_TRY(hipMemcpyAsync(L.h_dcan, L.dcan, g * nc * sizeof(int16_t), hipMemcpyDeviceToHost, s));
         if (L.resident) {
@@ -1136,6 +1136,9 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
     const int32_t G = group_for((size_t)dims[0] * dims[1]);
     const int32_t ngroups = (n + G - 1) / G;
     const int lanes = std::min<int>(g_lanes.load(), ngroups);
+    // automatic stage choice: 1 = a batch, 2 = a deep batch (several rounds of groups per worker: what
+    // counts is throughput, not the latency of one group -- the device stage also for large lattices)
+    const int deep = ngroups >= 4 * lanes ? 2 : 1;
     std::vector<int32_t> st(n, SVH_OK);
     std::vector<int32_t> grc(ngroups, SVH_OK);
     std::vector<std::string> errs(std::max(lanes, 1));
@@ -1180,7 +1183,7 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
         Job pending[2];   // group whose tail is still on slot k's stream
         Job cur = take();
         int k = 0;
-        if (cur.gi >= 0) note(cur, run_group(*slot[0], e->p, dims, cur.io, &st[cur.first], nullptr, nullptr, RG_A, true));
+        if (cur.gi >= 0) note(cur, run_group(*slot[0], e->p, dims, cur.io, &st[cur.first], nullptr, nullptr, RG_A, deep));
         while (cur.gi >= 0) {
             Job nxt = slot[1] ? take() : Job();
             if (nxt.gi >= 0) {
@@ -1190,7 +1193,7 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
                                                nullptr, RG_FINISH));
                     pending[o].gi = -1;
                 }
-                note(nxt, run_group(*slot[o], e->p, dims, nxt.io, &st[nxt.first], nullptr, nullptr, RG_A, true));
+                note(nxt, run_group(*slot[o], e->p, dims, nxt.io, &st[nxt.first], nullptr, nullptr, RG_A, deep));
             }
             if (grc[cur.gi] == SVH_OK)
                 note(cur, run_group(*slot[k], e->p, dims, cur.io, &st[cur.first], nullptr, nullptr, RG_HOST_B));
@@ -1200,7 +1203,7 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
                 pending[0].gi = -1;
                 nxt = take();
                 if (nxt.gi >= 0)
-                    note(nxt, run_group(*slot[0], e->p, dims, nxt.io, &st[nxt.first], nullptr, nullptr, RG_A, true));
+                    note(nxt, run_group(*slot[0], e->p, dims, nxt.io, &st[nxt.first], nullptr, nullptr, RG_A, deep));
             } else {
                 k = 1 - k;
             }

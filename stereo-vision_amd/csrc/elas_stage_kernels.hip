@@ -95,11 +95,11 @@ struct LatticeParams {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void lattice_consistency_events(int16_t* val, uint32_t* cntw, int32_t* wl, int nc,
                                                            const LatticeParams& P, int* s_n) {
+    // cntw arrives filled: c0 of every cell, counted on the untouched lattice by k_lattice_count
     const int tid = threadIdx.x, Wc = P.Wc, Hc = P.Hc;
     int32_t* alive = wl;
     int32_t* fresh[2] = {wl + nc, wl + 2 * (size_t)nc};
     if (tid < 3) s_n[tid] = 0;
-    for (int i = tid; i < (nc + 3) / 4; i += 512) cntw[i] = 0;
     __syncthreads();
     // (one LDS atomic per wave, not per lane: lanes of a wave append behind a common base)
     for (int i0 = 0; i0 < nc; i0 += 512) {
@@ -113,23 +113,6 @@ __device__ __forceinline__ void lattice_consistency_events(int16_t* val, uint32_
     }
     __syncthreads();
     const int nalive = s_n[0];
-    for (int k = tid; k < nalive; k += 512) {
-        const int at = alive[k];
-        const int vc = at / Wc, uc = at - vc * Wc, dv = val[at];
-        const int ulo = max(uc - P.ws, 0), uhi = min(uc + P.ws, Wc - 1);
-        const int vlo = max(vc - P.ws, 0), vhi = min(vc + P.ws, Hc - 1);
-        int cnt = 0;
-        for (int v2 = vlo; v2 <= vhi; v2++) {
-            const int16_t* row = val + v2 * Wc;
-            for (int u2 = ulo; u2 <= uhi; u2++) {
-                const int x = row[u2];
-                const int df = x > dv ? x - dv : dv - x;
-                cnt += (x >= 0) & (df <= P.thr);
-            }
-        }
-        atomicAdd(&cntw[at >> 2], (uint32_t)cnt << (8 * (at & 3)));   // bytes of one word: other lanes
-    }
-    __syncthreads();
     for (int k = tid; k < nalive; k += 512) {
         const int at = alive[k];
         const int c0 = (cntw[at >> 2] >> (8 * (at & 3))) & 255;
@@ -208,6 +191,56 @@ __device__ __forceinline__ void lattice_consistency_sweeps(int16_t* val, int nc,
 }
 
 // ---------------------------------------------------------------------------
+// Step 1 of the consistency filter for the whole group, on as many workgroups as the lattice has
+// tiles: c0(x) = similar valid cells in the (2 ws + 1)^2 window of x on the UNTOUCHED lattice.  This is
+// the bulk of the filter's work (121 cells per candidate with the reference's window) and the only
+// part without a dependence between cells; k_lattice, one workgroup per pair, starts from these
+// counts.  One byte per cell (windows of at most 255 cells), the layout of k_lattice's packed words.
+// ---------------------------------------------------------------------------
+constexpr int LCX = 64, LCY = 16, LCH = 7;   // tile and the largest halo (window 15 x 15)
+__global__ __launch_bounds__(256) void k_lattice_count(StageDev S, LatticeParams P) {
+    __shared__ int16_t s_t[LCY + 2 * LCH][LCX + 2 * LCH];
+    const int pair = blockIdx.z, nc = P.Wc * P.Hc;
+    const int16_t* raw = S.dcan + (size_t)pair * nc;
+    uint8_t* cnt8 = reinterpret_cast<uint8_t*>(S.cntw + (size_t)pair * ((nc + 3) / 4));
+    const int u0 = blockIdx.x * LCX, v0 = blockIdx.y * LCY;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int ws = P.ws, tw = LCX + 2 * ws, th = LCY + 2 * ws;
+    {
+        constexpr int NE = ((LCY + 2 * LCH) * (LCX + 2 * LCH) + 255) / 256;
+        int16_t r[NE];
+#pragma unroll
+        for (int k = 0; k < NE; k++) {   // all loads of a thread in flight before the first store
+            const int i = tid + 256 * k, y = i / tw, x = i - y * tw;
+            const int v = v0 - ws + y, u = u0 - ws + x;
+            r[k] = (i < th * tw && v >= 0 && v < P.Hc && u >= 0 && u < P.Wc) ? raw[v * P.Wc + u] : (int16_t)-1;
+        }
+#pragma unroll
+        for (int k = 0; k < NE; k++) {
+            const int i = tid + 256 * k, y = i / tw, x = i - y * tw;
+            if (i < th * tw) s_t[y][x] = r[k] < 0 ? kInv : r[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < LCY / 4; k++) {
+        const int ty = threadIdx.y + 4 * k, tx = threadIdx.x;
+        const int v = v0 + ty, u = u0 + tx;
+        if (v >= P.Hc || u >= P.Wc) continue;
+        const int dv = s_t[ty + ws][tx + ws];
+        int cnt = 0;
+        if (dv >= 0)
+            for (int y = 0; y <= 2 * ws; y++)
+                for (int x = 0; x <= 2 * ws; x++) {
+                    const int c = s_t[ty + y][tx + x];      // cells outside the lattice hold kInv
+                    const int df = c > dv ? c - dv : dv - c;
+                    cnt += (c >= 0) & (df <= P.thr);
+                }
+        cnt8[v * P.Wc + u] = (uint8_t)cnt;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // E5 / E6 / list / corners.  One block per pair.  kLds: lattice and counters fit LDS (3 bytes per
 // cell); otherwise the lattice is filtered in place in global memory (very large images).
 // ---------------------------------------------------------------------------
@@ -232,10 +265,16 @@ __global__ __launch_bounds__(512) void k_lattice(StageDev S, LatticeParams P) {
     __syncthreads();
     STAMP(1);
     if (P.need > 0) {
-        if ((2 * P.ws + 1) * (2 * P.ws + 1) <= 255 && P.need <= 255)
+        if ((2 * P.ws + 1) * (2 * P.ws + 1) <= 255 && P.need <= 255) {
+            if (kLds) {
+                const uint32_t* cg = S.cntw + (size_t)pair * ncw;     // counts of k_lattice_count
+                for (int i = tid; i < ncw; i += 512) cntw[i] = cg[i];
+            }
             lattice_consistency_events(val, cntw, S.wl + (size_t)pair * 3 * nc, nc, P, s_n);
-        else
+        }
+        else {
             lattice_consistency_sweeps(val, nc, P);
+        }
     }
     STAMP(2);
     // ---- removeRedundantSupportPoints (elas.cpp:213-279 as called at :501-502: distance 5,
@@ -707,6 +746,7 @@ __device__ void dt_merge(const M& m, unsigned* farleft, unsigned innerleft, unsi
 }
 
 struct DtParams {
+    int lds_ints;                 // ints of dynamic LDS of a k_delaunay block
     int lds_cap;                  // points whose records fit the block's LDS (28 bytes per point)
     int xoff;                     // added to x: the left corner points lie at -d in the right image
     int W, H, sup_cap, rec_cap;   // W: columns the points may use (image width + disp_max: the two
@@ -744,7 +784,7 @@ __device__ __forceinline__ void dt_segment(int m, int depth, int i, int* s, int*
 // The recursion of the divide and conquer, bottom-up: all nodes of one depth are independent (one
 // lane each), leaves at `depth` first, the root last.  FL / FR: hull handles (farleft, farright)
 // of the nodes of a depth, by first vertex, two depths alternating.
-template <class M>
+template <int kT, class M>
 __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const int* order, const int* oxy,
                                          unsigned* FL, unsigned* FR, int sup_cap, int64_t* dbg, bool stamp) {
     const int tid = threadIdx.x;
@@ -756,7 +796,7 @@ __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const 
         const unsigned* cfl = FL + (size_t)((d + 1) & 1) * sup_cap;
         const unsigned* cfr = FR + (size_t)((d + 1) & 1) * sup_cap;
         const unsigned tasks = 1u << d;
-        for (unsigned j = tid; j < tasks; j += 256) {
+        for (unsigned j = tid; j < tasks; j += kT) {
             int s, n, base;
             if (!dt_descend(m, d, j, &s, &n, &base)) continue;
             unsigned a, b;
@@ -777,11 +817,19 @@ __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const 
 }
 
 // ---------------------------------------------------------------------------
-// One block per (pair, side).  LDS: column / row histograms of the points.
+// One block of kT threads per (pair, side).  The dynamic LDS block is used three times over:
+//   ranks      column / row histograms and cursors; behind them the packed coordinates and the two
+//              bucket lists when they fit (the rank of a point walks its column and its row bucket:
+//              dependent reads, ~10 per point -- from LDS instead of L2);
+//   cut order  the two rank lists, the partition buffer and the prefix counts (16 bytes per point);
+//   build      the triangle records (28 bytes per point) when they fit.
+// kT = 256 for KITTI-size lattices; 1024 for large ones (1920x1080: 6-12 k points per side), where
+// the chunked loops of the first two phases are 4x shorter per thread.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_delaunay(StageDev S, DtParams P) {
+template <int kT>
+__global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
     extern __shared__ int s_hist[];   // [W + 1] column starts, [H + 1] row starts, then two cursors copies
-    __shared__ int s_scan[256 / 64 + 1];
+    __shared__ int s_scan[kT / 64 + 1];
     const int slot = blockIdx.x, pair = slot >> 1, side = slot & 1, tid = threadIdx.x;
     const int m = S.counts->nsup[pair];
     if (m < 3 || (S.counts->flags[pair] & STG_OVERFLOW)) {
@@ -807,18 +855,23 @@ __global__ __launch_bounds__(256) void k_delaunay(StageDev S, DtParams P) {
     const int nh = 2 * (P.W + P.H) + 2;
 #define STAMP(k) do { if (slot == 0 && tid == 0) S.counts->dbg[k] = wall_clock64(); } while (0)
     STAMP(8);
-    for (int i = tid; i < nh; i += 256) s_hist[i] = 0;
+    for (int i = tid; i < nh; i += kT) s_hist[i] = 0;
     __syncthreads();
 
     // ---- ranks in (x,y) and (y,x) order
+    const bool ldsR = nh + 3 * m <= P.lds_ints;          // coordinates + bucket lists next to the histograms
+    int* lpxy = ldsR ? s_hist + nh : pxy;
+    int* lbx = ldsR ? s_hist + nh + m : bx;
+    int* lby = ldsR ? s_hist + nh + 2 * m : by;
     int bad = 0;
-    for (int p = tid; p < m; p += 256) {
+    for (int p = tid; p < m; p += kT) {
         const int x = (side ? sup[3 * p] - sup[3 * p + 2] : sup[3 * p]) + P.xoff, y = sup[3 * p + 1];
         if (x < 0 || x >= P.W || y < 0 || y >= P.H) {
             bad = 1;
             continue;
         }
         pxy[p] = x | y << 16;
+        if (ldsR) lpxy[p] = x | y << 16;
         atomicAdd(&colstart[x + 1], 1);
         atomicAdd(&rowstart[y + 1], 1);
     }
@@ -833,36 +886,36 @@ __global__ __launch_bounds__(256) void k_delaunay(StageDev S, DtParams P) {
     for (int which = 0; which < 2; which++) {
         int* h = which ? rowstart : colstart;
         const int len = (which ? P.H : P.W) + 1;
-        const int chunk = (len + 255) / 256, a = tid * chunk, b = min(len, a + chunk);
+        const int chunk = (len + kT - 1) / kT, a = tid * chunk, b = min(len, a + chunk);
         int sum = 0;
         for (int i = a; i < b; i++) sum += h[i];
         int tot;
-        int run = block_excl_scan<256>(sum, s_scan, &tot);
+        int run = block_excl_scan<kT>(sum, s_scan, &tot);
         for (int i = a; i < b; i++) {
             run += h[i];
             h[i] = run;
         }
     }
     __syncthreads();
-    for (int i = tid; i < P.W; i += 256) curx[i] = colstart[i];
-    for (int i = tid; i < P.H; i += 256) cury[i] = rowstart[i];
+    for (int i = tid; i < P.W; i += kT) curx[i] = colstart[i];
+    for (int i = tid; i < P.H; i += kT) cury[i] = rowstart[i];
     __syncthreads();
-    for (int p = tid; p < m; p += 256) {
-        const int xy = pxy[p], x = xy & 0xffff, y = xy >> 16;
-        bx[atomicAdd(&curx[x], 1)] = p;
-        by[atomicAdd(&cury[y], 1)] = p;
+    for (int p = tid; p < m; p += kT) {
+        const int xy = lpxy[p], x = xy & 0xffff, y = xy >> 16;
+        lbx[atomicAdd(&curx[x], 1)] = p;
+        lby[atomicAdd(&cury[y], 1)] = p;
     }
     __syncthreads();
     int dup = 0;
-    for (int p = tid; p < m; p += 256) {
-        const int xy = pxy[p], x = xy & 0xffff, y = xy >> 16;
+    for (int p = tid; p < m; p += kT) {
+        const int xy = lpxy[p], x = xy & 0xffff, y = xy >> 16;
         int xr = colstart[x], yr = rowstart[y];
         for (int k = colstart[x]; k < colstart[x + 1]; k++) {
-            const int q = bx[k], qy = pxy[q] >> 16;
+            const int q = lbx[k], qy = lpxy[q] >> 16;
             xr += qy < y;
             dup |= (qy == y) & (q != p);
         }
-        for (int k = rowstart[y]; k < rowstart[y + 1]; k++) yr += (pxy[by[k]] & 0xffff) < x;
+        for (int k = rowstart[y]; k < rowstart[y + 1]; k++) yr += (lpxy[lby[k]] & 0xffff) < x;
         const unsigned e = (unsigned)xr | (unsigned)yr << 16;
         lx[xr] = e;
         ly[yr] = e;
@@ -881,7 +934,18 @@ __global__ __launch_bounds__(256) void k_delaunay(StageDev S, DtParams P) {
     // ---- alternating-cut order (triangle.cpp:5582-5604): level-synchronous stable partitions.
     // lx is sorted by x rank, ly by y rank, inside every segment; a cut by axis a takes the lower
     // half of the a-list and splits the other list the same way, stably.
-    const int chunk = (m + 255) / 256, c0 = tid * chunk, c1 = min(m, c0 + chunk);
+    const int chunk = (m + kT - 1) / kT, c0 = tid * chunk, c1 = min(m, c0 + chunk);
+    if (4 * m <= P.lds_ints) {
+        // the two lists, the partition buffer and the prefix counts move to LDS (the histograms and
+        // the bucket lists are dead; lx / ly were written to memory so that nothing aliased them)
+        unsigned* l0 = reinterpret_cast<unsigned*>(s_hist);
+        for (int i = c0; i < c1; i++) {
+            l0[i] = lx[i];
+            l0[m + i] = ly[i];
+        }
+        lx = l0; ly = l0 + m; tmp = l0 + 2 * m; Pc = l0 + 3 * m;
+        __syncthreads();
+    }
     int depth = 0;
     for (;; depth++) {
         const int axis = depth & 1;
@@ -899,7 +963,7 @@ __global__ __launch_bounds__(256) void k_delaunay(StageDev S, DtParams P) {
         }
         if (!__syncthreads_or(split)) break;
         int tot;
-        int run = block_excl_scan<256>(cnt, s_scan, &tot);
+        int run = block_excl_scan<kT>(cnt, s_scan, &tot);
         for (int i = c0; i < c1; i++) {
             int s, n;
             dt_segment(m, depth, i, &s, &n);
@@ -950,29 +1014,29 @@ __global__ __launch_bounds__(256) void k_delaunay(StageDev S, DtParams P) {
         ml.nbr = ml.ids + 3 * nrec;
         int* vxy = reinterpret_cast<int*>(ml.nbr + 3 * nrec);   // 12 * nrec bytes in: 4-byte aligned
         ml.vxy = vxy;
-        for (int p = tid; p < m; p += 256) vxy[p] = pxy[p];
-        dt_build(ml, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0);
+        for (int p = tid; p < m; p += kT) vxy[p] = pxy[p];
+        dt_build<kT>(ml, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0);
         // corner indices out for k_stage_pack (records 1 .. 2m-2)
-        for (int t = 1 + tid; t < 2 * m - 1; t += 256) {
+        for (int t = 1 + tid; t < 2 * m - 1; t += kT) {
             const unsigned a0 = ml.ids[3 * t], a1 = ml.ids[3 * t + 1], a2 = ml.ids[3 * t + 2];
             *reinterpret_cast<int4*>(mg.ids + 4 * (size_t)t) =
                 make_int4(a0 == 0xffffu ? -1 : (int)a0, a1 == 0xffffu ? -1 : (int)a1, a2 == 0xffffu ? -1 : (int)a2, 0);
         }
         __syncthreads();
     } else {
-        dt_build(mg, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0);
+        dt_build<kT>(mg, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0);
     }
     const MeshG& mesh = mg;
     // ---- surviving records = those without the ghost corner (the hull fan dies,
     // triangle.cpp:7800-7860); k_stage_pack writes them out in creation order
     const int nrec = 2 * m - 1;   // records 1 .. 2m-2
     int live = 0;
-    for (int t = 1 + tid; t < nrec; t += 256) {
+    for (int t = 1 + tid; t < nrec; t += kT) {
         const int4 v = *reinterpret_cast<const int4*>(mesh.ids + 4 * (size_t)t);
         live += (v.x >= 0) & (v.y >= 0) & (v.z >= 0);
     }
     int tot;
-    block_excl_scan<256>(live, s_scan, &tot);
+    block_excl_scan<kT>(live, s_scan, &tot);
     if (tid == 0) S.counts->ntri[slot] = tot;
     STAMP(30);
 #undef STAMP
@@ -1062,8 +1126,12 @@ struct Timed {
 // columns the points of a triangulation may use: x + disp_max in [0, W + 2 disp_max] (corner points
 // of addCornerSupportPoints: -d in the right image, W-1+d in the left one)
 static int dt_columns(const svh_elas_params& p, const Dims& d) { return d.W + 2 * std::max(p.disp_max, 0) + 1; }
+// large lattices (1920x1080: 83 k cells, 6-12 k support points per side) get the whole LDS of a CU: the
+// rank lists of the cut-order phase take 16 bytes per point
+static bool dt_large(const Dims& d) { return (size_t)d.Wc * d.Hc / 8 * 16 > 63 * 1024; }
 static size_t dt_lds_bytes(const svh_elas_params& p, const Dims& d) {
-    return std::max<size_t>(4 * (size_t)(2 * (dt_columns(p, d) + d.H) + 2), 63 * 1024);
+    const size_t hist = 4 * (size_t)(2 * (dt_columns(p, d) + d.H) + 2);
+    return dt_large(d) ? std::max<size_t>(hist, 159 * 1024) : std::max<size_t>(hist, 63 * 1024);
 }
 
 bool stage_device_ok(const svh_elas_params& p, const Dims& d) {
@@ -1073,12 +1141,17 @@ bool stage_device_ok(const svh_elas_params& p, const Dims& d) {
     return 4 * (size_t)(2 * (wx + d.H) + 2) <= 63 * 1024 && wx < (1 << 14) && d.H < (1 << 14);
 }
 
-// automatic mode takes the device stage only where it is the faster one: lattices that k_lattice
-// holds in LDS (up to ~20 k cells: KITTI-size images).  On 1920x1080 pairs (83 k cells, 5-8 k
-// support points: records in L2 instead of LDS) the two host threads per pair are still ahead.
-bool stage_device_preferred(const svh_elas_params& p, const Dims& d) {
+// automatic mode takes the device stage where it is the faster one.  Lattices that k_lattice holds in
+// LDS (up to ~20 k cells: KITTI-size images): always for batches.  Large lattices (1920x1080: 83 k cells
+// filtered in L2, 6-12 k support points per side with 32-bit records in L2): a group takes ~2 ms through
+// k_lattice + k_delaunay against ~1.2 ms on two host threads, so the host stage wins a latency-bound
+// batch of 8 pairs (3.2 k vs 1.7 k pairs/s, with 7 host cores) and the device stage a deep one (64
+// pairs: 4.3-4.7 k vs 3.4 k pairs/s, with 0.1 host cores); svh_elas_set_stage(1) forces it where host
+// cores are scarce (8 ranks on a 16-core quota).
+bool stage_device_preferred(const svh_elas_params& p, const Dims& d, bool deep_batch) {
     const size_t nc = (size_t)d.Wc * d.Hc;
-    return stage_device_ok(p, d) && 2 * ((nc + 1) & ~(size_t)1) + 4 * ((nc + 3) / 4) <= 62 * 1024;
+    if (!stage_device_ok(p, d)) return false;
+    return deep_batch || 2 * ((nc + 1) & ~(size_t)1) + 4 * ((nc + 3) / 4) <= 62 * 1024;
 }
 
 void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g, const StageDev& S,
@@ -1090,6 +1163,11 @@ void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Di
     L.add_corners = p.add_corners; L.sup_cap = S.sup_cap;
     const size_t nc = (size_t)d.Wc * d.Hc;
     const size_t lat_bytes = 2 * ((nc + 1) & ~(size_t)1) + 4 * ((nc + 3) / 4);   // cells + count bytes
+    if (L.need > 0 && (2 * L.ws + 1) * (2 * L.ws + 1) <= 255 && L.need <= 255) {
+        Timed t(cx, "k_lattice_count");
+        hipLaunchKernelGGL(k_lattice_count, dim3((d.Wc + LCX - 1) / LCX, (d.Hc + LCY - 1) / LCY, g), dim3(64, 4), 0, s,
+                           S, L);
+    }
     {
         Timed t(cx, "k_lattice");
         if (lat_bytes <= 62 * 1024)
@@ -1101,10 +1179,18 @@ void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Di
     D.W = dt_columns(p, d); D.H = d.H; D.sup_cap = S.sup_cap; D.rec_cap = S.rec_cap;
     D.xoff = std::max(p.disp_max, 0);
     const size_t dt_lds = dt_lds_bytes(p, d);
+    D.lds_ints = (int)(dt_lds / 4);
     D.lds_cap = (int)std::min<size_t>((dt_lds - 32) / 28 - 1, 8000);   // 16-bit handles: < 8191 points
     {
         Timed t(cx, "k_delaunay");
-        hipLaunchKernelGGL(k_delaunay, dim3(2 * g), dim3(256), dt_lds, s, S, D);
+        if (dt_large(d)) {
+            static const bool ok = hipFuncSetAttribute((const void*)k_delaunay<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       159 * 1024) == hipSuccess;
+            (void)ok;
+            hipLaunchKernelGGL(k_delaunay<1024>, dim3(2 * g), dim3(1024), dt_lds, s, S, D);
+        } else {
+            hipLaunchKernelGGL(k_delaunay<256>, dim3(2 * g), dim3(256), dt_lds, s, S, D);
+        }
     }
     {
         Timed t(cx, "k_stage_pack");

@@ -108,7 +108,7 @@ struct LaunchCtx;
 // the image geometry fits the device stage (LDS histograms, 14-bit coordinates)
 bool stage_device_ok(const svh_elas_params& p, const Dims& d);
 // ... and it is expected to beat the host stage there (what automatic mode asks)
-bool stage_device_preferred(const svh_elas_params& p, const Dims& d);
+bool stage_device_preferred(const svh_elas_params& p, const Dims& d, bool deep_batch = false);
 
 // ---------------------------------------------------------------- device
 // Kernel launchers (elas_kernels.hip).  LaunchCtx carries the hipStream_t (as

@@ -1,6 +1,6 @@
 """The secondary legs of bench.py on their own (Matcher, visual odometry, map fusion), so that a
 rocprofv3 kernel trace of this script shows their kernels only:
-    rocprofv3 --kernel-trace --stats -- python tools/gpu_legs.py [matcher|vo|map]"""
+    rocprofv3 --kernel-trace --stats -- python tools/gpu_legs.py [matcher|vo|map|replicas[K]]"""
 import json
 import os
 import sys
@@ -20,4 +20,7 @@ if which in ("vo", "all"):
     out["visual_odometry"] = bench.vo_bench(iters=60)
 if which in ("map", "all"):
     out["map_fusion"] = bench.map_bench(iters=40)
+if which.startswith("replicas"):   # replicas, replicas16, ...
+    ks = (int(which[8:]),) if which[8:] else (1, 4, 16)
+    out["vo_replicas"] = bench.vo_replicas_bench(ks=ks, frames=60)
 print(json.dumps(out))
