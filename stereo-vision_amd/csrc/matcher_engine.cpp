@@ -19,17 +19,35 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
-#include <string>
+#include <atomic>
 #include <chrono>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "matcher_internal.h"
+#include "vo_internal.h"
 
 namespace svh {
 
 int fail(int code, const std::string& msg);   // elas_engine.cpp: sets svh_last_error()
 static int mfail(int code, const std::string& msg) { return fail(code, msg); }
+
+static std::atomic<int> g_live_matchers{0};
+int wait_stream(void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    static const int forced = getenv("SVH_MATCHER_WAIT") ? atoi(getenv("SVH_MATCHER_WAIT")) : -1;   // 0 spin, 1 sleep-poll
+    const bool poll = forced >= 0 ? forced == 1 : g_live_matchers.load(std::memory_order_relaxed) > 1;
+    if (!poll) return (int)hipStreamSynchronize(s);
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return (int)e;
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
 
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
@@ -306,7 +324,10 @@ static int remove_outliers(const svh_matcher_params& p, std::vector<svh_p_match>
     std::vector<int32_t> tri((size_t)3 * (2 * n + 16));
     // the Matcher is a single-stream, latency-bound path: large votes triangulate on 4 threads
     static const int par = getenv("SVH_DELAUNAY_PAR") ? atoi(getenv("SVH_DELAUNAY_PAR")) : 2;
-    const int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 16, n >= 1500 ? par : 0);
+    // (several live Matcher objects = several sequences on this GPU: their host threads already fill the
+    // cores, the helper pool would only be fought over)
+    const bool alone = g_live_matchers.load(std::memory_order_relaxed) <= 1;
+    const int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 16, (n >= 1500 && alone) ? par : 0);
     if (nt < 0) return mfail(SVH_ERR_UNSUPPORTED, "outlier triangulation failed");
     std::vector<int32_t> votes(n, 0);
     const float ft = (float)p.outlier_flow_tolerance, dt = (float)p.outlier_disp_tolerance;
@@ -442,7 +463,7 @@ static int run_matching(svh_matcher* m, int dense, int32_t method, bool use_prio
         HIP_TRY(hipMemcpyAsync(m->h_cnt, result_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         if (nq > 0)
             HIP_TRY(hipMemcpyAsync(m->h_pm, result, (size_t)nq * sizeof(svh_p_match), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY((hipError_t)wait_stream(s));
         HIP_TRY(hipGetLastError());
         const int32_t count = std::min(*m->h_cnt, nq);
         dst.assign(m->h_pm, m->h_pm + count);
@@ -491,6 +512,7 @@ void svh_matcher_params_default(svh_matcher_params* p) {
 svh_matcher* svh_matcher_create(const svh_matcher_params* p) {
     if (!p) return nullptr;
     svh_matcher* m = new svh_matcher();
+    g_live_matchers++;
     m->p = *p;
     m->margin = 8 + 1;                                      // matcher.cpp:56
     if (p->half_resolution) m->p.match_radius /= 2;         // matcher.cpp:59-62
@@ -504,6 +526,7 @@ svh_matcher* svh_matcher_create(const svh_matcher_params* p) {
 
 void svh_matcher_destroy(svh_matcher* m) {
     if (!m) return;
+    g_live_matchers--;
     if (g_mtiming && m->tcalls[0] && m->tcalls[1]) {
         const double a = 1.0 / (double)m->tcalls[0], b = 1.0 / (double)m->tcalls[1];
         fprintf(stderr, "[svh matcher timing] pushBack: pack+enqueue %.3f ms, gpu wait %.3f ms | matchFeatures: "
@@ -580,8 +603,8 @@ int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* 
         if (rc) return rc;
     }
     const double t1 = g_mtiming ? mnow_ms() : 0;
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream2));
+    HIP_TRY((hipError_t)wait_stream(m->stream));
+    HIP_TRY((hipError_t)wait_stream(m->stream2));
     HIP_TRY(hipGetLastError());
     for (int k = 0; k < 2; k++)
         if (src[k]) {

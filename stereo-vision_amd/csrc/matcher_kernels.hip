@@ -655,46 +655,87 @@ __global__ __launch_bounds__(256) void k_refine_group(svh_p_match* __restrict__ 
 }
 
 // Matrix::solve, 6x6 with one right-hand side   libviso2/src/matrix.cpp:648-760
-// (same operation order as the reference's double code; IEEE ops, no contraction)
-__device__ bool solve6(double* A, double* B) {
+// The matrix of parabolicFitting is A^T A of a CONSTANT 9x6 design matrix (matcher.cpp:1725-1733), so
+// the Gauss-Jordan elimination with full pivoting takes the same pivots and the same multipliers for
+// every match: they are evaluated at compile time (IEEE double, one rounding per operation, no
+// contraction -- the reference's operation sequence), and the kernel only replays what the elimination
+// does to the right-hand side: swap, scale by 1/pivot, subtract multiples -- 36 double operations on
+// registers instead of a 6x6 elimination with data-dependent indexing (which lived in scratch).
+struct Solve6Prog {
+    int irow[6], icol[6];
+    double pivinv[6];
+    double dum[6][6];
+    bool ok;
+};
+constexpr double kFA[9][6] = {{1, 1, 1, -1, -1, 1}, {0, 1, 0, 0, -1, 1}, {1, 1, -1, 1, -1, 1},
+                              {1, 0, 0, -1, 0, 1},  {0, 0, 0, 0, 0, 1},  {1, 0, 0, 1, 0, 1},
+                              {1, 1, -1, -1, 1, 1}, {0, 1, 0, 0, 1, 1},  {1, 1, 1, 1, 1, 1}};
+constexpr double cabs_(double x) { return x < 0 ? -x : x; }
+constexpr Solve6Prog make_solve6_prog() {
+    Solve6Prog P{};
+    double A[36] = {};
+    for (int r = 0; r < 6; r++)
+        for (int e = 0; e < 6; e++) {
+            double s = 0.0;
+            for (int q = 0; q < 9; q++) s = s + kFA[q][r] * kFA[q][e];
+            A[r * 6 + e] = s;
+        }
     int ipiv[6] = {0, 0, 0, 0, 0, 0};
+    P.ok = true;
     for (int it = 0; it < 6; it++) {
         double big = 0.0;
         int irow = 0, icol = 0;
         for (int j = 0; j < 6; j++)
             if (ipiv[j] != 1)
                 for (int q = 0; q < 6; q++)
-                    if (ipiv[q] == 0 && fabs(A[j * 6 + q]) >= big) {
-                        big = fabs(A[j * 6 + q]);
+                    if (ipiv[q] == 0 && cabs_(A[j * 6 + q]) >= big) {
+                        big = cabs_(A[j * 6 + q]);
                         irow = j;
                         icol = q;
                     }
         ++ipiv[icol];
-        if (irow != icol) {
+        if (irow != icol)
             for (int l = 0; l < 6; l++) {
-                const double s = A[irow * 6 + l];
+                const double t = A[irow * 6 + l];
                 A[irow * 6 + l] = A[icol * 6 + l];
-                A[icol * 6 + l] = s;
+                A[icol * 6 + l] = t;
             }
-            const double s = B[irow];
-            B[irow] = B[icol];
-            B[icol] = s;
-        }
-        if (fabs(A[icol * 6 + icol]) < 1e-20) return false;
-        const double pivinv = __ddiv_rn(1.0, A[icol * 6 + icol]);
+        P.irow[it] = irow;
+        P.icol[it] = icol;
+        if (cabs_(A[icol * 6 + icol]) < 1e-20) P.ok = false;
+        const double pivinv = 1.0 / A[icol * 6 + icol];
+        P.pivinv[it] = pivinv;
         A[icol * 6 + icol] = 1.0;
-        for (int l = 0; l < 6; l++) A[icol * 6 + l] = __dmul_rn(A[icol * 6 + l], pivinv);
-        B[icol] = __dmul_rn(B[icol], pivinv);
-        for (int ll = 0; ll < 6; ll++)
+        for (int l = 0; l < 6; l++) A[icol * 6 + l] = A[icol * 6 + l] * pivinv;
+        for (int ll = 0; ll < 6; ll++) {
+            P.dum[it][ll] = 0.0;
             if (ll != icol) {
                 const double dum = A[ll * 6 + icol];
+                P.dum[it][ll] = dum;
                 A[ll * 6 + icol] = 0.0;
-                for (int l = 0; l < 6; l++)
-                    A[ll * 6 + l] = __dsub_rn(A[ll * 6 + l], __dmul_rn(A[icol * 6 + l], dum));
-                B[ll] = __dsub_rn(B[ll], __dmul_rn(B[icol], dum));
+                for (int l = 0; l < 6; l++) A[ll * 6 + l] = A[ll * 6 + l] - A[icol * 6 + l] * dum;
             }
+        }
     }
-    return true;
+    return P;
+}
+constexpr Solve6Prog kSolve6 = make_solve6_prog();
+static_assert(kSolve6.ok, "A^T A of the quadratic fit is regular");
+
+__device__ __forceinline__ void solve6_rhs(double (&B)[6]) {
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+        const int irow = kSolve6.irow[it], icol = kSolve6.icol[it];
+        if (irow != icol) {
+            const double t = B[irow];
+            B[irow] = B[icol];
+            B[icol] = t;
+        }
+        B[icol] = __dmul_rn(B[icol], kSolve6.pivinv[it]);
+#pragma unroll
+        for (int ll = 0; ll < 6; ll++)
+            if (ll != icol) B[ll] = __dsub_rn(B[ll], __dmul_rn(B[icol], kSolve6.dum[it][ll]));
+    }
 }
 
 // M11'  Matcher::parabolicFitting   matcher.cpp:1574-1662 (refinement == 2); false drops the match
@@ -704,39 +745,38 @@ __device__ bool parabolic(const SobelView& s1, const SobelView& s2, int margin, 
         return false;
     uint32_t ref[4], d[4];
     small_desc(s1.du, s1.dv, s1.bpl, (int)u1, (int)v1, ref);
-    int cost[49];
-    int min_ind = 0, min_cost = 0;
-    for (int q = 0; q < 49; q++) {
-        small_desc(s2.du, s2.dv, s2.bpl, (int)*u2 + q % 7 - 3, (int)*v2 + q / 7 - 3, d);
+    auto cost_at = [&](int q7u, int q7v) {
+        small_desc(s2.du, s2.dv, s2.bpl, (int)*u2 + q7u - 3, (int)*v2 + q7v - 3, d);
         uint32_t c = 0;
 #pragma unroll
         for (int w = 0; w < 4; w++) c = __builtin_amdgcn_sad_u8(ref[w], d[w], c);
-        cost[q] = (int)c;
-        if (q == 0 || (int)c < min_cost) {
+        return (int)c;
+    };
+    int min_ind = 0, min_cost = 0;
+    for (int q = 0; q < 49; q++) {
+        const int c = cost_at(q % 7, q / 7);
+        if (q == 0 || c < min_cost) {
             min_ind = q;
-            min_cost = (int)c;
+            min_cost = c;
         }
     }
     const int du = min_ind % 7, dv = min_ind / 7;
     if (du == 0 || du == 6 || dv == 0 || dv == 6) return false;
-    // design matrix of the 3x3 quadratic fit (matcher.cpp:1725-1733)
-    const double FA[9][6] = {{1, 1, 1, -1, -1, 1}, {0, 1, 0, 0, -1, 1}, {1, 1, -1, 1, -1, 1},
-                             {1, 0, 0, -1, 0, 1},  {0, 0, 0, 0, 0, 1},  {1, 0, 0, 1, 0, 1},
-                             {1, 1, -1, -1, 1, 1}, {0, 1, 0, 0, 1, 1},  {1, 1, 1, 1, 1, 1}};
-    double c9[9], b[6], AtA[36];
+    // the 3x3 costs around the minimum (evaluated again: nine small descriptors instead of a
+    // 49-entry array with a data-dependent index), design matrix of the fit: matcher.cpp:1725-1733
+    double c9[9], b[6];
+#pragma unroll
     for (int i = -1; i <= 1; i++)
-        for (int j = -1; j <= 1; j++) c9[(i + 1) * 3 + (j + 1)] = (double)cost[(dv + i) * 7 + (du + j)];
+#pragma unroll
+        for (int j = -1; j <= 1; j++) c9[(i + 1) * 3 + (j + 1)] = (double)cost_at(du + j, dv + i);
+#pragma unroll
     for (int r = 0; r < 6; r++) {
         double acc = 0.0;
-        for (int q = 0; q < 9; q++) acc = __dadd_rn(acc, __dmul_rn(FA[q][r], c9[q]));
+#pragma unroll
+        for (int q = 0; q < 9; q++) acc = __dadd_rn(acc, __dmul_rn(kFA[q][r], c9[q]));
         b[r] = acc;
-        for (int e = 0; e < 6; e++) {
-            double s = 0.0;
-            for (int q = 0; q < 9; q++) s = __dadd_rn(s, __dmul_rn(FA[q][r], FA[q][e]));
-            AtA[r * 6 + e] = s;
-        }
     }
-    if (!solve6(AtA, b)) return false;
+    solve6_rhs(b);
     const float divisor = (float)__dsub_rn(__dmul_rn(b[2], b[2]), __dmul_rn(__dmul_rn(4.0, b[0]), b[1]));
     if ((double)fabsf(divisor) < 1e-8 || fabs(b[2]) < 1e-8) return false;
     const float ddv = (float)__ddiv_rn(

@@ -163,7 +163,7 @@ int estimate(svh_vo* v, const svh_p_match* pm, int32_t N, double* tr6) {
     vlaunch_estimate(s, reinterpret_cast<const svh_p_match*>(v->d_in), N,
                      reinterpret_cast<const int32_t*>(v->d_in + m_bytes), iters, c, v->d_hyp_tr,
                      v->d_hyp_count, v->d_flags, v->d_J, v->d_res, v->h_out, v->h_inl);
-    VO_TRY(hipStreamSynchronize(s));
+    VO_TRY((hipError_t)wait_stream(s));
     VO_TRY(hipGetLastError());
     const VoResult& r = *v->h_out;
     v->inliers.assign(v->h_inl, v->h_inl + r.n_inliers);

@@ -20,6 +20,12 @@ struct VoResult {          // written by k_vo_refine into pinned host memory
     int32_t pad_;
 };
 
+// Wait for a stream of a Matcher / visual-odometry object.  One live object: the driver's spinning
+// wait (lowest latency for the single-sequence case of stereomapper).  Several live objects in the
+// process (K independent sequences on one GPU): polling with short sleeps, so that K host threads do
+// not burn K cores spinning on a GPU they share (matcher_engine.cpp keeps the count).
+int wait_stream(void* stream);   // returns a hipError_t value
+
 // pinned host -> device copy by a kernel (bytes is a multiple of 16)
 void vlaunch_upload(void* stream, const uint8_t* pinned, uint8_t* dev, size_t bytes);
 void vlaunch_estimate(void* stream, const svh_p_match* pm, int N, const int32_t* samples, int iters,
