@@ -147,6 +147,7 @@ struct Lane {
     float* tmp = nullptr;          // [gcap][2][DN]
     int32_t* labels = nullptr;
     int32_t* counts = nullptr;
+    int32_t* seg_nroots = nullptr;   // [2 * gcap][tiles] tile-local roots per 64 x 16 tile (k_seg_tile -> k_seg_sum)
     // pinned host
     int16_t* h_dcan = nullptr;
     uint8_t* h_img = nullptr;
@@ -172,7 +173,7 @@ struct Lane {
         (void)hipFree(img); (void)hipFree(desc); (void)hipFree(dcan); (void)hipFree(owner);
         (void)hipFree(prior_dev); (void)hipFree(raster); (void)hipFree(planes); (void)hipFree(seed);
         (void)hipFree(mask); (void)hipFree(Draw); (void)hipFree(D); (void)hipFree(tmp);
-        (void)hipFree(labels); (void)hipFree(counts);
+        (void)hipFree(labels); (void)hipFree(counts); (void)hipFree(seg_nroots); seg_nroots = nullptr;
         img = desc = prior_dev = nullptr; dcan = nullptr; owner = nullptr; raster = nullptr;
         planes = Draw = D = tmp = nullptr; seed = mask = nullptr; labels = counts = nullptr;
         (void)hipHostFree(h_dcan); (void)hipHostFree(h_prior); (void)hipHostFree(h_img);
@@ -227,6 +228,7 @@ struct Lane {
         HIP_TRY(hipMalloc(&tmp, G2 * DN * sizeof(float)));
         HIP_TRY(hipMalloc(&labels, G2 * DN * sizeof(int32_t)));
         HIP_TRY(hipMalloc(&counts, G2 * DN * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&seg_nroots, G2 * (size_t)((d.DW + 63) / 64) * ((d.DH + 15) / 16) * sizeof(int32_t)));   // one count per 64 x 16 tile
         const size_t nc = (size_t)d.Wc * d.Hc;
         HIP_TRY(hipMalloc(&dcan, g * nc * sizeof(int16_t)));
         HIP_TRY(hipHostMalloc(&h_dcan, g * nc * sizeof(int16_t)));
@@ -597,7 +599,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
             rc = tap_dev(L, taps, SVH_ELAS_D1_RAW, L.Draw, DN); if (rc) return rc;
             rc = tap_dev(L, taps, SVH_ELAS_D2_RAW, L.Draw + DN, DN); if (rc) return rc;
         }
-        const PostScratch ps = {L.tmp, L.labels, L.counts};
+        const PostScratch ps = {L.tmp, L.labels, L.counts, L.seg_nroots};
         const int nside = p.postprocess_only_left ? 1 : 2;
         if (!lr_done) launch_lr(cx, p, d, g, G, out);
         if (tapping) {
@@ -1136,9 +1138,9 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
     const int32_t G = group_for((size_t)dims[0] * dims[1]);
     const int32_t ngroups = (n + G - 1) / G;
     const int lanes = std::min<int>(g_lanes.load(), ngroups);
-    // automatic stage choice: 1 = a batch, 2 = a deep batch (several rounds of groups per worker: what
-    // counts is throughput, not the latency of one group -- the device stage also for large lattices)
-    const int deep = ngroups >= 4 * lanes ? 2 : 1;
+    // automatic stage choice: 1 = a batch, 2 = a deep batch (32 pairs or more: what counts is throughput,
+    // not the ~2 ms a group of large lattices spends in k_lattice + k_delaunay -- the device stage there too)
+    const int deep = n >= 32 ? 2 : 1;
     std::vector<int32_t> st(n, SVH_OK);
     std::vector<int32_t> grc(ngroups, SVH_OK);
     std::vector<std::string> errs(std::max(lanes, 1));

@@ -425,15 +425,16 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
     // half of its neighbour; support_match_rows assigns the disparities of a trip to the lanes of a
     // row so that lane position p always reads a slot congruent to p modulo 16, in the forward and
     // in the backward search alike: every phase covers the 16 slots of the bank array once.
-    static_assert(kST / kWave == 8 && kSB == 32, "one row of 16 lanes per candidate, 8 waves");
+    static_assert(kST / kWave == 8 && (kSB == 32 || kSB == 64), "one row of 16 lanes per candidate, 8 waves");
     const int grp = lane >> 4;
     const int gl = lane & 15;
-    // forward search: every candidate of the block (row 4*wave' .. of the block's 32 rows)
+    // forward search: every candidate of the block, 32 per round (4 per wave)
     __shared__ int16_t s_fwd[kSB];     // forward disparity per candidate, -1 = none
     __shared__ uint8_t s_todo[kSB];    // candidates that need the backward search, compacted
     __shared__ int s_ntodo;
-    {
-        const int c = wave + grp * (kST / kWave);
+#pragma unroll
+    for (int rep = 0; rep < kSB / 32; rep++) {
+        const int c = rep * 32 + wave + grp * (kST / kWave);
         const bool have = c < ncand;
         const int uc = uc0 + (have ? c : 0), u = uc * P.step;
         const bool in = have && uc > 0 && u >= 5 && u <= P.W - 6;
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
     __syncthreads();
     // Only the candidates whose forward search produced a disparity (about half of them) are
     // searched backwards.  They are compacted first, so that the backward searches fill whole
-    // waves and the remaining waves retire instead of idling through the trips of their neighbours.
+    // waves (with 64 candidates per block: usually all eight of them, like the forward rounds).
     if (wave == 0) {
         const int mine = lane < kSB ? (int)s_fwd[lane] : -1;
         const uint64_t mask = __builtin_amdgcn_ballot_w64(mine >= 0);
@@ -455,9 +456,8 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
     }
     __syncthreads();
     const int ntodo = s_ntodo;
-    if (4 * wave >= ntodo) return;
-    {
-        const int t = 4 * wave + grp;
+    for (int t0 = 4 * wave; t0 < ntodo; t0 += 4 * (kST / kWave)) {
+        const int t = t0 + grp;
         const bool have = t < ntodo;
         const int c = have ? (int)s_todo[t] : 0;
         const int d = have ? (int)s_fwd[c] : 0;
@@ -1186,9 +1186,11 @@ __global__ __launch_bounds__(256) void k_seg_tile(GroupDev G, DevMaps m, PostScr
     __shared__ float sD[CY][CX];
     __shared__ int sL[CX * CY];
     __shared__ int sC[CX * CY];
+    __shared__ int s_nr;           // tile-local roots listed so far
     int pair;
     const float* D = post_map(m, blockIdx.z, nside, &pair);
     if (!G.hdr->active[pair]) return;
+    if (threadIdx.y == 0 && threadIdx.x == 0) s_nr = 0;   // (three barriers before its first use)
     const size_t zo = (size_t)blockIdx.z * DW * DH;
     const int x0 = blockIdx.x * CX, y0 = blockIdx.y * CY;
     const int tx = threadIdx.x;   // lane: a wave owns whole tile rows ty = threadIdx.y + 4k
@@ -1272,8 +1274,19 @@ __global__ __launch_bounds__(256) void k_seg_tile(GroupDev G, DevMaps m, PostScr
             if (root == i) size = sC[i];   // this pixel is the tile-local root
         }
         S.labels[zo + gi] = label;
-        S.counts[zo + gi] = size;   // > 0 exactly at the tile-local roots: also their marker for k_seg_sum
+        S.counts[zo + gi] = size;   // > 0 exactly at the tile-local roots
+        // The tile-local roots are listed per tile (in `tmp`, which is free until k_gap_tile; a tile's
+        // list starts where its pixels would start if the map were stored tile by tile, so it can hold
+        // every pixel of the tile): k_seg_sum visits a few roots per tile instead of scanning the counts
+        // of every pixel.  Positions from an LDS counter, the tile's count is written once.
+        if (size > 0) {
+            const int bh = min(CY, DH - y0);                    // rows of this band of tiles
+            reinterpret_cast<int32_t*>(S.tmp)[zo + (size_t)y0 * DW + (size_t)x0 * bh + atomicAdd(&s_nr, 1)] = gi;
+        }
     }
+    __syncthreads();
+    if (threadIdx.y == 0 && tx == 0)
+        S.nroots[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s_nr;
 }
 
 // unions across tile borders: one thread per pixel of a tile's first row / column
@@ -1314,18 +1327,26 @@ __global__ __launch_bounds__(256) void k_seg_border(GroupDev G, DevMaps m, PostS
     uf_union(L, L[i], L[i - step]);
 }
 
-// add the local size of every merged tile-local component to its global root
-__global__ __launch_bounds__(256) void k_seg_sum(GroupDev G, PostScratch S, int nside, int n,
+// add the local size of every merged tile-local component to its global root: one wave per tile of
+// k_seg_tile walks that tile's list of roots
+__global__ __launch_bounds__(256) void k_seg_sum(GroupDev G, PostScratch S, int nside, int DW, int DH,
                                                  int min_size) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
     if (!G.hdr->active[blockIdx.y / nside]) return;
+    const int n = DW * DH;
     const size_t zo = (size_t)blockIdx.y * n;
-    // a tile-local root that is not a global root is never added to, so its entry still is the
-    // tile-local size written by k_seg_tile (the seam merges of k_seg_border changed labels only)
-    const int size = S.counts[zo + i];
-    if (size > 0) {
-        int32_t* L = S.labels + zo;
+    const int tcols = (DW + CX - 1) / CX, trows = (DH + CY - 1) / CY;
+    const int tile = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= tcols * trows) return;
+    const int ty = tile / tcols, tx = tile - ty * tcols;
+    const int y0 = ty * CY, x0 = tx * CX, bh = min(CY, DH - y0);
+    const int nroots = S.nroots[(size_t)blockIdx.y * tcols * trows + tile];
+    const int32_t* list = reinterpret_cast<const int32_t*>(S.tmp) + zo + (size_t)y0 * DW + (size_t)x0 * bh;
+    int32_t* L = S.labels + zo;
+    for (int k = lane; k < nroots; k += 64) {
+        // a tile-local root that is not a global root is never added to, so its entry still is the
+        // tile-local size written by k_seg_tile (the seam merges of k_seg_border changed labels only)
+        const int i = list[k];
+        const int size = S.counts[zo + i];
         const int root = uf_find(L, i);
         if (root != i) {
             L[i] = root;
@@ -1635,7 +1656,8 @@ void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d
     P.support_threshold = p.support_threshold;
     // LDS need of the staged kernel: two rows of both strips (16 B slots).  32 candidates per
     // 512-thread block was the best of the block shapes tried (16/256 ... 128/1024: all within 3 %).
-    constexpr int sb = 32;
+    static const int sb_env = getenv("SVH_SUPPORT_SB") ? atoi(getenv("SVH_SUPPORT_SB")) : 64;
+    const int sb = sb_env == 32 ? 32 : 64;
     const int span = (sb - 1) * d.step;
     const size_t wl = (size_t)std::min(d.W, span + 2 * p.disp_max + 5);
     const size_t wr = (size_t)std::min(d.W, span + p.disp_max + 5);
@@ -1645,7 +1667,10 @@ void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d
         // (pairs * lattice rows rounded up to 8) * chunks blocks: XCD-aware order, see the kernel
         const int chunks = (d.Wc + sb - 1) / sb;
         const dim3 grid((unsigned)(((d.Hc * g + 7) / 8) * 8 * chunks), 1, 1);
-        hipLaunchKernelGGL((k_support_lds<sb, 512>), grid, dim3(512), lds, (hipStream_t)cx.stream, desc, dcan, P);
+        if (sb == 32)
+            hipLaunchKernelGGL((k_support_lds<32, 512>), grid, dim3(512), lds, (hipStream_t)cx.stream, desc, dcan, P);
+        else
+            hipLaunchKernelGGL((k_support_lds<64, 512>), grid, dim3(512), lds, (hipStream_t)cx.stream, desc, dcan, P);
     } else {
         const int cands = d.Wc * d.Hc;
         LAUNCH("k_support", k_support, dim3((cands + 3) / 4, g), dim3(256), desc, dcan, P);
@@ -1776,7 +1801,7 @@ void launch_segments_label(const LaunchCtx& cx, const svh_elas_params& p, const 
     if (nhor + nver > 0)
         LAUNCH("k_seg_border", k_seg_border, dim3((nhor + nver + 255) / 256, z), b256, G, in, S, nside,
                d.DW, d.DH, p.speckle_sim_threshold, nhor);
-    LAUNCH("k_seg_sum", k_seg_sum, lin, b256, G, S, nside, n, min_size);
+    LAUNCH("k_seg_sum", k_seg_sum, dim3((tiles.x * tiles.y + 3) / 4, z), b256, G, S, nside, d.DW, d.DH, min_size);
 }
 
 

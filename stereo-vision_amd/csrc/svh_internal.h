@@ -182,6 +182,7 @@ struct PostScratch {
     float* tmp;
     int32_t* labels;
     int32_t* counts;   // tile-local sizes at tile roots (0 elsewhere), then component sizes at roots
+    int32_t* nroots;   // [g * nside][tiles] tile-local roots per 64 x 16 tile; their pixel indices are listed in `tmp`
 };
 // default configuration only (see post_tiles_ok): gap interpolation + adaptive mean as two tile
 // kernels (D -> tmp -> D); the caller must skip launch_gap / launch_adaptive_mean then

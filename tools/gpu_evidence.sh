@@ -12,7 +12,12 @@ cd $R
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err
 timeout 600 python bench.py --gpus 2 --steps 10 --warmup 2 --dist-backend gloo --no-extras --no-cpu-baseline > $O/bench_line_2ranks_gloo_1gpu.json 2> /dev/null
 timeout 600 python bench.py --workload hd1080 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_line_hd1080.json 2> /dev/null
-timeout 600 python bench.py --workload hd1080 --batch 64 --group 4 --lanes 8 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_x64.json 2> /dev/null
+timeout 600 python bench.py --workload hd1080 --stage device --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_device_stage.json 2> /dev/null
+timeout 600 python bench.py --workload hd1080 --batch 64 --group 8 --lanes 6 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_x64.json 2> /dev/null
+timeout 600 python bench.py --workload hd1080 --stage host --batch 64 --group 4 --lanes 8 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_x64_host_stage.json 2> /dev/null
+timeout 600 python bench.py --lanes 3 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_lanes3.json 2> /dev/null
+timeout 600 python bench.py --lanes 6 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_lanes6.json 2> /dev/null
+timeout 600 python bench.py --force-dist --dist-backend nccl --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_1rank_nccl.json 2> $O/bench_line_1rank_nccl.err
 timeout 600 python bench.py --workload sequence --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_line_sequence.json 2> /dev/null
 cd /tmp
 kt() {  # name cmd...
@@ -26,18 +31,22 @@ kt() {  # name cmd...
 }
 kt kitti python $R/bench.py --no-extras --no-cpu-baseline --steps 12 --warmup 3
 kt hd1080 python $R/bench.py --workload hd1080 --no-extras --no-cpu-baseline --steps 20 --warmup 5
+kt hd1080_x64 python $R/bench.py --workload hd1080 --batch 64 --group 8 --lanes 6 --no-extras --no-cpu-baseline --steps 8 --warmup 3
 kt sequence python $R/bench.py --workload sequence --no-extras --no-cpu-baseline --steps 12 --warmup 3
 kt matcher python $R/tools/gpu_legs.py matcher
 kt vo python $R/tools/gpu_legs.py vo
 kt map python $R/tools/gpu_legs.py map
+kt vo_replicas16 python $R/tools/gpu_legs.py replicas16
 GRAFT_REPO_ROOT=$R bash $R/tools/gpu_pmc_all.sh > $O/pmc_summary.txt 2>&1
 cp $R/gpurun_out/pmc_issue.json $R/gpurun_out/pmc_traffic.json $O/
 ls -la $O | tail -20
 python - <<PY
 import json
-for f in ("bench_line","bench_line_2ranks_gloo_1gpu","bench_line_hd1080","bench_line_hd1080_x64","bench_line_sequence"):
+for f in ("bench_line","bench_line_2ranks_gloo_1gpu","bench_line_hd1080","bench_line_hd1080_device_stage","bench_line_hd1080_x64","bench_line_hd1080_x64_host_stage","bench_line_sequence","bench_line_lanes3","bench_line_lanes6","bench_line_1rank_nccl"):
     try:
         d=json.loads([l for l in open("$O/%s.json"%f) if l.startswith("{")][-1])
-        print(f, round(d["value"]), "n_gpus", d["n_gpus"], "cores", d["config"]["host_cores_used"], d["roofline"]["kernel"], round(d["roofline"]["frac"],3))
+        print(f, round(d["value"]), "n_gpus", d["n_gpus"], "cores", d["config"]["host_cores_used"], d["roofline"]["kernel"], round(d["roofline"]["frac"],3), d.get("outputs_match_golden"), d["config"].get("stage_groups_device_handed_back"))
     except Exception as e: print(f, "ERR", e)
 PY
+GRAFT_REPO_ROOT=$R bash $R/tools/gpu_pmc_all.sh _hd1080 --workload hd1080 > $O/pmc_summary_hd1080.txt 2>&1
+cp $R/gpurun_out/pmc_issue_hd1080.json $R/gpurun_out/pmc_traffic_hd1080.json $O/
