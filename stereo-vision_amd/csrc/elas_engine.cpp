@@ -257,8 +257,8 @@ struct Lane {
             auto take = [&](size_t bytes) { size_t at = off; off = (off + bytes + 255) & ~(size_t)255; return at; };
             const size_t a_sup = take((size_t)g * 3 * cap * 4), a_cnt = take(sizeof(StageCounts));
             const size_t a_ids = take(S2 * 4 * rec * 4), a_xys = take(S2 * 4 * rec * 4), a_nbr = take(S2 * 4 * rec * 4);
-            size_t a_arr[10];
-            for (int k = 0; k < 10; k++) a_arr[k] = take(S2 * cap * 4);
+            size_t a_arr[11];
+            for (int k = 0; k < 11; k++) a_arr[k] = take(S2 * cap * 4);
             const size_t a_fl = take(S2 * 2 * cap * 4), a_fr = take(S2 * 2 * cap * 4);
             const size_t a_wl = take((size_t)g * 3 * nc * 4), a_cw = take((size_t)g * (nc / 4 + 1) * 4);
             HIP_TRY(hipMalloc(&stage_blob, off));
@@ -275,6 +275,7 @@ struct Lane {
             uint32_t** ua[4] = {&stg.lx, &stg.ly, &stg.tmp, &stg.P};
             for (int k = 0; k < 6; k++) *ia[k] = reinterpret_cast<int32_t*>(b + a_arr[k]);
             for (int k = 0; k < 4; k++) *ua[k] = reinterpret_cast<uint32_t*>(b + a_arr[6 + k]);
+            stg.dmap = reinterpret_cast<int32_t*>(b + a_arr[10]);
             stg.fl = reinterpret_cast<uint32_t*>(b + a_fl);
             stg.fr = reinterpret_cast<uint32_t*>(b + a_fr);
             stg.wl = reinterpret_cast<int32_t*>(b + a_wl);

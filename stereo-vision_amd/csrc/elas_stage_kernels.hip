@@ -830,13 +830,17 @@ template <int kT>
 __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
     extern __shared__ int s_hist[];   // [W + 1] column starts, [H + 1] row starts, then two cursors copies
     __shared__ int s_scan[kT / 64 + 1];
+    __shared__ int s_m;               // points left after coincident ones were dropped (-1: stack overflow)
     const int slot = blockIdx.x, pair = slot >> 1, side = slot & 1, tid = threadIdx.x;
-    const int m = S.counts->nsup[pair];
+    int m = S.counts->nsup[pair];
+    const int m_all = m;              // k_stage_pack walks the records of m_all points
     if (m < 3 || (S.counts->flags[pair] & STG_OVERFLOW)) {
         if (tid == 0) S.counts->ntri[slot] = 0;
         return;
     }
     const size_t so = (size_t)slot * P.sup_cap;
+    int* dmap = S.dmap + so;
+    bool remap = false;               // point p of the triangulation is support point dmap[p]
     const int32_t* sup = S.sup_raw + (size_t)pair * 3 * P.sup_cap;
     int* pxy = S.pxy + so;
     int* bx = S.buck + so;
@@ -855,17 +859,24 @@ __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
     const int nh = 2 * (P.W + P.H) + 2;
 #define STAMP(k) do { if (slot == 0 && tid == 0) S.counts->dbg[k] = wall_clock64(); } while (0)
     STAMP(8);
+    // ---- ranks in (x,y) and (y,x) order.  Second trip only when coincident points were found and dropped.
+    for (;;) {
     for (int i = tid; i < nh; i += kT) s_hist[i] = 0;
     __syncthreads();
-
-    // ---- ranks in (x,y) and (y,x) order
     const bool ldsR = nh + 3 * m <= P.lds_ints;          // coordinates + bucket lists next to the histograms
     int* lpxy = ldsR ? s_hist + nh : pxy;
     int* lbx = ldsR ? s_hist + nh + m : bx;
     int* lby = ldsR ? s_hist + nh + 2 * m : by;
     int bad = 0;
     for (int p = tid; p < m; p += kT) {
-        const int x = (side ? sup[3 * p] - sup[3 * p + 2] : sup[3 * p]) + P.xoff, y = sup[3 * p + 1];
+        int x, y;
+        if (!remap) {
+            x = (side ? sup[3 * p] - sup[3 * p + 2] : sup[3 * p]) + P.xoff;
+            y = sup[3 * p + 1];
+        } else {
+            x = pxy[p] & 0xffff;
+            y = pxy[p] >> 16;
+        }
         if (x < 0 || x >= P.W || y < 0 || y >= P.H) {
             bad = 1;
             continue;
@@ -921,13 +932,89 @@ __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
         ly[yr] = e;
         byx[xr] = p;
     }
-    if (__syncthreads_or(dup)) {
-        // coincident points: the survivor depends on Triangle's pivot stream -> host path
+    if (!__syncthreads_or(dup)) break;
+    // ---- Coincident points (possible with candidate_stepsize <= 2 * lr_threshold: two support points
+    // of a row that land on the same right-image pixel).  Triangle sorts the vertices with a quicksort
+    // whose pivots come from its own generator (vertexsort / randomnation, triangle.cpp:5446-5476,
+    // 4045-4049; the mesh's seed starts at 1) and then keeps the FIRST vertex of every run of equal
+    // ones (triangle.cpp:6179-6196): which of two coincident points survives is a property of that
+    // pivot stream.  One lane replays it -- same generator, same Hoare partition, same order of the
+    // recursive calls (a node, its left part, its right part) -- on packed keys x << 14 | y with the
+    // point index riding along, drops the repeats, and the rank phase runs again on the survivors
+    // (distinct points: everything after this is independent of the pivots).
+    for (int p = tid; p < m; p += kT) {
+        const int xy = pxy[p];
+        tmp[p] = (unsigned)((xy & 0xffff) << 14 | (xy >> 16));
+        dmap[p] = p;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned* key = tmp;
+        unsigned* stk = Pc;                     // (start, count) pairs
+        const int stk_cap = P.sup_cap / 2;
+        unsigned seed = 1;
+        int top = 0;
+        bool ok = true;
+        stk[0] = 0; stk[1] = (unsigned)m; top = 1;
+        while (top > 0 && ok) {
+            top--;
+            const int s0 = (int)stk[2 * top], n = (int)stk[2 * top + 1];
+            unsigned* a = key + s0;
+            int* ai = dmap + s0;
+            if (n == 2) {
+                if (a[0] > a[1]) {
+                    const unsigned t = a[0]; a[0] = a[1]; a[1] = t;
+                    const int ti = ai[0]; ai[0] = ai[1]; ai[1] = ti;
+                }
+                continue;
+            }
+            seed = (seed * 1366u + 150889u) % 714025u;
+            const unsigned pv = a[seed / (714025u / (unsigned)n + 1u)];
+            int l = -1, r = n;
+            while (l < r) {
+                do { l++; } while (l <= r && a[l] < pv);
+                do { r--; } while (l <= r && a[r] > pv);
+                if (l < r) {
+                    const unsigned t = a[l]; a[l] = a[r]; a[r] = t;
+                    const int ti = ai[l]; ai[l] = ai[r]; ai[r] = ti;
+                }
+            }
+            // children, pushed right first so that the left one is sorted next (the reference recurses
+            // into the left part before the right part; the generator advances once per partition)
+            if (top + 2 > stk_cap) { ok = false; break; }
+            if (r < n - 2) { stk[2 * top] = (unsigned)(s0 + r + 1); stk[2 * top + 1] = (unsigned)(n - r - 1); top++; }
+            if (l > 1) { stk[2 * top] = (unsigned)s0; stk[2 * top + 1] = (unsigned)l; top++; }
+        }
+        int j = 0;
+        for (int i = 1; i < m; i++)
+            if (key[i] != key[j]) {
+                j++;
+                key[j] = key[i];
+                dmap[j] = dmap[i];
+            }
+        s_m = ok ? j + 1 : -1;
+    }
+    __syncthreads();
+    if (s_m < 0 || remap) {
+        // (a stack deeper than the scratch holds, or repeats among distinct points: cannot happen; the
+        // host path would decide)
         if (tid == 0) {
             atomicOr(&S.counts->flags[pair], STG_DUP);
             S.counts->ntri[slot] = 0;
         }
         return;
+    }
+    m = s_m;
+    for (int p = tid; p < m; p += kT) pxy[p] = (int)(tmp[p] >> 14) | (int)(tmp[p] & 0x3fffu) << 16;
+    remap = true;
+    __syncthreads();
+    if (m < 3) {
+        // fewer than three distinct vertices: no triangle
+        for (int t = 1 + tid; t < 2 * m_all - 1; t += kT)
+            *reinterpret_cast<int4*>(S.ids + (size_t)slot * 4 * P.rec_cap + 4 * (size_t)t) = make_int4(-1, -1, -1, 0);
+        if (tid == 0) S.counts->ntri[slot] = 0;
+        return;
+    }
     }
 
     STAMP(9);
@@ -1017,14 +1104,31 @@ __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
         for (int p = tid; p < m; p += kT) vxy[p] = pxy[p];
         dt_build<kT>(ml, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0);
         // corner indices out for k_stage_pack (records 1 .. 2m-2)
+        // (after coincident points were dropped the triangulation's point p is support point dmap[p])
+        auto sid = [&](unsigned a) { return a == 0xffffu ? -1 : (remap ? dmap[a] : (int)a); };
         for (int t = 1 + tid; t < 2 * m - 1; t += kT) {
             const unsigned a0 = ml.ids[3 * t], a1 = ml.ids[3 * t + 1], a2 = ml.ids[3 * t + 2];
-            *reinterpret_cast<int4*>(mg.ids + 4 * (size_t)t) =
-                make_int4(a0 == 0xffffu ? -1 : (int)a0, a1 == 0xffffu ? -1 : (int)a1, a2 == 0xffffu ? -1 : (int)a2, 0);
+            *reinterpret_cast<int4*>(mg.ids + 4 * (size_t)t) = make_int4(sid(a0), sid(a1), sid(a2), 0);
         }
         __syncthreads();
     } else {
         dt_build<kT>(mg, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0);
+        if (remap) {
+            for (int t = 1 + tid; t < 2 * m - 1; t += kT) {
+                int4 v = *reinterpret_cast<const int4*>(mg.ids + 4 * (size_t)t);
+                v.x = v.x >= 0 ? dmap[v.x] : -1;
+                v.y = v.y >= 0 ? dmap[v.y] : -1;
+                v.z = v.z >= 0 ? dmap[v.z] : -1;
+                *reinterpret_cast<int4*>(mg.ids + 4 * (size_t)t) = v;
+            }
+            __syncthreads();
+        }
+    }
+    if (remap) {
+        // fewer points, fewer records: what lies behind them is a leftover of an earlier group
+        for (int t = 2 * m - 1 + tid; t < 2 * m_all - 1; t += kT)
+            *reinterpret_cast<int4*>(mg.ids + 4 * (size_t)t) = make_int4(-1, -1, -1, 0);
+        __syncthreads();
     }
     const MeshG& mesh = mg;
     // ---- surviving records = those without the ghost corner (the hull fan dies,

@@ -98,6 +98,7 @@ struct StageDev {
     int32_t* xys;           //                  their packed coordinates,
     uint32_t* nbr;          //                  neighbour handles
     int32_t *pxy, *buck, *buck2, *byx, *order, *oxy;   // [2g][sup_cap]
+    int32_t* dmap;          // [2g][sup_cap] surviving point -> support index, after coincident points were dropped
     uint32_t *lx, *ly, *tmp, *P;                        // [2g][sup_cap]
     uint32_t *fl, *fr;                                  // [2g][2][sup_cap] hull handles per node
     int32_t* wl;            // [g][3*Wc*Hc] k_lattice: valid cells, two work lists of fresh drops

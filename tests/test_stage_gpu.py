@@ -142,12 +142,15 @@ def test_batch_device_stage_equals_single_host_stage(dev_stage, capfd):
 
 
 @pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref")
-def test_coincident_points_fall_back_to_host(dev_stage, oracle_lib):
+def test_coincident_points_stay_on_the_device(dev_stage, oracle_lib):
     """candidate_stepsize 2 with lr_threshold 3: two support points of one row may land on the same
-    right-image pixel; Triangle keeps the one its randomised quicksort puts first.  The device stage
-    flags such pairs and the engine reruns them on the host -- the results still equal the oracle's"""
+    right-image pixel; Triangle keeps the one its randomised quicksort puts first.  k_delaunay replays
+    that quicksort (same generator, same partition, same call order) on one lane, drops the repeats and
+    triangulates the survivors: nothing comes back to the host, and every stage equals the oracle's
+    (which uses the real Triangle)"""
     seen = 0
-    for seed in range(40, 46):
+    before = dev_stage.stage_stats()
+    for seed in range(40, 52):
         prm = H.robotics(candidate_stepsize=2, lr_threshold=3, incon_min_support=3, support_threshold=0.95)
         l, r = H.synth_pair(240, 120, seed, dmax=30, noise=6)
         want = H.oracle_elas_run(prm, l, r)
@@ -160,7 +163,7 @@ def test_coincident_points_fall_back_to_host(dev_stage, oracle_lib):
         assert got.status == 0
         assert_same(want, got)
     assert seen > 0, "no case with coincident right-image points was generated"
-    assert dev_stage.stage_stats()[1] >= seen     # those pairs did come back from the device
+    assert dev_stage.stage_stats()[1] == before[1]     # no group was handed back to the host path
 
 
 def test_device_resident_batch_keeps_failed_pairs_untouched(dev_stage, capfd):
