@@ -458,11 +458,12 @@ def main():
         args.group = 1 if args.workload == "hd1080" else 32
 
     # The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4)
-    # and kernels of one hardware queue run one after the other: with the latency-bound stage
-    # kernels (k_delaunay: one workgroup per triangulation, ~1 ms) sharing queues with the
-    # streaming kernels, 8 queues measured +4 % pairs/s; more than 8 did not help.  Must be set
-    # before the runtime starts; an explicit setting of the caller wins.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # and kernels of one hardware queue run one after the other.  The 6 double-buffered workers use 12
+    # streams, and two of a group's kernels (k_delaunay ~0.8 ms, k_lattice ~0.2 ms: one workgroup per
+    # triangulation / pair) occupy their queue while using almost none of the machine: with 16 queues
+    # every stream has its own (round 3: 28.2 k pairs/s at 8, 29.6 k at 16, 29.3-29.6 k at 24-32; round 2
+    # measured 4 -> 8 at +4 %).  Must be set before the runtime starts; an explicit setting of the caller wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import torch.distributed as dist
 
