@@ -8,6 +8,13 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/evidence
 mkdir -p $O
+# PMC passes first: bench.py quotes the summaries (measured HBM traffic, VALU counts) only when their
+# build stamp is the loaded library's, so they must be in profiles/ before the bench lines are taken
+GRAFT_REPO_ROOT=$R bash $R/tools/gpu_pmc_all.sh > $O/pmc_summary.txt 2>&1
+cp $R/gpurun_out/pmc_issue.json $R/gpurun_out/pmc_traffic.json $O/
+ROUND=${ROUND:-r03}
+cp $R/gpurun_out/pmc_issue.json $R/profiles/${ROUND}_pmc_issue.json
+cp $R/gpurun_out/pmc_traffic.json $R/profiles/${ROUND}_pmc_traffic.json
 cd $R
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err
 timeout 600 python bench.py --gpus 2 --steps 10 --warmup 2 --dist-backend gloo --no-extras --no-cpu-baseline > $O/bench_line_2ranks_gloo_1gpu.json 2> /dev/null
@@ -37,8 +44,6 @@ kt matcher python $R/tools/gpu_legs.py matcher
 kt vo python $R/tools/gpu_legs.py vo
 kt map python $R/tools/gpu_legs.py map
 kt vo_replicas16 python $R/tools/gpu_legs.py replicas16
-GRAFT_REPO_ROOT=$R bash $R/tools/gpu_pmc_all.sh > $O/pmc_summary.txt 2>&1
-cp $R/gpurun_out/pmc_issue.json $R/gpurun_out/pmc_traffic.json $O/
 ls -la $O | tail -20
 python - <<PY
 import json
