@@ -221,6 +221,7 @@ def vo_bench(iters=40):
 
     dev = Hh.ProductVo(prm)
     run(dev, 5)
+    del dev     # (one live object: the library waits for its stream by spinning, the single-sequence mode)
     frame, est, ok, nm, ni = run(Hh.ProductVo(prm), iters)
     out = {"workload": "VisualOdometryStereo::process on libviso2/img quad 1344x391, default parameters, "
                        "calibration of demo.cpp", "frame_ms": frame, "estimateMotion_ms": est,

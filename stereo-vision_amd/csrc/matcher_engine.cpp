@@ -40,7 +40,7 @@ static std::atomic<int> g_live_matchers{0};
 int wait_stream(void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static const int forced = getenv("SVH_MATCHER_WAIT") ? atoi(getenv("SVH_MATCHER_WAIT")) : -1;   // 0 spin, 1 sleep-poll
-    const bool poll = forced >= 0 ? forced == 1 : g_live_matchers.load(std::memory_order_relaxed) > 1;
+    const bool poll = forced >= 0 ? forced == 1 : g_live_matchers.load(std::memory_order_relaxed) > 2;
     if (!poll) return (int)hipStreamSynchronize(s);
     for (;;) {
         const hipError_t e = hipStreamQuery(s);
@@ -326,7 +326,7 @@ static int remove_outliers(const svh_matcher_params& p, std::vector<svh_p_match>
     static const int par = getenv("SVH_DELAUNAY_PAR") ? atoi(getenv("SVH_DELAUNAY_PAR")) : 2;
     // (several live Matcher objects = several sequences on this GPU: their host threads already fill the
     // cores, the helper pool would only be fought over)
-    const bool alone = g_live_matchers.load(std::memory_order_relaxed) <= 1;
+    const bool alone = g_live_matchers.load(std::memory_order_relaxed) <= 2;
     const int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 16, (n >= 1500 && alone) ? par : 0);
     if (nt < 0) return mfail(SVH_ERR_UNSUPPORTED, "outlier triangulation failed");
     std::vector<int32_t> votes(n, 0);

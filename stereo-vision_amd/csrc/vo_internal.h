@@ -20,9 +20,9 @@ struct VoResult {          // written by k_vo_refine into pinned host memory
     int32_t pad_;
 };
 
-// Wait for a stream of a Matcher / visual-odometry object.  One live object: the driver's spinning
-// wait (lowest latency for the single-sequence case of stereomapper).  Several live objects in the
-// process (K independent sequences on one GPU): polling with short sleeps, so that K host threads do
+// Wait for a stream of a Matcher / visual-odometry object.  One or two live objects: the driver's
+// spinning wait (lowest latency for the single-sequence case of stereomapper).  Three or more live objects
+// in the process (K independent sequences on one GPU): polling with short sleeps, so that K host threads do
 // not burn K cores spinning on a GPU they share (matcher_engine.cpp keeps the count).
 int wait_stream(void* stream);   // returns a hipError_t value
 
