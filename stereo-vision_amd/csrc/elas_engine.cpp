@@ -627,21 +627,39 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     };
 
     // ---- finished maps of the active pairs to the callers' host buffers
+    // map k of the active pairs [j0, j1) -> the callers' buffers.  Runs of pairs whose host buffers follow
+    // one another (one big array, the usual case) go down as ONE strided copy (device maps of a pair are
+    // interleaved D1, D2: source pitch 2 DN, destination pitch DN) instead of one copy per pair.
+    static const bool strided = !(getenv("SVH_D2H_STRIDED") && atoi(getenv("SVH_D2H_STRIDED")) == 0);
+    auto copy_map = [&](int k, hipStream_t cs, const int32_t* active) -> int {
+        const size_t bytes = DN * sizeof(float);
+        for (int32_t j = 0; j < g;) {
+            if (!active[j]) { j++; continue; }
+            int32_t e = j + 1;
+            while (strided && e < g && active[e] &&
+                   reinterpret_cast<const char*>(io.hD[k][e]) == reinterpret_cast<const char*>(io.hD[k][e - 1]) + bytes)
+                e++;
+            const float* src = L.D + ((size_t)2 * j + k) * DN;
+            if (e - j > 1)
+                HIP_TRY(hipMemcpy2DAsync(io.hD[k][j], bytes, src, 2 * bytes, bytes, (size_t)(e - j),
+                                         hipMemcpyDeviceToHost, cs));
+            else
+                HIP_TRY(hipMemcpyAsync(io.hD[k][j], src, bytes, hipMemcpyDeviceToHost, cs));
+            j = e;
+        }
+        return SVH_OK;
+    };
     auto copy_out = [&](const int32_t* active) -> int {
         if (io.out_device) return SVH_OK;
         if (early_d2) {   // (issued after the post-processing launches: a pageable copy blocks this thread)
             HIP_TRY(hipStreamWaitEvent(L.copy_stream, L.match_ev, 0));
-            for (int32_t j = 0; j < g; j++)
-                if (active[j])
-                    HIP_TRY(hipMemcpyAsync(io.hD[1][j], L.D + ((size_t)2 * j + 1) * DN, DN * sizeof(float),
-                                           hipMemcpyDeviceToHost, L.copy_stream));
+            rc = copy_map(1, L.copy_stream, active);
+            if (rc) return rc;
             HIP_TRY(hipEventRecord(L.copy_ev, L.copy_stream));
         }
-        for (int32_t j = 0; j < g; j++) {
-            if (!active[j]) continue;
-            for (int k = 0; k < (early_d2 ? 1 : 2); k++)
-                HIP_TRY(hipMemcpyAsync(io.hD[k][j], L.D + ((size_t)2 * j + k) * DN, DN * sizeof(float),
-                                       hipMemcpyDeviceToHost, s));
+        for (int k = 0; k < (early_d2 ? 1 : 2); k++) {
+            rc = copy_map(k, s, active);
+            if (rc) return rc;
         }
         if (early_d2) HIP_TRY(hipStreamWaitEvent(s, L.copy_ev, 0));   // the lane's stream ends after both
         return SVH_OK;
@@ -705,13 +723,24 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
                 }
             (void)hipGetLastError();   // a pageable pointer makes the query fail: not an error here
             if (pinned) {
-                for (int32_t j = 0; j < g; j++)
-                    for (int k = 0; k < 2; k++) {
+                // packed images whose buffers follow one another go up as one strided copy per camera
+                // (device layout: I1, I2 of a pair interleaved)
+                static const bool strided_up = !(getenv("SVH_D2H_STRIDED") && atoi(getenv("SVH_D2H_STRIDED")) == 0);
+                for (int k = 0; k < 2; k++)
+                    for (int32_t j = 0; j < g;) {
                         uint8_t* dst = L.img + ((size_t)2 * j + k) * N;
-                        if (io.pitch == W)
-                            HIP_TRY(hipMemcpyAsync(dst, io.hI[k][j], N, hipMemcpyHostToDevice, s));
-                        else
+                        if (io.pitch != W) {
                             HIP_TRY(hipMemcpy2DAsync(dst, W, io.hI[k][j], io.pitch, W, H, hipMemcpyHostToDevice, s));
+                            j++;
+                            continue;
+                        }
+                        int32_t e = j + 1;
+                        while (strided_up && e < g && io.hI[k][e] == io.hI[k][e - 1] + N) e++;
+                        if (e - j > 1)
+                            HIP_TRY(hipMemcpy2DAsync(dst, 2 * N, io.hI[k][j], N, N, (size_t)(e - j), hipMemcpyHostToDevice, s));
+                        else
+                            HIP_TRY(hipMemcpyAsync(dst, io.hI[k][j], N, hipMemcpyHostToDevice, s));
+                        j = e;
                     }
             } else {
                 for (int32_t j = 0; j < g; j++)

@@ -425,16 +425,18 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
     // half of its neighbour; support_match_rows assigns the disparities of a trip to the lanes of a
     // row so that lane position p always reads a slot congruent to p modulo 16, in the forward and
     // in the backward search alike: every phase covers the 16 slots of the bank array once.
-    static_assert(kST / kWave == 8 && (kSB == 32 || kSB == 64), "one row of 16 lanes per candidate, 8 waves");
+    constexpr int kNW = kST / kWave, kPerRound = 4 * kNW;        // candidates per round: 4 per wave
+    static_assert(kSB % kPerRound == 0 && kSB <= 256, "whole rounds; candidate indices fit a byte");
     const int grp = lane >> 4;
     const int gl = lane & 15;
-    // forward search: every candidate of the block, 32 per round (4 per wave)
+    // forward search: every candidate of the block, kPerRound per round (4 per wave)
     __shared__ int16_t s_fwd[kSB];     // forward disparity per candidate, -1 = none
     __shared__ uint8_t s_todo[kSB];    // candidates that need the backward search, compacted
     __shared__ int s_ntodo;
 #pragma unroll
-    for (int rep = 0; rep < kSB / 32; rep++) {
-        const int c = rep * 32 + wave + grp * (kST / kWave);
+    for (int rep = 0; rep < kSB / kPerRound; rep++) {
+        const int c = rep * kPerRound + wave + grp * kNW;
+        if (rep * kPerRound >= ncand) break;                     // (block-uniform)
         const bool have = c < ncand;
         const int uc = uc0 + (have ? c : 0), u = uc * P.step;
         const bool in = have && uc > 0 && u >= 5 && u <= P.W - 6;
@@ -445,18 +447,24 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
     __syncthreads();
     // Only the candidates whose forward search produced a disparity (about half of them) are
     // searched backwards.  They are compacted first, so that the backward searches fill whole
-    // waves (with 64 candidates per block: usually all eight of them, like the forward rounds).
+    // waves (with two or more forward rounds per block: usually all of them, like the forward rounds).
     if (wave == 0) {
-        const int mine = lane < kSB ? (int)s_fwd[lane] : -1;
-        const uint64_t mask = __builtin_amdgcn_ballot_w64(mine >= 0);
-        if (mine >= 0) s_todo[__builtin_popcountll(mask & ((1ull << lane) - 1))] = (uint8_t)lane;
-        if (lane == 0) s_ntodo = __builtin_popcountll(mask);
-        // everything else is settled now: column 0 stays at calloc's 0, no forward match -> -1
-        if (lane < ncand && mine < 0) dcan[lane] = (int16_t)((uc0 + lane) > 0 ? -1 : 0);
+        int base = 0;
+#pragma unroll
+        for (int c0 = 0; c0 < kSB; c0 += kWave) {
+            const int c = c0 + lane;
+            const int mine = c < ncand ? (int)s_fwd[c] : -1;
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(mine >= 0);
+            if (mine >= 0) s_todo[base + __builtin_popcountll(mask & ((1ull << lane) - 1))] = (uint8_t)c;
+            base += __builtin_popcountll(mask);
+            // everything else is settled now: column 0 stays at calloc's 0, no forward match -> -1
+            if (c < ncand && mine < 0) dcan[c] = (int16_t)((uc0 + c) > 0 ? -1 : 0);
+        }
+        if (lane == 0) s_ntodo = base;
     }
     __syncthreads();
     const int ntodo = s_ntodo;
-    for (int t0 = 4 * wave; t0 < ntodo; t0 += 4 * (kST / kWave)) {
+    for (int t0 = 4 * wave; t0 < ntodo; t0 += kPerRound) {
         const int t = t0 + grp;
         const bool have = t < ntodo;
         const int c = have ? (int)s_todo[t] : 0;
@@ -1656,6 +1664,9 @@ void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d
     P.support_threshold = p.support_threshold;
     // LDS need of the staged kernel: two rows of both strips (16 B slots).  32 candidates per
     // 512-thread block was the best of the block shapes tried (16/256 ... 128/1024: all within 3 %).
+    // candidates per 512-thread block: 64 (two forward rounds).  32: 341 vs 316 us per isolated 32-pair
+    // launch.  A whole lattice row per 1024-thread block (79 KB of LDS) is faster alone (304 us) and slower
+    // in the pipeline (29.1 vs 29.5 k pairs/s): two such blocks take a CU's LDS away from everything else.
     static const int sb_env = getenv("SVH_SUPPORT_SB") ? atoi(getenv("SVH_SUPPORT_SB")) : 64;
     const int sb = sb_env == 32 ? 32 : 64;
     const int span = (sb - 1) * d.step;
