@@ -277,6 +277,28 @@ def vo_replicas_bench(ks=(1, 4, 16), frames=40):
                         "alternating, one host thread per object", "runs": out}
 
 
+def vo_replicas_processes(procs=4, per_proc=4, frames=60):
+    """the same K = procs x per_proc sequences as `procs` PROCESSES with `per_proc` objects each (every
+    process has its own HIP runtime: what serialises K objects of one process is the runtime's launch
+    path, ~45 launches and copies per frame)"""
+    script = os.path.join(ROOT, "tools", "gpu_legs.py")
+    ps = [subprocess.Popen([sys.executable, script, "replicas%d" % per_proc], stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, text=True) for _ in range(procs)]
+    tot, cores, ok = 0.0, 0.0, 0
+    for pr in ps:
+        out, _ = pr.communicate(timeout=600)
+        try:
+            r = json.loads(out.strip().splitlines()[-1])["vo_replicas"]["runs"][0]
+            tot += r["frames_per_s"]
+            cores += r["host_cores_used"]
+            ok += 1
+        except (ValueError, KeyError, IndexError):
+            pass
+    return {"processes": procs, "replicas_per_process": per_proc, "processes_ok": ok, "frames_per_s": tot,
+            "host_cores_used": round(cores, 2),
+            "note": "sum of the processes' own rates (they start together and run the same number of frames)"}
+
+
 def map_bench(iters=30):
     """3-D reprojection + map fusion of one 1242x375 frame (createCurrentMap +
     addDisparityMapToReconstruction), device vs the CPU restatement (oracle, "port": the reference's
@@ -456,7 +478,9 @@ def main():
     if args.group <= 0:
         # hd1080: 8 pairs per step, one pair per lane; kitti: the stages between the matching phases
         # (k_lattice, k_delaunay) are latency-bound single-workgroup jobs -- 32 pairs share one launch
-        args.group = 1 if args.workload == "hd1080" else 32
+        # (hd1080 on the device stage: pairs of a group share the launches of its latency-bound stage
+        # kernels -- 8 pairs per step as 4 lanes x 2 pairs: 2.2 k pairs/s against 1.7 k as 8 x 1)
+        args.group = (2 if args.stage == "device" else 1) if args.workload == "hd1080" else 32
 
     # The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4)
     # and kernels of one hardware queue run one after the other.  The 6 double-buffered workers use 12
@@ -874,6 +898,7 @@ def main():
             out["visual_odometry"] = vo_bench()
             out["map_fusion"] = map_bench()
             out["visual_odometry"]["replicas"] = vo_replicas_bench()
+            out["visual_odometry"]["replicas"]["as_processes"] = vo_replicas_processes()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(I1, I2, params, what, budget_s=args.cpu_budget,
                                                workers=int(avail) if args.workload == "kitti" else 0)

@@ -129,9 +129,10 @@ int32_t svh_elas_set_group(int32_t pairs);
  * list :495-523, the two Delaunay triangulations :534-600): 1 = on the device (k_lattice,
  * k_delaunay: no host round trip inside a pair), 0 = on the host (elas_host.cpp, delaunay.cpp),
  * -1 = automatic (the default: batches of images whose candidate lattice fits the device
- * kernel's LDS -- up to ~20 k lattice cells, e.g. 1242x375 -- on the device; larger images and
- * a single svh_elas_process on the host, where two host threads are the shorter path for one
- * pair).  Results are identical.  Returns the mode in effect. */
+ * kernel's LDS -- up to ~20 k lattice cells, e.g. 1242x375 -- and batches of 32 or more pairs of
+ * larger images on the device; a single svh_elas_process and small batches of large images on
+ * the host, where two host threads are the shorter path for one pair).  Use 1 where host cores
+ * are scarce (several ranks per node).  Results are identical.  Returns the mode in effect. */
 int32_t svh_elas_set_stage(int32_t where);
 /* diagnostics: groups of pairs that took the device stage since the library was loaded, and how
  * many of them it handed back to the host path (coincident support points in a triangulation,

@@ -761,6 +761,10 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         const int sm = g_stage_mode.load();
         L.resident = !L.force_host && L.stage_ok &&
                      (sm == 1 || (sm < 0 && prefer_device && stage_device_preferred(p, d, prefer_device > 1)));
+        // a batch worker whose group runs the device stage has nothing to do on the host until the group
+        // is done: it sleeps between polls also in a one-round (latency-bound) batch, instead of spinning
+        // on a core that another rank may need (8 pairs of 1920x1080 per step: 4-7 cores -> < 1)
+        if (L.resident && prefer_device) L.poll_wait = true;
         if (!L.resident || tapping)
             HIP_TRY(hipMemcpyAsync(L.h_dcan, L.dcan, g * nc * sizeof(int16_t), hipMemcpyDeviceToHost, s));
         if (L.resident) {

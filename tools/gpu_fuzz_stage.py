@@ -18,7 +18,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 dup_mode = len(sys.argv) > 3 and sys.argv[3] == "dup"
 ndup = 0
 shapes = [(320, 200), (401, 177), (512, 160), (288, 240), (640, 480), (1242, 375), (97, 61), (1000, 120)]
-S.set_stage(1)
+S.set_stage(int(os.environ.get("SVH_FUZZ_STAGE", "1")))   # 1 = device stage (default), 0 = host stage
 bad = 0
 few = 0
 for seed in range(first, first + count):
