@@ -282,8 +282,11 @@ def vo_replicas_processes(procs=4, per_proc=4, frames=60):
     process has its own HIP runtime: what serialises K objects of one process is the runtime's launch
     path, ~45 launches and copies per frame)"""
     script = os.path.join(ROOT, "tools", "gpu_legs.py")
+    # (the runtime's default of 4 hardware queues per process: this bench's own 16 times several
+    # processes oversubscribes the device's queue slots -- 1.9 k instead of 4.8 k frames/s)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="4")
     ps = [subprocess.Popen([sys.executable, script, "replicas%d" % per_proc], stdout=subprocess.PIPE,
-                           stderr=subprocess.DEVNULL, text=True) for _ in range(procs)]
+                           stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(procs)]
     tot, cores, ok = 0.0, 0.0, 0
     for pr in ps:
         out, _ = pr.communicate(timeout=600)

@@ -297,13 +297,13 @@ __global__ __launch_bounds__(512) void k_lattice(StageDev S, LatticeParams P) {
                 const int nxt = t + 6 < steps ? line[(t + 6) * ss] : kInv;
                 int dv = cur;
                 if (dv >= 0) {
+                    // "valid and within 1 of dv" = (unsigned)(x - dv + 1) <= 2: an invalid cell is -32768
                     bool fb = false, fa = false;
+                    const int t1 = 1 - dv;
 #pragma unroll
                     for (int j = 0; j < 5; j++) {
-                        const int db = b[j] > dv ? b[j] - dv : dv - b[j];
-                        const int da = a[j] > dv ? a[j] - dv : dv - a[j];
-                        fb |= (b[j] >= 0) & (db <= 1);
-                        fa |= (a[j] >= 0) & (da <= 1);
+                        fb |= (unsigned)(b[j] + t1) <= 2u;
+                        fa |= (unsigned)(a[j] + t1) <= 2u;
                     }
                     if (fb && fa) {
                         dv = kInv;
