@@ -217,7 +217,14 @@ __global__ __launch_bounds__(256) void k_descriptor_stream(DevImages img, int W,
                 out.z = w1 | ((uint32_t)u << 24);
                 out.w = (vcar >> 24) | z2 | ((vcar << 16) & 0xFF000000u);
                 if (!inside) out = make_uint4(0, 0, 0, 0);
-                if (x_out) dst[(uint32_t)(y * W) + xo] = out;
+                if (x_out) {
+                    // streamed out, read again only after the whole group's descriptors are written
+                    uint4* q = &dst[(uint32_t)(y * W) + xo];
+                    __builtin_nontemporal_store(out.x, &q->x);
+                    __builtin_nontemporal_store(out.y, &q->y);
+                    __builtin_nontemporal_store(out.z, &q->z);
+                    __builtin_nontemporal_store(out.w, &q->w);
+                }
             }
             w3 = w2; w2 = w1; w1 = Wc;
             y2 = y1; y1 = Yc;
