@@ -1883,19 +1883,30 @@ __global__ __launch_bounds__(256) void k_gap_tile(GroupDev G, DevMaps m, PostScr
     const int x0 = blockIdx.x * QX, y0 = blockIdx.y * QY;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     {
-        // the label -> root -> size look-ups are dependent loads: each level is fetched for all
-        // of a thread's entries before the next one starts
-        constexpr int AW = QX + 2 * HG, NE = ((QY + 2 * HG) * AW + 255) / 256;
+        // Rows wave, wave + 4, ... of the tile: 64 columns by the lanes, the 2 HG columns beyond them
+        // as a second, short pass (row-wise addressing costs a fraction of splitting a flat index).
+        // The label -> root -> size look-ups are dependent loads: each level is fetched for all
+        // of a thread's entries before the next one starts.
+        constexpr int AW = QX + 2 * HG, AH = QY + 2 * HG, NR = AH / 4, NE = NR + (AH * 8 + 255) / 256;
+        static_assert(AH % 4 == 0 && AW - 64 == 8, "tile shape");
         const int32_t* L = S.labels + (size_t)blockIdx.z * DW * DH;
         const int32_t* Cn = S.counts + (size_t)blockIdx.z * DW * DH;
+        const int lane = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
         float val[NE];
         int lab[NE];
+        int er[NE], ec[NE];
 #pragma unroll
         for (int k = 0; k < NE; k++) {
-            const int i = tid + 256 * k;
-            const int r = i / AW, c = i - r * AW;
-            const int gy = y0 - HG + r, gx = x0 - HG + c;
-            const bool in = i < (QY + 2 * HG) * AW && gy >= 0 && gy < DH && gx >= 0 && gx < DW;
+            if (k < NR) {
+                er[k] = wave + 4 * k;
+                ec[k] = lane;
+            } else {
+                const int e = tid + 256 * (k - NR);
+                er[k] = e >> 3;
+                ec[k] = 64 + (e & 7);
+            }
+            const int gy = y0 - HG + er[k], gx = x0 - HG + ec[k];
+            const bool in = er[k] < AH && gy >= 0 && gy < DH && gx >= 0 && gx < DW;
             val[k] = in ? D[(size_t)gy * DW + gx] : -10.f;
             lab[k] = (in && min_size > 0) ? L[(size_t)gy * DW + gx] : -1;
         }
@@ -1908,13 +1919,8 @@ __global__ __launch_bounds__(256) void k_gap_tile(GroupDev G, DevMaps m, PostScr
                 if (lab[k] >= 0 && Cn[lab[k]] < min_size) val[k] = -10.f;
         }
 #pragma unroll
-        for (int k = 0; k < NE; k++) {
-            const int i = tid + 256 * k;
-            if (i < (QY + 2 * HG) * AW) {
-                const int r = i / AW, c = i - r * AW;
-                sA[r][c] = val[k];
-            }
-        }
+        for (int k = 0; k < NE; k++)
+            if (er[k] < AH) sA[er[k]][ec[k]] = val[k];
     }
     __syncthreads();
     for (int i = tid; i < (QY + 2 * HG) * QX; i += 256) {
@@ -1931,33 +1937,56 @@ __global__ __launch_bounds__(256) void k_gap_tile(GroupDev G, DevMaps m, PostScr
     }
 }
 
-// one 8- or 4-tap adaptive-mean evaluation; `line` points at the centre, taps at (first + k - pos)
-template <int kTaps>
-__device__ __forceinline__ bool am_eval(const float* line, int stride, int pos, float centre, float* res) {
-    constexpr int back = kTaps == 8 ? 3 : 1, lead = kTaps - 1;
-    const int first = pos + back - lead;
-    float ws[kTaps], fs[kTaps];
+// One 8- or 4-tap adaptive-mean evaluation with the taps in window order (tap k lies k - HL places
+// from the centre).  The reference keeps the window in a ring of kTaps slots and adds the slots in
+// slot order (elas.cpp:1570-1640): slot s holds tap (s - first) & (kTaps - 1), first = pos + back -
+// lead.  Slots j and j + 4 are added first (one SSE add of the two halves; the sum of a pair does not
+// depend on the order of its two terms), which pairs tap m with tap m + 4 whatever `first` is, and the
+// four pair sums are then added from slot 0 upwards -- so the ring position only rotates the order of
+// that last chain, by kRot = first & 3.  kRot is a template argument: every wave of k_mean_tile
+// works on positions of one residue, so the taps are read at constant LDS offsets and no select or
+// address arithmetic is spent on the ring.
+//
+// The weights are carried at a quarter of the reference's: w/4 = max(0, 1 - mm/4) is one fused
+// multiply-add with the clamp modifier instead of a subtraction and a maximum (v_max_f32 issues at
+// half the rate of v_fma_f32, profiles/r03_microbench_valu.txt).  Scaling by 2^-2 is exact and
+// commutes with every rounding in the chain (products, pair sums, the two chains; no value of a
+// disparity map is near the denormal range), so both sums come out at exactly a quarter and their
+// quotient is the reference's, bit for bit.
+__device__ __forceinline__ float am_weight_q(float val, float centre) {
+    const float mm = __uint_as_float(__float_as_uint(__fsub_rn(val, centre)) & 0x4F000000u);
+    return __builtin_amdgcn_fmed3f(__fmaf_rn(mm, -0.25f, 1.0f), 0.0f, 1.0f);
+}
+
+template <int kTaps, int kRot, typename Tap>
+__device__ __forceinline__ bool am_eval_rot(Tap tap, float centre, float* res) {
+    constexpr int kCentre = kTaps == 8 ? 4 : 2;        // the centre tap: difference 0, weight 4 (here 1)
+    float P[4], F[4];
 #pragma unroll
-    for (int s = 0; s < kTaps; s++) {
-        const int k = (s - first) & (kTaps - 1);
-        const float t = line[(first + k - pos) * stride];
-        const float w = am_weight(t, centre);
-        ws[s] = w;
-        fs[s] = __fmul_rn(t, w);
-    }
-    float wl[4], fl[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int m = 0; m < 4; m++) {
+        float w0 = 1.0f, f0 = centre;
+        if (m != kCentre) {
+            const float t0 = tap(m);
+            w0 = am_weight_q(t0, centre);
+            f0 = __fmul_rn(t0, w0);
+        }
         if (kTaps == 8) {
-            wl[j] = __fadd_rn(ws[j], ws[j + kTaps / 2]);
-            fl[j] = __fadd_rn(fs[j], fs[j + kTaps / 2]);
+            float w1 = 1.0f, f1 = centre;
+            if (m + 4 != kCentre) {
+                const float t1 = tap(m + 4);
+                w1 = am_weight_q(t1, centre);
+                f1 = __fmul_rn(t1, w1);
+            }
+            P[m] = __fadd_rn(w0, w1);
+            F[m] = __fadd_rn(f0, f1);
         } else {
-            wl[j] = ws[j];
-            fl[j] = fs[j];
+            P[m] = w0;
+            F[m] = f0;
         }
     }
-    const float wsum = __fadd_rn(__fadd_rn(__fadd_rn(wl[0], wl[1]), wl[2]), wl[3]);
-    const float fsum = __fadd_rn(__fadd_rn(__fadd_rn(fl[0], fl[1]), fl[2]), fl[3]);
+    constexpr int a = (4 - kRot) & 3;
+    const float wsum = __fadd_rn(__fadd_rn(__fadd_rn(P[a], P[(a + 1) & 3]), P[(a + 2) & 3]), P[(a + 3) & 3]);
+    const float fsum = __fadd_rn(__fadd_rn(__fadd_rn(F[a], F[(a + 1) & 3]), F[(a + 2) & 3]), F[(a + 3) & 3]);
     if (wsum > 0) {
         const float dv = __fdiv_rn(fsum, wsum);
         if (dv >= 0) {
@@ -1968,63 +1997,132 @@ __device__ __forceinline__ bool am_eval(const float* line, int stride, int pos, 
     return false;
 }
 
+// LDS layout of k_mean_tile.  The input tile is stored column-swizzled: column c of a row sits at
+// (c & 3) * kMeanSub + (c >> 2), so that a wave whose lanes take every fourth column (one residue of
+// x mod 4) reads 16 consecutive words per row; four rows per wave, rows kMeanSA = 80 = 16 (mod 64)
+// words apart, cover the 64 banks exactly once.  The row-pass result is stored plainly with rows 65
+// words apart (the stride-4 writes of the row pass and the row-strided reads of the column pass are
+// both conflict-free with it).
+constexpr int kMeanSub = 20, kMeanSA = 80, kMeanSB = 65;
+
+template <int kTaps, int kQ>
+__device__ __forceinline__ void mean_row_pass(const float* sA, float* sB, int x0, int y0, int DW, int DH,
+                                              int lane) {
+    constexpr int back = kTaps == 8 ? 3 : 1, lead = kTaps - 1, HL = lead - back, HR = back;
+    constexpr int AH = QY + HL + HR;
+    const int l = lane & 15, rs = lane >> 4;
+    const int gx = x0 + 4 * l + kQ;
+    const bool xin = gx >= lead - back && gx <= DW - 1 - back;
+    const float* a = sA + rs * kMeanSA + l;
+    float* b = sB + rs * kMeanSB + 4 * l + kQ;
+#pragma unroll 2
+    for (int r4 = 0; r4 < AH; r4 += 4) {
+        const int r = r4 + rs;
+        if (r < AH) {
+            const int gy = y0 - HL + r;
+            const float* row = a + r4 * kMeanSA;
+            const float centre = row[((kQ + HL) & 3) * kMeanSub + ((kQ + HL) >> 2)];
+            float res = centre < 0 ? -10.f : 0.f;
+            if (centre >= 0 && xin && gy >= 3 && gy < DH - 3)
+                am_eval_rot<kTaps, (kQ - HL) & 3>(
+                    [&](int k) { return row[((kQ + k) & 3) * kMeanSub + ((kQ + k) >> 2)]; }, centre, &res);
+            b[r4 * kMeanSB] = res;
+        }
+    }
+}
+
+template <int kTaps, int kQ>
+__device__ __forceinline__ void mean_col_pass(const float* sB, float* D, const float (&orig)[QY / 4], int x0,
+                                              int y0, int DW, int DH, int lane) {
+    constexpr int back = kTaps == 8 ? 3 : 1, lead = kTaps - 1, HL = lead - back;
+    const int gx = x0 + lane;
+    if (gx >= DW) return;
+    const bool xin = gx >= 3 && gx < DW - 3;
+#pragma unroll
+    for (int j = 0; j < QY / 4; j++) {
+        const int r = kQ + 4 * j, gy = y0 + r;
+        if (gy >= DH) break;
+        const float* col = sB + r * kMeanSB + lane;
+        float res = orig[j];
+        const float centre = col[HL * kMeanSB];
+        if (centre >= 0 && xin && gy >= lead - back && gy <= DH - 1 - back)
+            am_eval_rot<kTaps, (kQ - HL) & 3>([&](int k) { return col[k * kMeanSB]; }, centre, &res);
+        D[(size_t)gy * DW + gx] = res;
+    }
+}
+
 template <int kTaps>
 __global__ __launch_bounds__(256) void k_mean_tile(GroupDev G, DevMaps m, PostScratch S, int nside, int DW,
                                                    int DH) {
     constexpr int back = kTaps == 8 ? 3 : 1, lead = kTaps - 1;
     constexpr int HL = lead - back, HR = back;         // taps reach HL before and HR after the centre
-    __shared__ float sA[QY + HL + HR][QX + HL + HR];   // input (negatives as -10) with halo
-    __shared__ float sB[QY + HL + HR][QX];             // horizontal-pass result (D_tmp), rows with halo
+    constexpr int AW = QX + HL + HR, AH = QY + HL + HR;
+    static_assert((AW + 3) / 4 <= kMeanSub && 4 * kMeanSub <= kMeanSA && QX <= kMeanSB, "tile layout");
+    __shared__ float sA[AH * kMeanSA];                 // input (negatives as -10) with halo, swizzled
+    __shared__ float sB[AH * kMeanSB];                 // horizontal-pass result (D_tmp), rows with halo
     int pair;
     float* D = post_map(m, blockIdx.z, nside, &pair);
     if (!G.hdr->active[pair]) return;
     const float* in = S.tmp + (size_t)blockIdx.z * DW * DH;   // written by k_gap_tile
     const int x0 = blockIdx.x * QX, y0 = blockIdx.y * QY;
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    constexpr int AW = QX + HL + HR, AH = QY + HL + HR;
+    const int lane = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    float orig[QY / 4];
     {
-        // all of a thread's tile entries are requested before the first one is used (a plain
-        // load / clamp / store loop waits for memory once per entry: 11 round trips per thread)
-        constexpr int NE = (AH * AW + 255) / 256;
-        float val[NE];
+        // Rows wave, wave + 4, ... of the tile: 64 columns by the lanes, the HL + HR columns beyond
+        // them as a second, short pass.  All of a thread's entries are requested before the first
+        // one is used (a load / clamp / store loop waits for memory once per entry), and so are the
+        // values the column pass falls back to where it does not fire.
+        constexpr int NR = (AH + 3) / 4, XW = AW - 64, NX = (AH * XW + 255) / 256;
+        float val[NR], xv[NX];
+        const int gxm = x0 - HL + lane;
+        const bool cin = gxm >= 0 && gxm < DW;
 #pragma unroll
-        for (int k = 0; k < NE; k++) {
-            const int i = tid + 256 * k;
-            const int r = i / AW, c = i - r * AW;
+        for (int j = 0; j < NR; j++) {
+            const int r = wave + 4 * j, gy = y0 - HL + r;
+            val[j] = (r < AH && gy >= 0 && gy < DH && cin) ? in[(size_t)gy * DW + gxm] : -10.f;
+        }
+        const int tid = wave * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            const int e = tid + 256 * k, r = e / XW, c = 64 + (e - r * XW);
             const int gy = y0 - HL + r, gx = x0 - HL + c;
-            const bool inside = i < AH * AW && gy >= 0 && gy < DH && gx >= 0 && gx < DW;
-            val[k] = inside ? in[(size_t)gy * DW + gx] : -10.f;
+            xv[k] = (e < AH * XW && gy >= 0 && gy < DH && gx < DW) ? in[(size_t)gy * DW + gx] : -10.f;
         }
 #pragma unroll
-        for (int k = 0; k < NE; k++) {
-            const int i = tid + 256 * k;
-            if (i < AH * AW) {
-                const int r = i / AW, c = i - r * AW;
-                sA[r][c] = val[k] < 0 ? -10.f : val[k];     // D_copy initialisation (elas.cpp:1553-1560)
-            }
+        for (int j = 0; j < QY / 4; j++) {
+            const int gy = y0 + wave + 4 * j, gx = x0 + lane;
+            orig[j] = (gy < DH && gx < DW) ? in[(size_t)gy * DW + gx] : 0.f;
+        }
+        const int sw = (lane & 3) * kMeanSub + (lane >> 2);
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const int r = wave + 4 * j;
+            if (r < AH) sA[r * kMeanSA + sw] = val[j] < 0 ? -10.f : val[j];   // D_copy (elas.cpp:1553-1560)
+        }
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            const int e = tid + 256 * k, r = e / XW, c = 64 + (e - r * XW);
+            if (e < AH * XW) sA[r * kMeanSA + (c & 3) * kMeanSub + (c >> 2)] = xv[k] < 0 ? -10.f : xv[k];
         }
     }
     __syncthreads();
-    // horizontal pass -> D_tmp: -10 where the input is invalid, 0 where valid but never written
-    for (int i = tid; i < AH * QX; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const int gy = y0 - HL + r, gx = x0 + c;
-        const float centre = sA[r][c + HL];
-        float res = centre < 0 ? -10.f : 0.f;
-        if (gy >= 3 && gy < DH - 3 && gx >= lead - back && gx <= DW - 1 - back)
-            am_eval<kTaps>(&sA[r][c + HL], 1, gx, centre, &res);
-        sB[r][c] = res;
+    // horizontal pass -> D_tmp: -10 where the input is invalid, 0 where valid but never written.
+    // Wave q takes the columns with x = q (mod 4), four rows at a time.
+    switch (wave) {
+        case 0: mean_row_pass<kTaps, 0>(sA, sB, x0, y0, DW, DH, lane); break;
+        case 1: mean_row_pass<kTaps, 1>(sA, sB, x0, y0, DW, DH, lane); break;
+        case 2: mean_row_pass<kTaps, 2>(sA, sB, x0, y0, DW, DH, lane); break;
+        default: mean_row_pass<kTaps, 3>(sA, sB, x0, y0, DW, DH, lane); break;
     }
     __syncthreads();
-    // vertical pass on D_tmp; where it does not fire the map keeps the filter's input
-    for (int i = tid; i < QY * QX; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const int gy = y0 + r, gx = x0 + c;
-        if (gy >= DH || gx >= DW) continue;
-        float res = in[(size_t)gy * DW + gx];
-        if (gx >= 3 && gx < DW - 3 && gy >= lead - back && gy <= DH - 1 - back)
-            am_eval<kTaps>(&sB[r + HL][c], QX, gy, sB[r + HL][c], &res);
-        D[(size_t)gy * DW + gx] = res;
+    // vertical pass on D_tmp, wave q on the rows with y = q (mod 4); where it does not fire the map
+    // keeps the filter's input
+    switch (wave) {
+        case 0: mean_col_pass<kTaps, 0>(sB, D, orig, x0, y0, DW, DH, lane); break;
+        case 1: mean_col_pass<kTaps, 1>(sB, D, orig, x0, y0, DW, DH, lane); break;
+        case 2: mean_col_pass<kTaps, 2>(sB, D, orig, x0, y0, DW, DH, lane); break;
+        default: mean_col_pass<kTaps, 3>(sB, D, orig, x0, y0, DW, DH, lane); break;
     }
 }
 
