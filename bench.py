@@ -788,9 +788,22 @@ def main():
             n2 = int((g2[: z["d2"].size] != z["d2"]).sum())
             if n1 or n2:
                 bad.append({"pair": k, "golden": gold[(first + k) % 4], "d1_mismatch_px": n1, "d2_mismatch_px": n2})
+        # ... and every other copy of the batch against the copy of its crop among those (on the device):
+        # any pair a race or a stale buffer had touched anywhere in the batch shows up here
+        copies_bad = 0
+        if B > 4:
+            n4 = (B // 4) * 4
+            for dD in (dD1, dD2):
+                ref4 = dD[:4].unsqueeze(0)
+                for lo in range(0, n4, 1024):    # bounded temporaries: 1024 maps per comparison
+                    hi = min(lo + 1024, n4)
+                    eq = (dD[lo:hi].view(-1, 4, H, W) == ref4).flatten(2).all(dim=2)
+                    copies_bad += int((~eq).sum().item())
         golden_check = {"pairs_checked": min(B, 8), "mismatches": bad,
+                        "copies_checked": max(0, (B // 4) * 4 - 4), "copies_differing": copies_bad,
                         "what": "D1 and D2 of the first pairs after the last timed step == reference "
-                                "Elas::process on the same crops (tests/golden/*.npz), every pixel"}
+                                "Elas::process on the same crops (tests/golden/*.npz), every pixel; every "
+                                "other pair of the batch == the copy of its crop among the first four"}
 
     if rank == 0:
         valid = float((dD1[:min(B, 64)] >= 0).float().mean().item())
@@ -830,7 +843,7 @@ def main():
             "roofline": roofline,
         }
         if golden_check is not None:
-            out["outputs_match_golden"] = len(golden_check["mismatches"]) == 0
+            out["outputs_match_golden"] = len(golden_check["mismatches"]) == 0 and golden_check["copies_differing"] == 0
             out["golden_check"] = golden_check
         if use_dist:
             out["config"]["dist_backend"] = args.dist_backend
