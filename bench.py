@@ -437,6 +437,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the default) or gloo (CPU collectives: lets several ranks "
                          "share one GPU when the multi-rank path is exercised on a 1-GPU box)")
+    ap.add_argument("--soak", type=int, default=0,
+                    help="after the timed region: this many extra steps, the output maps zero-filled before "
+                         "each and EVERY pair of the batch verified after it (urban crops only; a race / "
+                         "stale-buffer detector, reported as golden_check.soak)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (and run the record gather and the barriers) even "
                          "with one rank: one execution of the RCCL path on a 1-GPU box")
@@ -790,17 +794,36 @@ def main():
                 bad.append({"pair": k, "golden": gold[(first + k) % 4], "d1_mismatch_px": n1, "d2_mismatch_px": n2})
         # ... and every other copy of the batch against the copy of its crop among those (on the device):
         # any pair a race or a stale buffer had touched anywhere in the batch shows up here
-        copies_bad = 0
-        if B > 4:
-            n4 = (B // 4) * 4
-            for dD in (dD1, dD2):
-                ref4 = dD[:4].unsqueeze(0)
-                for lo in range(0, n4, 1024):    # bounded temporaries: 1024 maps per comparison
-                    hi = min(lo + 1024, n4)
-                    eq = (dD[lo:hi].view(-1, 4, H, W) == ref4).flatten(2).all(dim=2)
-                    copies_bad += int((~eq).sum().item())
+        def copies_differing():
+            bad_ = 0
+            if B > 4:
+                n4 = (B // 4) * 4
+                for dD in (dD1, dD2):
+                    ref4 = dD[:4].unsqueeze(0)
+                    for lo in range(0, n4, 1024):    # bounded temporaries: 1024 maps per comparison
+                        hi = min(lo + 1024, n4)
+                        eq = (dD[lo:hi].view(-1, 4, H, W) == ref4).flatten(2).all(dim=2)
+                        bad_ += int((~eq).sum().item())
+            return bad_
+        copies_bad = copies_differing()
+        soak = None
+        if args.soak > 0 and not use_dist:
+            gz = [np.load(os.path.join(Hh.GOLDEN, gold[(first + k) % 4] + ".npz")) for k in range(min(B, 4))]
+            g1 = [torch.from_numpy(z_["d1"].reshape(H, W)).to(dev) for z_ in gz]
+            g2 = [torch.from_numpy(z_["d2"].reshape(H, W)).to(dev) for z_ in gz]
+            soak_bad = 0
+            for _ in range(args.soak):
+                dD1.zero_()
+                dD2.zero_()
+                torch.cuda.synchronize()
+                step()
+                torch.cuda.synchronize()
+                for k in range(min(B, 4)):
+                    soak_bad += int(not torch.equal(dD1[k], g1[k])) + int(not torch.equal(dD2[k], g2[k]))
+                soak_bad += copies_differing()
+            soak = {"steps": args.soak, "pairs_verified": args.soak * B, "maps_differing": soak_bad}
         golden_check = {"pairs_checked": min(B, 8), "mismatches": bad,
-                        "copies_checked": max(0, (B // 4) * 4 - 4), "copies_differing": copies_bad,
+                        "copies_checked": max(0, (B // 4) * 4 - 4), "copies_differing": copies_bad, "soak": soak,
                         "what": "D1 and D2 of the first pairs after the last timed step == reference "
                                 "Elas::process on the same crops (tests/golden/*.npz), every pixel; every "
                                 "other pair of the batch == the copy of its crop among the first four"}
@@ -843,7 +866,8 @@ def main():
             "roofline": roofline,
         }
         if golden_check is not None:
-            out["outputs_match_golden"] = len(golden_check["mismatches"]) == 0 and golden_check["copies_differing"] == 0
+            out["outputs_match_golden"] = (len(golden_check["mismatches"]) == 0 and golden_check["copies_differing"] == 0
+                                           and (golden_check["soak"] is None or golden_check["soak"]["maps_differing"] == 0))
             out["golden_check"] = golden_check
         if use_dist:
             out["config"]["dist_backend"] = args.dist_backend
