@@ -25,6 +25,7 @@ timeout 600 python bench.py --workload hd1080 --batch 256 --group 16 --lanes 6 -
 timeout 600 python bench.py --workload hd1080 --stage host --batch 64 --group 4 --lanes 8 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_x64_host_stage.json 2> /dev/null
 timeout 600 python bench.py --lanes 3 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_lanes3.json 2> /dev/null
 timeout 600 python bench.py --lanes 6 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_lanes6.json 2> /dev/null
+timeout 600 python bench.py --steps 8 --warmup 2 --no-extras --no-cpu-baseline --soak 60 > $O/bench_line_soak60.json 2> /dev/null
 timeout 600 python bench.py --force-dist --dist-backend nccl --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_1rank_nccl.json 2> $O/bench_line_1rank_nccl.err
 timeout 600 python bench.py --workload sequence --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_line_sequence.json 2> /dev/null
 cd /tmp
@@ -48,7 +49,7 @@ kt vo_replicas16 python $R/tools/gpu_legs.py replicas16
 ls -la $O | tail -20
 python - <<PY
 import json
-for f in ("bench_line","bench_line_2ranks_gloo_1gpu","bench_line_hd1080","bench_line_hd1080_device_stage","bench_line_hd1080_x64","bench_line_hd1080_x256","bench_line_hd1080_x64_host_stage","bench_line_sequence","bench_line_lanes3","bench_line_lanes6","bench_line_1rank_nccl"):
+for f in ("bench_line","bench_line_2ranks_gloo_1gpu","bench_line_hd1080","bench_line_hd1080_device_stage","bench_line_hd1080_x64","bench_line_hd1080_x256","bench_line_hd1080_x64_host_stage","bench_line_sequence","bench_line_lanes3","bench_line_lanes6","bench_line_soak60","bench_line_1rank_nccl"):
     try:
         d=json.loads([l for l in open("$O/%s.json"%f) if l.startswith("{")][-1])
         print(f, round(d["value"]), "n_gpus", d["n_gpus"], "cores", d["config"]["host_cores_used"], d["roofline"]["kernel"], round(d["roofline"]["frac"],3), d.get("outputs_match_golden"), d["config"].get("stage_groups_device_handed_back"))
