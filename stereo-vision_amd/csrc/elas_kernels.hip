@@ -1289,12 +1289,14 @@ __global__ __launch_bounds__(256) void k_seg_tile(GroupDev G, DevMaps m, PostScr
             if (root == i) size = sC[i];   // this pixel is the tile-local root
         }
         S.labels[zo + gi] = label;
-        S.counts[zo + gi] = size;   // > 0 exactly at the tile-local roots
         // The tile-local roots are listed per tile (in `tmp`, which is free until k_gap_tile; a tile's
         // list starts where its pixels would start if the map were stored tile by tile, so it can hold
         // every pixel of the tile): k_seg_sum visits a few roots per tile instead of scanning the counts
         // of every pixel.  Positions from an LDS counter, the tile's count is written once.
         if (size > 0) {
+            // the size is stored at the tile-local roots only: counts are never read anywhere else (labels
+            // point at roots), so what an earlier group left at the other pixels does not matter
+            S.counts[zo + gi] = size;
             const int bh = min(CY, DH - y0);                    // rows of this band of tiles
             reinterpret_cast<int32_t*>(S.tmp)[zo + (size_t)y0 * DW + (size_t)x0 * bh + atomicAdd(&s_nr, 1)] = gi;
         }
