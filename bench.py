@@ -422,13 +422,15 @@ def main():
                     help="kitti workload: the four urban crops tiled (default) or seeded synthetic pairs")
     ap.add_argument("--batch", type=int, default=0,
                     help="pairs per step and GPU (0 = 6144 for kitti: a step of ~0.2 s, so that the "
-                         "driver's 20 steps run for seconds; 8 for hd1080)")
+                         "driver's 20 steps run for seconds; hd1080: configs[3]'s batch of 64 pairs shared "
+                         "by the GPUs -- 64 on one, 8 each on eight)")
     ap.add_argument("--unique", type=int, default=64,
                     help="different synthetic pairs generated per rank; the batch tiles them")
     ap.add_argument("--lanes", type=int, default=0,
                     help="double-buffered pipeline workers per GPU (0 = auto: 1.5 per available core, <= 24)")
     ap.add_argument("--group", type=int, default=0,
-                    help="pairs per kernel launch, 1..32 (0 = 32 for kitti, 1 for hd1080)")
+                    help="pairs per kernel launch, 1..32 (0 = 32 for kitti; hd1080: 8 for steps of 32 pairs "
+                         "or more, else 1 on the host stage and 2 on the device stage)")
     ap.add_argument("--spinup", type=float, default=1.0,
                     help="seconds of untimed steps before the warmup (GPU clocks, lane buffers)")
     ap.add_argument("--profile-in-timed-region", type=int, default=1,
@@ -481,13 +483,20 @@ def main():
         args.batch = hi_ - lo_
         args.seq_first = lo_
     if args.batch <= 0:
-        args.batch = 6144 if args.workload == "kitti" else 8
+        # hd1080 = BASELINE.json configs[3]: "batch=64 sharded 8 per GPU" -- the batch of 64 pairs is the
+        # workload, one GPU takes all of it, eight take 8 each
+        args.batch = 6144 if args.workload == "kitti" else max(8, 64 // max(world, 1))
     if args.group <= 0:
         # hd1080: 8 pairs per step, one pair per lane; kitti: the stages between the matching phases
         # (k_lattice, k_delaunay) are latency-bound single-workgroup jobs -- 32 pairs share one launch
         # (hd1080 on the device stage: pairs of a group share the launches of its latency-bound stage
         # kernels -- 8 pairs per step as 4 lanes x 2 pairs: 2.2 k pairs/s against 1.7 k as 8 x 1)
-        args.group = (2 if args.stage == "device" else 1) if args.workload == "hd1080" else 32
+        if args.workload != "hd1080":
+            args.group = 32
+        elif args.batch >= 32 and args.stage != "host":
+            args.group = 8            # a deep step: the library's automatic mode takes the device stage
+        else:
+            args.group = 2 if args.stage == "device" else 1
 
     # The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4)
     # and kernels of one hardware queue run one after the other.  The 6 double-buffered workers use 12
@@ -541,7 +550,7 @@ def main():
     cores_per_rank = avail / max(world, 1)
     # (with the device stage the workers only enqueue and sleep: 6 of them, 12 streams, already
     # saturate the device; more only stretches every kernel's in-run duration)
-    dev_stage = args.stage != "host" and args.workload != "hd1080"
+    dev_stage = args.stage != "host" and (args.workload != "hd1080" or args.stage == "device" or args.batch >= 32)
     # device stage: 6 workers whatever the core count (they use ~0.03 cores each; 8 ranks on a 16-core
     # quota keep the depth the single-GPU number was measured with); host stage: by cores
     lanes = args.lanes or (6 if dev_stage else int(max(2, min(24, round(1.5 * cores_per_rank)))))
@@ -845,7 +854,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_pair": 1e3 * elapsed / (args.steps * B),
             "higher_is_better": True,
-            "scaling": "strong" if args.workload == "sequence" else "weak",
+            "scaling": "strong" if args.workload in ("sequence", "hd1080") else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": data,

@@ -18,9 +18,11 @@ cp $R/gpurun_out/pmc_traffic.json $R/profiles/${ROUND}_pmc_traffic.json
 cd $R
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err
 timeout 600 python bench.py --gpus 2 --steps 10 --warmup 2 --dist-backend gloo --no-extras --no-cpu-baseline > $O/bench_line_2ranks_gloo_1gpu.json 2> /dev/null
-timeout 600 python bench.py --workload hd1080 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_line_hd1080.json 2> /dev/null
-timeout 600 python bench.py --workload hd1080 --stage device --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_device_stage.json 2> /dev/null
-timeout 600 python bench.py --workload hd1080 --batch 64 --group 8 --lanes 6 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_x64.json 2> /dev/null
+# hd1080 = configs[3]: the batch of 64 pairs on this one GPU (the default); then the share of one GPU of
+# eight (8 pairs per step: latency-bound) on the host stage (automatic there) and on the device stage
+timeout 600 python bench.py --workload hd1080 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_hd1080.json 2> /dev/null
+timeout 600 python bench.py --workload hd1080 --batch 8 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_b8.json 2> /dev/null
+timeout 600 python bench.py --workload hd1080 --batch 8 --stage device --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_b8_device_stage.json 2> /dev/null
 timeout 600 python bench.py --workload hd1080 --batch 256 --group 16 --lanes 6 --steps 8 --warmup 2 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_x256.json 2> /dev/null
 timeout 600 python bench.py --workload hd1080 --stage host --batch 64 --group 4 --lanes 8 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_x64_host_stage.json 2> /dev/null
 timeout 600 python bench.py --lanes 3 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_lanes3.json 2> /dev/null
@@ -39,8 +41,8 @@ kt() {  # name cmd...
   [ -n "$DB" ] && python $R/tools/rocpd_summary.py $DB > $O/kernel_stats_$name.txt
 }
 kt kitti python $R/bench.py --no-extras --no-cpu-baseline --steps 12 --warmup 3
-kt hd1080 python $R/bench.py --workload hd1080 --no-extras --no-cpu-baseline --steps 20 --warmup 5
-kt hd1080_x64 python $R/bench.py --workload hd1080 --batch 64 --group 8 --lanes 6 --no-extras --no-cpu-baseline --steps 8 --warmup 3
+kt hd1080 python $R/bench.py --workload hd1080 --no-extras --no-cpu-baseline --steps 8 --warmup 3
+kt hd1080_b8 python $R/bench.py --workload hd1080 --batch 8 --no-extras --no-cpu-baseline --steps 20 --warmup 5
 kt sequence python $R/bench.py --workload sequence --no-extras --no-cpu-baseline --steps 12 --warmup 3
 kt matcher python $R/tools/gpu_legs.py matcher
 kt vo python $R/tools/gpu_legs.py vo
@@ -49,7 +51,7 @@ kt vo_replicas16 python $R/tools/gpu_legs.py replicas16
 ls -la $O | tail -20
 python - <<PY
 import json
-for f in ("bench_line","bench_line_2ranks_gloo_1gpu","bench_line_hd1080","bench_line_hd1080_device_stage","bench_line_hd1080_x64","bench_line_hd1080_x256","bench_line_hd1080_x64_host_stage","bench_line_sequence","bench_line_lanes3","bench_line_lanes6","bench_line_soak60","bench_line_1rank_nccl"):
+for f in ("bench_line","bench_line_2ranks_gloo_1gpu","bench_line_hd1080","bench_line_hd1080_b8","bench_line_hd1080_b8_device_stage","bench_line_hd1080_x256","bench_line_hd1080_x64_host_stage","bench_line_sequence","bench_line_lanes3","bench_line_lanes6","bench_line_soak60","bench_line_1rank_nccl"):
     try:
         d=json.loads([l for l in open("$O/%s.json"%f) if l.startswith("{")][-1])
         print(f, round(d["value"]), "n_gpus", d["n_gpus"], "cores", d["config"]["host_cores_used"], d["roofline"]["kernel"], round(d["roofline"]["frac"],3), d.get("outputs_match_golden"), d["config"].get("stage_groups_device_handed_back"))
