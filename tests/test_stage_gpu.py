@@ -81,11 +81,14 @@ def test_device_stage_synthetic(seed, w, h, kw, dev_stage, oracle_lib):
 
 
 @pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
-def test_device_stage_large_image_takes_the_global_memory_forms(dev_stage, oracle_lib):
-    """1920x600: the lattice (384 x 120 cells) does not fit k_lattice's LDS and the ~4 k support
-    points exceed the LDS record capacity of k_delaunay, so the in-place global-memory lattice filter
-    and the 32-bit L2 triangle records run (automatic mode would pick the host stage here)"""
-    l, r = H.synth_pair(1920, 600, 31, dmax=120, planes=8)
+@pytest.mark.parametrize("w,h,seed,dmax", [(1920, 600, 31, 120), (1920, 1080, 32, 230)])
+def test_device_stage_large_image_takes_the_global_memory_forms(w, h, seed, dmax, dev_stage, oracle_lib):
+    """1920x600 / 1920x1080 (BASELINE.json configs[3]): the lattice (384 x 120 / 384 x 216 cells) does not
+    fit k_lattice's LDS and the support points exceed the LDS record capacity of k_delaunay, so the in-place
+    global-memory lattice filter and the 32-bit L2 triangle records run, k_delaunay with 1024 threads and the
+    whole LDS of a CU for its rank and cut-order phases (automatic mode picks the host stage for a single
+    pair of this size)"""
+    l, r = H.synth_pair(w, h, seed, dmax=dmax, planes=8)
     prm = H.robotics()
     before = dev_stage.stage_stats()
     got = product_run(dev_stage, prm, l, r)
@@ -104,7 +107,7 @@ FUZZ_SHAPES = [(320, 200), (401, 177), (512, 160), (288, 240)]
 @pytest.mark.parametrize("seed", range(300, 330))
 def test_device_stage_param_fuzz(seed, dev_stage, oracle_lib):
     """every field of Elas::parameters moves; small candidate steps with a wide L/R threshold
-    produce coincident right-image points, which the device hands back to the host path"""
+    produce coincident right-image points (k_delaunay replays Triangle's quicksort for those)"""
     prm = H.fuzz_elas_params(seed)
     w, h = FUZZ_SHAPES[seed % 4]
     l, r = H.synth_pair(w, h, seed, dmax=min(48, prm.disp_max - 8))
