@@ -796,7 +796,15 @@ __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const 
         const unsigned* cfl = FL + (size_t)((d + 1) & 1) * sup_cap;
         const unsigned* cfr = FR + (size_t)((d + 1) & 1) * sup_cap;
         const unsigned tasks = 1u << d;
-        for (unsigned j = tid; j < tasks; j += kT) {
+        // Large triangulations (1024 threads, records in L2): consecutive nodes go to DIFFERENT waves (lane
+        // l of wave w takes node l * waves + w).  The merges of one depth run the same code but branch
+        // apart at every seam step, and every step is a chain of L2 round trips: sixteen waves keep sixteen
+        // chains in flight where one wave kept one (1920x1080: build 1 290 -> 940 us).  With the records in
+        // LDS (KITTI size, 256 threads) the same spreading is slower (634 -> 744 us): there a step is
+        // instruction-bound and the lanes of one wave share most of it.
+        constexpr unsigned kWaves = kT / 64;
+        const unsigned j0 = kT >= 1024 ? (unsigned)(tid & 63) * kWaves + (unsigned)(tid >> 6) : (unsigned)tid;
+        for (unsigned j = j0; j < tasks; j += kT) {
             int s, n, base;
             if (!dt_descend(m, d, j, &s, &n, &base)) continue;
             unsigned a, b;
