@@ -142,6 +142,7 @@ struct Lane {
     float* planes = nullptr;       // 6 per triangle
     uint32_t* seed = nullptr;      // [gcap][2][cells][gwords]
     uint32_t* mask = nullptr;
+    uint16_t* lists = nullptr;     // [gcap][2][cells][64] candidate records (k_grid_list)
     float* Draw = nullptr;         // [gcap][2][DN]
     float* D = nullptr;            // [gcap][2][DN]  (host-output mode)
     float* tmp = nullptr;          // [gcap][2][DN]
@@ -172,7 +173,7 @@ struct Lane {
         (void)hipSetDevice(device);
         (void)hipFree(img); (void)hipFree(desc); (void)hipFree(dcan); (void)hipFree(owner);
         (void)hipFree(prior_dev); (void)hipFree(raster); (void)hipFree(planes); (void)hipFree(seed);
-        (void)hipFree(mask); (void)hipFree(Draw); (void)hipFree(D); (void)hipFree(tmp);
+        (void)hipFree(mask); (void)hipFree(lists); lists = nullptr; (void)hipFree(Draw); (void)hipFree(D); (void)hipFree(tmp);
         (void)hipFree(labels); (void)hipFree(counts); (void)hipFree(seg_nroots); seg_nroots = nullptr;
         img = desc = prior_dev = nullptr; dcan = nullptr; owner = nullptr; raster = nullptr;
         planes = Draw = D = tmp = nullptr; seed = mask = nullptr; labels = counts = nullptr;
@@ -245,6 +246,7 @@ struct Lane {
         const size_t gw_bytes = G2 * d.gw * d.gh * d.gwords * sizeof(uint32_t);
         HIP_TRY(hipMalloc(&seed, gw_bytes));
         HIP_TRY(hipMalloc(&mask, gw_bytes));
+        if (d.gwords == 8) HIP_TRY(hipMalloc(&lists, G2 * d.gw * d.gh * 64 * sizeof(uint16_t)));
         hp.resize(g);
         // fixed layout of the packed lists when the device builds them
         o_P = (sizeof(GroupHdr) + 63) & ~(size_t)63;
@@ -553,6 +555,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         G.planes = L.planes;
         G.seed = L.seed;
         G.mask = L.mask;
+        G.lists = L.lists;
         G.desc = L.desc;
         G.owner = L.owner;
         // triangle ownership is stored as owner_base + 1 + index; the base moves above everything
