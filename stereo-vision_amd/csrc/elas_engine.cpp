@@ -142,7 +142,7 @@ struct Lane {
     float* planes = nullptr;       // 6 per triangle
     uint32_t* seed = nullptr;      // [gcap][2][cells][gwords]
     uint32_t* mask = nullptr;
-    uint16_t* lists = nullptr;     // [gcap][2][cells][64] candidate records (k_grid_list)
+    uint16_t* lists = nullptr;     // [gcap][2][cells][32] candidate records (k_grid_list)
     float* Draw = nullptr;         // [gcap][2][DN]
     float* D = nullptr;            // [gcap][2][DN]  (host-output mode)
     float* tmp = nullptr;          // [gcap][2][DN]
@@ -246,7 +246,7 @@ struct Lane {
         const size_t gw_bytes = G2 * d.gw * d.gh * d.gwords * sizeof(uint32_t);
         HIP_TRY(hipMalloc(&seed, gw_bytes));
         HIP_TRY(hipMalloc(&mask, gw_bytes));
-        if (d.gwords == 8) HIP_TRY(hipMalloc(&lists, G2 * d.gw * d.gh * 64 * sizeof(uint16_t)));
+        if (d.gwords == 8) HIP_TRY(hipMalloc(&lists, G2 * d.gw * d.gh * 32 * sizeof(uint16_t)));
         hp.resize(g);
         // fixed layout of the packed lists when the device builds them
         o_P = (sizeof(GroupHdr) + 63) & ~(size_t)63;

@@ -18,7 +18,6 @@
 
 #include <algorithm>
 #include <cstdlib>
-#include <mutex>
 
 #include "svh_internal.h"
 
@@ -680,29 +679,33 @@ __global__ __launch_bounds__(256) void k_grid_dilate(GroupDev G, int slots, int 
     G.mask[i] = o;
 }
 
-// Candidate records for k_match_walk (disp_max <= 255): one wave per cell turns the cell's 256-bit set into
-// 64 uint16: [0] = number of candidates, [1..63] = the first 63 of them, ascending, as 16 * d (the byte
-// offset of the candidate in a descriptor row = the rank field of the matcher's keys).  Cells with more
-// than 63 candidates are decoded from the bit set by the matcher itself.
+// Candidate records for k_match_list (disp_max <= 255): one wave per cell turns the cell's 256-bit set into
+// ML_CAP = 32 uint16: [0..27] the candidates, ascending, as 16 * d (the byte offset of the candidate in a
+// descriptor row), padded with the last one; [28..30] the last candidate; [31] their number.  Cells with more
+// than 28 candidates are decoded from the bit set by the matcher itself.
 __global__ __launch_bounds__(256) void k_grid_list(GroupDev G, int ncells) {
     const int lane = threadIdx.x & 63;
     const int cell = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
     if (cell >= ncells) return;
     const uint32_t* bits = G.mask + (size_t)cell * 8;
     const uint32_t wq = lane < 8 ? bits[lane] : 0u;
-    uint16_t* rec = G.lists + (size_t)cell * 64;
-    int n = 0;
+    uint16_t* rec = G.lists + (size_t)cell * 32;
+    int n = 0, last = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint64_t m = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wq, 2 * q) |
                            ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wq, 2 * q + 1) << 32);
         if ((m >> lane) & 1) {
             const int idx = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (idx < 63) rec[1 + idx] = (uint16_t)((64 * q + lane) * 16);
+            if (idx < 28) rec[idx] = (uint16_t)((64 * q + lane) * 16);
         }
+        if (m) last = 64 * q + 63 - __builtin_clzll(m);
         n += __builtin_popcountll(m);
     }
-    if (lane == 0) rec[0] = (uint16_t)n;
+    // (the padding is written by other lanes than the candidates: no ordering needed)
+    if (lane < 31 && lane >= n) rec[lane] = (uint16_t)(last * 16);
+    if (lane == 31) rec[31] = (uint16_t)n;
+    if (lane >= 28 && lane < 31 && lane < n) rec[lane] = (uint16_t)(last * 16);
 }
 
 // ---------------------------------------------------------------------------
@@ -1098,47 +1101,47 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P, 
 }
 
 // ---------------------------------------------------------------------------
-// E11 + E12, row-group walker (round 4; the default for the presets).
+// E11 + E12, list form (round 4; the default for the presets).
 //   Elas::findMatch / updatePosteriorMinimum     libelas/src/elas.cpp:784-955
 //   Elas::leftRightConsistencyCheck              libelas/src/elas.cpp:1122-1204
-// k_match_keyed spends ~19 VALU operations per candidate: every lane decodes its own cell's bit set,
-// a wave of 64 consecutive pixels spans 3-4 grid cells (it runs as long as the longest of their
-// lists), and a block stages its two rows, scans them and exits -- nothing overlaps the staging.
-// Here:
-//  * a wave's 64 lanes are ONE grid cell (grid_size columns) x 3 image rows, so the candidate list
-//    is wave-uniform: it is decoded once per wave into LDS (ballot order = ascending d = the
-//    reference's list order) and read back four candidates per broadcast ds_read_b128;
-//  * a candidate costs 5.5 VALU operations: one address add, four v_sad_hi_u8 -- the instruction
-//    accumulates (SAD << 16) on top of its third operand, so a chain started on `rank` IS the
-//    key  cost << 16 | rank  of the keyed minimum -- and half a v_min3_i32;
-//  * cell candidates inside the plane band are NOT excluded per lane (elas.cpp:871): the band scan
+// Block structure of k_match_keyed (one block = one image row of one pair, both maps, the two
+// descriptor rows staged once, raw disparities and the L/R check in LDS), with the scan rebuilt:
+//  * candidates come from per-cell LISTS (k_grid_list: 32 uint16 per cell, 16*d, padded with the last
+//    one), staged in LDS with the rows: a lane reads four candidates with one ds_read_b64 instead of
+//    decoding its cell's bit set (~19 operations per candidate before);
+//  * a candidate costs one address operation, four v_sad_hi_u8 and half a v_min3: the instruction
+//    accumulates (SAD << 16) on top of its third operand, so a chain started on the candidate's rank
+//    (its list index; 512 + d in the plane band) IS the key  cost << 16 | rank  of the keyed minimum;
+//  * cell candidates inside the plane band are not excluded per lane (elas.cpp:871): the band scan
 //    evaluates the same disparity with its prior, and while every prior of the band is negative
 //    (and the plane valid) that key is strictly smaller, so the extra key never wins; waves that
-//    cannot rely on this take the checked form of the loop;
-//  * one persistent block per CU walks row groups (3 rows of one pair): 15 matching waves and one
-//    LOADER wave.  The loader lands the 3 descriptor rows of the other image for the NEXT pass with
-//    global_load_lds_dwordx4 (LDS-DMA, no registers) into the second of two 60 KB row buffers
-//    while the matching waves scan the first; passes alternate left map / right map.  The raw
-//    disparities of a row group stay in LDS (int16) and the L/R check runs on them while the next
-//    group's left pass is already under way;
-//  * rows are S slots apart with S = 4 (mod 16): the three rows of a wave then fall into disjoint
-//    bank quarters of every ds_read_b128 lane group and the scan is conflict-free.
+//    cannot rely on this, or sit next to the image border, take the checked form of the loops;
+//  * rows and lists land by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write
+//    pass; owner words and planes of all of a thread's pixels are requested before the scan starts.
 // ---------------------------------------------------------------------------
-constexpr int MW_ROWS = 3;      // image rows per row group
-constexpr int MW_LIST = 128;    // candidates per list chunk (half of a 256-bit set)
-constexpr int MW_WAVES = 16;    // 15 matching waves + 1 loader
-constexpr int MW_ITEMS = 64;    // row groups one block can walk
+constexpr int ML_CAP = 32;     // uint16 per cell record: [0..27] candidates, [28..30] last candidate, [31] count
+constexpr int ML_FAST = 28;    // cells with more candidates are decoded from their bit set
 
-struct MatchWalk {
-    int S;          // LDS row stride in 16-byte slots, == 4 (mod 16)
-    int Wr;         // raw-disparity row stride (int16 entries)
-    int gpc;        // row groups per full cell row = ceil(grid_size / 3)
-    int full_cr;    // cell rows of full height
-    int gpp;        // row groups per pair
-    int total;      // row groups of the launch
-    int dbg;        // timing experiments (SVH_WALK_DBG): 1 no matching, 2 no LDS-DMA, 4 no task loads, 8 no L/R
-};
-
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+// LDS accesses by absolute byte address: keeps the per-candidate arithmetic at one v_sub / v_add
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
+    const u32x4_t q = *(__attribute__((address_space(3))) const u32x4_t*)(uintptr_t)addr;
+    return make_uint4(q.x, q.y, q.z, q.w);
+}
+__device__ __forceinline__ uint2 lds_read8(uint32_t addr) {
+    const u32x2_t q = *(__attribute__((address_space(3))) const u32x2_t*)(uintptr_t)addr;
+    return make_uint2(q.x, q.y);
+}
+__device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
+    return *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)addr;
+}
+__device__ __forceinline__ uint32_t lds_read2(uint32_t addr) {
+    return *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)addr;
+}
 __device__ __forceinline__ int sad_hi16(const uint4& a, const uint4& b, uint32_t k) {
     k = __builtin_amdgcn_sad_hi_u8(a.x, b.x, k);
     k = __builtin_amdgcn_sad_hi_u8(a.y, b.y, k);
@@ -1150,288 +1153,147 @@ __device__ __forceinline__ int min3i(int a, int b, int c) {
     const int m = b < c ? b : c;
     return a < m ? a : m;
 }
-
-// the loader's share: rows row0 .. row0+nrows-1 of one descriptor map -> buf, S slots apart
-__device__ __forceinline__ void mw_issue_rows(uint4* buf, const uint4* img_desc, int row0, int nrows, int W, int H,
-                                              int S, int lane) {
-    const int total = nrows * S;
-    for (int j0 = 0; j0 < total; j0 += kWave) {
+// n 16-byte slots global -> LDS by the whole block, lane-linear (LDS-DMA)
+__device__ __forceinline__ void dma_slots(uint4* dst, const uint4* src, int n, int wave, int nwaves, int lane) {
+    for (int j0 = wave * kWave; j0 < n; j0 += nwaves * kWave) {
         const int j = j0 + lane;
-        const int r = (j >= S ? 1 : 0) + (j >= 2 * S ? 1 : 0);
-        int i = j - r * S;
-        i = i < W ? i : W - 1;                 // the pad slots of a row repeat its last descriptor
-        int line = row0 + r;
-        line = line < H - 3 ? line : H - 3;    // elas.cpp:829
-        line = line > 2 ? line : 2;
-        if (j < total)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(img_desc + (size_t)line * W + i),
-                (__attribute__((address_space(3))) void*)(buf + j0), 16, 0, 0);
+        if (j < n)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j),
+                                             (__attribute__((address_space(3))) void*)(dst + j0), 16, 0, 0);
     }
 }
 
-struct WalkItem {
-    int pair, cr, row0, nrows;
-};
-__device__ __forceinline__ WalkItem mw_item(int it, const MatchWalk& Q, const MatchParams& P) {
-    WalkItem w;
-    w.pair = it / Q.gpp;
-    const int g = it - w.pair * Q.gpp;
-    int k;
-    if (g < Q.full_cr * Q.gpc) {
-        w.cr = g / Q.gpc;
-        k = g - w.cr * Q.gpc;
-    } else {
-        w.cr = Q.full_cr;
-        k = g - Q.full_cr * Q.gpc;
-    }
-    w.row0 = w.cr * P.grid_size + MW_ROWS * k;
-    int left = P.grid_size - MW_ROWS * k;
-    left = left < P.H - w.row0 ? left : P.H - w.row0;
-    w.nrows = left < MW_ROWS ? left : MW_ROWS;
-    return w;
-}
-
-// LDS accesses by absolute byte address (the row buffers sit at runtime offsets of the dynamic
-// segment; an integer address keeps the per-candidate arithmetic at one v_sub / v_add)
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) const u32x4_t* lds_u4_ptr;
-__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
-__device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
-    const u32x4_t q = *(lds_u4_ptr)(uintptr_t)addr;
-    return make_uint4(q.x, q.y, q.z, q.w);
-}
-
-// per-lane constants of a matching wave: lane = row r (0..2) x column col (0..grid_size-1) of a cell
-struct WalkLane {
-    int r, col;
-    bool ok;          // col < grid_size (lanes beyond 3 * grid_size idle)
-    int off_px;       // r * W + col
-    uint32_t off_row; // (r * S + col) * 16: byte offset of the lane's pixel from (row 0, cell start) in a row buffer
-    int off_raw;      // r * Wr + col
+struct MatchList {
+    int kIters;      // pixels per thread (template argument of the launch)
+    int Wr;          // raw-row stride (int16)
+    int dbg;
 };
 
-// What a wave knows about one of its tasks (a grid cell x row group of one map) ahead of running
-// it: where it is (uniform) and the loads already in flight for it (per lane).
-struct WalkTask {
-    int ph, c;         // pass number of the block (2 * row group + map), cell
-    uint32_t pk;       // row group: pair | cell row << 5 | k << 13 | rows << 16 | active << 18 ; 0: no task
-    int tri0;          // first triangle of the (pair, map) slot
-    int t;             // owner word, then owning triangle (< 0: none)
-    uint4 own;         // the pixel's own descriptor
-    uint32_t rec;      // lane 0: candidates of the cell, lane i > 0: candidate i - 1 (16 * d)
-    float4 pl;         // plane + validity of the owning triangle
-};
-__device__ __forceinline__ int wt_pair(uint32_t pk) { return (int)(pk & 31u); }
-__device__ __forceinline__ int wt_cr(uint32_t pk) { return (int)((pk >> 5) & 255u); }
-__device__ __forceinline__ int wt_k(uint32_t pk) { return (int)((pk >> 13) & 7u); }
-__device__ __forceinline__ int wt_rows(uint32_t pk) { return (int)((pk >> 16) & 3u); }
-__device__ __forceinline__ bool wt_active(uint32_t pk) { return (pk >> 18) & 1u; }
-
-// stage 1 of a task's loads: owner word, own descriptor, the cell's candidate record.  The loads are
-// issued UNCONDITIONALLY (lanes and tasks without work read a valid dummy address): a load under a
-// branch makes hipcc wait with vmcnt(0) at the next use of any older load, which would drain the
-// prefetches of the following tasks with it.
-__device__ __forceinline__ void mw_fetch1(WalkTask& T, const WalkLane& L, const GroupDev& G, const MatchParams& P,
-                                          int lane) {
-    const bool act = wt_active(T.pk);
-    const int side = T.ph & 1, z = act ? 2 * wt_pair(T.pk) + side : 0, cr = act ? wt_cr(T.pk) : 0;
-    const int c = act ? T.c : 0;
-    const int row0 = act ? cr * P.grid_size + MW_ROWS * wt_k(T.pk) : 0;
-    const size_t N = (size_t)P.W * P.H;
-    const int u = c * P.grid_size + L.col;
-    const bool inner = act && L.ok && L.r < wt_rows(T.pk) && (uint32_t)(u - 2) < (uint32_t)(P.W - 4);
-    const int32_t* own_row = G.owner + (size_t)z * N + (size_t)row0 * P.W + c * P.grid_size;   // uniform
-    const int32_t t = own_row[inner ? (uint32_t)L.off_px : 0u];
-    T.t = inner ? t : 0;              // 0 <= owner_base: reads as "no triangle" in mw_fetch2
-    int line = row0 + L.r;
-    line = line < P.H - 3 ? line : P.H - 3;
-    line = line > 2 ? line : 2;
-    const uint4* dz = reinterpret_cast<const uint4*>(G.desc) + (size_t)z * N;   // uniform
-    T.own = dz[inner ? (uint32_t)(line * P.W + u) : 0u];
-    const uint16_t* rec = G.lists + ((size_t)z * P.gw * P.gh + (size_t)cr * P.gw + c) * 64;   // uniform
-    T.rec = rec[(uint32_t)lane];
-}
-// stage 2: the plane of the owning triangle (needs the owner word)
-__device__ __forceinline__ void mw_fetch2(WalkTask& T, const GroupDev& G) {
-    T.t = T.t - G.owner_base - 1;     // values <= owner_base are leftovers of earlier groups
-    T.pl = *reinterpret_cast<const float4*>(G.raster + (T.t >= 0 ? (uint32_t)(T.tri0 + T.t) : 0u));
-}
-
-// kSide = 0: left map (candidate u - d in image 2's rows), 1: right map (u + d in image 1's rows)
-template <int kSide, bool kFast>
-__device__ __forceinline__ int mw_scan(const uint32_t* list, int n, uint32_t rowaddr, const uint4& own, int best,
-                                       int u, int W, int dlo, uint32_t blen, bool has_band) {
-    if (kFast) {
-        uint4 cc = *reinterpret_cast<const uint4*>(list);
-        for (int i = 0; i < n; i += 4) {
-            const uint4 cn = *reinterpret_cast<const uint4*>(list + i + 4);   // next trip's four
-            const uint4 o0 = lds_read16(kSide ? rowaddr + cc.x : rowaddr - cc.x);
-            const uint4 o1 = lds_read16(kSide ? rowaddr + cc.y : rowaddr - cc.y);
-            const uint4 o2 = lds_read16(kSide ? rowaddr + cc.z : rowaddr - cc.z);
-            const uint4 o3 = lds_read16(kSide ? rowaddr + cc.w : rowaddr - cc.w);
-            best = min3i(best, sad_hi16(own, o0, cc.x), sad_hi16(own, o1, cc.y));
-            best = min3i(best, sad_hi16(own, o2, cc.z), sad_hi16(own, o3, cc.w));
-            cc = cn;
+// the reference's scan of one pixel, list form.  rowaddr: LDS address of the other image's slot at this
+// pixel's column; lrec: LDS address of the cell's record
+template <int kSide>
+__device__ __forceinline__ int ml_pixel(const uint4& own, const float4& pl, int u, int v, uint32_t rowaddr,
+                                        uint32_t lrec, const int* s_band, int neg_prior, const MatchParams& P,
+                                        const uint32_t* __restrict__ bits) {
+    const int valid = __float_as_int(pl.w);
+    const int d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pl.x, (float)u), __fmul_rn(pl.y, (float)v)), pl.z);
+    const int rad = P.plane_radius;
+    int dlo = d_plane - rad;
+    dlo = dlo > 0 ? dlo : 0;
+    int dhi = d_plane + rad;
+    dhi = dhi < P.disp_max ? dhi : P.disp_max;
+    const uint32_t blen = (uint32_t)(dhi - dlo);
+    const bool has_band = dhi >= dlo;
+    const uint32_t tail = lds_read4(lrec + 2 * (ML_CAP - 2));   // [30] last candidate, [31] count
+    const int n = (int)(tail >> 16), dmax = (int)(tail & 0xFFFFu) >> 4;
+    const bool cell_in = kSide ? u + dmax < P.W - 2 : u - dmax >= 2;
+    const bool band_in = d_plane - rad >= 0 && d_plane + rad <= P.disp_max &&
+                         (kSide ? u + d_plane + rad < P.W - 2 : u - d_plane - rad >= 2);
+    // wave-uniform choice of the loop forms (this function runs under "live" lanes only)
+    const bool big = __builtin_amdgcn_ballot_w64(n > ML_FAST) != 0;
+    const bool fast = !big && neg_prior && __builtin_amdgcn_ballot_w64(!(valid && cell_in && band_in)) == 0;
+    int best = 0x7FFFFFFF;
+    if (fast) {
+        // ---- cell candidates, four per trip; rank = list index (ascending d, the reference's order)
+        for (int i = 0; __builtin_amdgcn_ballot_w64(i < n) != 0; i += 4) {
+            if (i >= n) continue;   // (an empty record is padded with d = 0, which is not a candidate)
+            const uint2 cc = lds_read8(lrec + 2 * i);
+            const uint32_t c0 = cc.x & 0xFFFFu, c1 = cc.x >> 16, c2 = cc.y & 0xFFFFu, c3 = cc.y >> 16;
+            const uint4 o0 = lds_read16(kSide ? rowaddr + c0 : rowaddr - c0);
+            const uint4 o1 = lds_read16(kSide ? rowaddr + c1 : rowaddr - c1);
+            const uint4 o2 = lds_read16(kSide ? rowaddr + c2 : rowaddr - c2);
+            const uint4 o3 = lds_read16(kSide ? rowaddr + c3 : rowaddr - c3);
+            best = min3i(best, sad_hi16(own, o0, (uint32_t)i), sad_hi16(own, o1, (uint32_t)i + 1));
+            best = min3i(best, sad_hi16(own, o2, (uint32_t)i + 2), sad_hi16(own, o3, (uint32_t)i + 3));
         }
-    } else {
-        for (int i = 0; i < n; i += 2) {
-            const uint2 cc = *reinterpret_cast<const uint2*>(list + i);
-            const int d0 = (int)(cc.x >> 4), d1 = (int)(cc.y >> 4);
+        // ---- the plane band with its prior, two disparities per trip; rank = 512 + d
+        const int nb = 2 * rad + 1;
+        const uint32_t a0 = kSide ? rowaddr + (uint32_t)(d_plane - rad) * 16u : rowaddr - (uint32_t)(d_plane - rad) * 16u;
+        const uint32_t rk0 = (uint32_t)(512 + d_plane - rad);
+        for (int k = 0; k < nb; k += 2) {
+            const int k1 = k + 1 < nb ? k + 1 : k;
+            const uint4 o0 = lds_read16(kSide ? a0 + 16u * k : a0 - 16u * k);
+            const uint4 o1 = lds_read16(kSide ? a0 + 16u * k1 : a0 - 16u * k1);
+            const int key0 = sad_hi16(own, o0, rk0 + (uint32_t)k + (uint32_t)s_band[k]);
+            const int key1 = sad_hi16(own, o1, rk0 + (uint32_t)k1 + (uint32_t)s_band[k1]);
+            best = min3i(best, key0, key1);
+        }
+        if (best == 0x7FFFFFFF) return -1;
+        const int rank = best & 0xFFFF;
+        return rank >= 512 ? rank - 512 : (int)(lds_read2(lrec + 2 * rank) >> 4);
+    }
+    // ---- checked form: per-candidate range and band tests.  rank = d (cell), 512 + d (band)
+    if (!big) {
+        for (int i = 0; __builtin_amdgcn_ballot_w64(i < n) != 0; i += 2) {
+            if (i >= n) continue;
+            const uint32_t cc = lds_read4(lrec + 2 * i);
+            const uint32_t c0 = cc & 0xFFFFu, c1 = cc >> 16;
+            const int d0 = (int)(c0 >> 4), d1 = (int)(c1 >> 4);
             const int u0 = kSide ? u + d0 : u - d0, u1 = kSide ? u + d1 : u - d1;
-            const bool ok0 = (uint32_t)(u0 - 2) < (uint32_t)(W - 4) && !(has_band && (uint32_t)(d0 - dlo) <= blen);
-            const bool ok1 = (uint32_t)(u1 - 2) < (uint32_t)(W - 4) && !(has_band && (uint32_t)(d1 - dlo) <= blen);
-            const uint4 o0 = lds_read16(ok0 ? (kSide ? rowaddr + cc.x : rowaddr - cc.x) : rowaddr);
-            const uint4 o1 = lds_read16(ok1 ? (kSide ? rowaddr + cc.y : rowaddr - cc.y) : rowaddr);
-            const int k0 = ok0 ? sad_hi16(own, o0, cc.x) : 0x7FFFFFFF;
-            const int k1 = ok1 ? sad_hi16(own, o1, cc.y) : 0x7FFFFFFF;
+            const bool ok0 = (uint32_t)(u0 - 2) < (uint32_t)(P.W - 4) && !(has_band && (uint32_t)(d0 - dlo) <= blen);
+            const bool ok1 = (uint32_t)(u1 - 2) < (uint32_t)(P.W - 4) && !(has_band && (uint32_t)(d1 - dlo) <= blen);
+            const uint4 o0 = lds_read16(ok0 ? (kSide ? rowaddr + c0 : rowaddr - c0) : rowaddr);
+            const uint4 o1 = lds_read16(ok1 ? (kSide ? rowaddr + c1 : rowaddr - c1) : rowaddr);
+            const int k0 = ok0 ? sad_hi16(own, o0, (uint32_t)d0) : 0x7FFFFFFF;
+            const int k1 = ok1 ? sad_hi16(own, o1, (uint32_t)d1) : 0x7FFFFFFF;
             best = min3i(best, k0, k1);
         }
-    }
-    return best;
-}
-
-template <int kSide>
-__device__ __forceinline__ void mw_compute(const WalkTask& T, const WalkLane& L, const GroupDev& G,
-                                           const MatchParams& P, const MatchWalk& Q, uint32_t buf_addr, int16_t* raw,
-                                           uint32_t* list, const int* s_band, int neg_prior, int lane,
-                                           int write_raw) {
-    const int gs = P.grid_size;
-    const int row0 = wt_cr(T.pk) * gs + MW_ROWS * wt_k(T.pk);
-    const int u = T.c * gs + L.col, v = row0 + L.r;
-    const bool in_tile = L.ok && L.r < wt_rows(T.pk) && u < P.W;
-    const uint4 own = T.own;
-    const bool live = T.t >= 0 && (int)texture16(own) >= P.match_texture;   // t >= 0 implies 2 <= u < W-2
-    int res = -10;
-    if (__builtin_amdgcn_ballot_w64(live) != 0) {
-        const int n = __builtin_amdgcn_readfirstlane((int)T.rec);             // candidates of the cell
-        const float4 pl = T.pl;
-        const int valid = __float_as_int(pl.w);
-        const int d_plane =
-            (int)__fadd_rn(__fadd_rn(__fmul_rn(pl.x, (float)u), __fmul_rn(pl.y, (float)v)), pl.z);
-        const int rad = P.plane_radius;
-        int dlo = d_plane - rad;
-        dlo = dlo > 0 ? dlo : 0;
-        int dhi = d_plane + rad;
-        dhi = dhi < P.disp_max ? dhi : P.disp_max;
-        const uint32_t blen = (uint32_t)(dhi - dlo);
-        const bool has_band = dhi >= dlo;
-        const uint32_t rowaddr = buf_addr + (uint32_t)(T.c * gs) * 16u + L.off_row;   // LDS address of the pixel's slot
-        int best = 0x7FFFFFFF;
-        if (n <= 63) {
-            // ---- the cell's candidates came with the task (k_grid_list): into the wave's LDS list,
-            // padded with the last one up to a multiple of four (a repeated candidate is harmless)
-            const int dmax16 = n > 0 ? __builtin_amdgcn_readlane((int)T.rec, n) : 0;   // lists ascend
-            const uint32_t e = lane <= n ? T.rec : (uint32_t)dmax16;
-            if (lane > 0) list[lane - 1] = e;
-            if (lane < 8) list[63 + lane] = (uint32_t)dmax16;
-            // wave-uniform fast path: plane valid, priors negative, nothing warps out of the row
-            const int dmax = dmax16 >> 4;
-            const bool cell_in = kSide ? u + dmax < P.W - 2 : u - dmax >= 2;
-            const bool band_in = d_plane - rad >= 0 && d_plane + rad <= P.disp_max &&
-                                 (kSide ? u + d_plane + rad < P.W - 2 : u - d_plane - rad >= 2);
-            const bool fast = neg_prior && __builtin_amdgcn_ballot_w64(live && !(valid && cell_in && band_in)) == 0;
-            if (live) {
-                // cell candidates (elas.cpp:868-880 / 902-914)
-                if (Q.dbg & 16) {
-                } else if (fast)
-                    best = mw_scan<kSide, true>(list, n, rowaddr, own, best, u, P.W, dlo, blen, has_band);
-                else
-                    best = mw_scan<kSide, false>(list, n, rowaddr, own, best, u, P.W, dlo, blen, has_band);
-                // the plane band with its prior (elas.cpp:881-890 / 916-926), two disparities per trip
-                const int nb = 2 * rad + 1;
-                if (Q.dbg & 32) {
-                } else if (fast) {
-                    const uint32_t a0 = kSide ? rowaddr + (uint32_t)(d_plane - rad) * 16u
-                                              : rowaddr - (uint32_t)(d_plane - rad) * 16u;
-                    const uint32_t rk0 = (uint32_t)(512 + d_plane - rad) * 16u;
-                    for (int k = 0; k < nb; k += 2) {
-                        const int k1 = k + 1 < nb ? k + 1 : k;
-                        const uint4 o0 = lds_read16(kSide ? a0 + 16u * k : a0 - 16u * k);
-                        const uint4 o1 = lds_read16(kSide ? a0 + 16u * k1 : a0 - 16u * k1);
-                        const int key0 = sad_hi16(own, o0, rk0 + 16u * k + (uint32_t)s_band[k]);
-                        const int key1 = sad_hi16(own, o1, rk0 + 16u * k1 + (uint32_t)s_band[k1]);
-                        best = min3i(best, key0, key1);
-                    }
-                }
-            }
-            if (!fast && live) {
-                for (int dc = dlo; dc <= dhi; dc++) {
-                    const int uw = kSide ? u + dc : u - dc;
-                    const bool ok = (uint32_t)(uw - 2) < (uint32_t)(P.W - 4);
-                    const uint4 o = lds_read16(ok ? (kSide ? rowaddr + 16u * dc : rowaddr - 16u * dc) : rowaddr);
-                    int dd = dc - d_plane;
-                    dd = dd < 0 ? -dd : dd;
-                    const uint32_t pr = valid ? (uint32_t)s_band[rad + dd] : 0u;
-                    const int key = sad_hi16(own, o, (uint32_t)(512 + dc) * 16u + pr);
-                    best = ok && key < best ? key : best;
-                }
-            }
-        } else {
-            // ---- more than 63 candidates (rare): decode the cell's bit set, 64 disparities per chunk,
-            // everything in the checked form
-            const uint32_t* bits = G.mask + ((size_t)(2 * wt_pair(T.pk) + kSide) * P.gw * P.gh +
-                                             (size_t)wt_cr(T.pk) * P.gw + T.c) * 8;
-            const uint32_t wq = lane < 8 ? bits[lane] : 0u;
-#pragma unroll 1
-            for (int q = 0; q < 4; q++) {
-                const uint64_t m = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wq, 2 * q) |
-                                   ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wq, 2 * q + 1) << 32);
-                if (m == 0) continue;
-                const int nq = __builtin_popcountll(m);
-                if ((m >> lane) & 1)
-                    list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] =
-                        (uint32_t)(64 * q + lane) * 16u;
-                if (lane < 2) list[nq + lane] = (uint32_t)(64 * q + 63 - __builtin_clzll(m)) * 16u;
-                if (live) best = mw_scan<kSide, false>(list, nq, rowaddr, own, best, u, P.W, dlo, blen, has_band);
-            }
-            if (live) {
-                for (int dc = dlo; dc <= dhi; dc++) {
-                    const int uw = kSide ? u + dc : u - dc;
-                    const bool ok = (uint32_t)(uw - 2) < (uint32_t)(P.W - 4);
-                    const uint4 o = lds_read16(ok ? (kSide ? rowaddr + 16u * dc : rowaddr - 16u * dc) : rowaddr);
-                    int dd = dc - d_plane;
-                    dd = dd < 0 ? -dd : dd;
-                    const uint32_t pr = valid ? (uint32_t)s_band[rad + dd] : 0u;
-                    const int key = sad_hi16(own, o, (uint32_t)(512 + dc) * 16u + pr);
-                    best = ok && key < best ? key : best;
-                }
+    } else {
+        // a cell of the wave holds more candidates than a record: every lane decodes its cell's bit set
+        for (int q = 0; q < 8; q++) {
+            uint32_t b = bits[q];
+            while (b) {
+                const int dc = q * 32 + __builtin_ctz(b);
+                b &= b - 1;
+                const int uw = kSide ? u + dc : u - dc;
+                if ((uint32_t)(uw - 2) >= (uint32_t)(P.W - 4) || (has_band && (uint32_t)(dc - dlo) <= blen)) continue;
+                const uint4 o = lds_read16(kSide ? rowaddr + 16u * dc : rowaddr - 16u * dc);
+                const int key = sad_hi16(own, o, (uint32_t)dc);
+                best = key < best ? key : best;
             }
         }
-        if (live) res = best != 0x7FFFFFFF ? ((best >> 4) & 255) : -1;
     }
-    if (in_tile) {
-        raw[T.c * gs + L.off_raw] = (int16_t)res;
-        if (write_raw)
-            G.Draw[(size_t)(2 * wt_pair(T.pk) + kSide) * P.DW * P.DH + (size_t)v * P.DW + u] = (float)res;
+    for (int dc = dlo; dc <= dhi; dc++) {
+        const int uw = kSide ? u + dc : u - dc;
+        const bool ok = (uint32_t)(uw - 2) < (uint32_t)(P.W - 4);
+        const uint4 o = lds_read16(ok ? (kSide ? rowaddr + 16u * dc : rowaddr - 16u * dc) : rowaddr);
+        int dd = dc - d_plane;
+        dd = dd < 0 ? -dd : dd;
+        const uint32_t pr = valid ? (uint32_t)s_band[rad + dd] : 0u;
+        const int key = sad_hi16(own, o, (uint32_t)(512 + dc) + pr);
+        best = ok && key < best ? key : best;
     }
+    return best != 0x7FFFFFFF ? (best & 511) : -1;
 }
 
-// the matching waves wait for their LDS traffic only: loads already issued for the next tasks stay in flight
-__device__ __forceinline__ void mw_barrier_compute() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// the loader's LDS-DMA must have landed before the others pass the barrier
-__device__ __forceinline__ void mw_barrier_loader() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <bool kLr>
-__global__ __launch_bounds__(MW_WAVES * 64) void k_match_walk(GroupDev G, MatchParams P, MatchWalk Q, DevMaps out,
-                                                              int write_raw, float lr_threshold) {
-    extern __shared__ uint4 s_dyn[];   // [2][MW_ROWS * S] descriptor rows | raw [2][2][MW_ROWS][Wr] int16 | lists
-    __shared__ int4 s_tab[MW_ITEMS];   // the block's row groups: packed descriptor, first triangle of both slots
+template <bool kLr, int kIters>
+__global__ __launch_bounds__(512) void k_match_list(GroupDev G, MatchParams P, MatchList Q, DevMaps out,
+                                                    int write_raw, float lr_threshold) {
+    extern __shared__ uint4 s_dyn[];   // rows [2][W] | cell records [2][gw][ML_CAP] u16 | raw [2][Wr] int16
     __shared__ int s_band[32];         // P[|k - radius|] << 16
-    __shared__ int s_neg, s_next;
+    __shared__ int s_neg;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave == MW_WAVES - 1;
-    uint4* bufR = s_dyn;                         // rows of image 2: the left-map pass scans them
-    uint4* bufL = s_dyn + MW_ROWS * Q.S;         // rows of image 1: the right-map pass
-    int16_t* raws = reinterpret_cast<int16_t*>(s_dyn + 2 * MW_ROWS * Q.S);
-    const int raw_side = MW_ROWS * Q.Wr;         // one side's raw rows
-    uint32_t* list = reinterpret_cast<uint32_t*>(raws + 4 * raw_side) + wave * (MW_LIST + 8);
+    const int row_id = blockIdx.x;
+    const int pair = row_id / P.DH, v = row_id - pair * P.DH;
+    if (!G.hdr->active[pair]) return;
     const size_t N = (size_t)P.W * P.H;
-    const int stride = (int)gridDim.x;
-    const int nitems = (Q.total - (int)blockIdx.x + stride - 1) / stride;   // <= MW_ITEMS (launch_match)
+    uint4* s_rows = s_dyn;
+    uint16_t* s_rec = reinterpret_cast<uint16_t*>(s_dyn + 2 * P.W);
+    int16_t* s_raw = reinterpret_cast<int16_t*>(s_rec + 2 * P.gw * ML_CAP);
+    int line = v < P.H - 3 ? v : P.H - 3;
+    line = line > 2 ? line : 2;
+    const int cr = v / P.grid_size, cells = P.gw * P.gh;
+    {
+        const uint4* l1 = reinterpret_cast<const uint4*>(G.desc) + (size_t)(2 * pair) * N + (size_t)line * P.W;
+        dma_slots(s_rows, l1, P.W, wave, (int)(blockDim.x >> 6), lane);
+        dma_slots(s_rows + P.W, l1 + N, P.W, wave, (int)(blockDim.x >> 6), lane);
+        const int rq = P.gw * ML_CAP * 2 / 16;   // uint4 per side
+        const uint4* r1 = reinterpret_cast<const uint4*>(G.lists + ((size_t)(2 * pair) * cells + (size_t)cr * P.gw) * ML_CAP);
+        const uint4* r2 = reinterpret_cast<const uint4*>(G.lists + ((size_t)(2 * pair + 1) * cells + (size_t)cr * P.gw) * ML_CAP);
+        dma_slots(reinterpret_cast<uint4*>(s_rec), r1, rq, wave, (int)(blockDim.x >> 6), lane);
+        dma_slots(reinterpret_cast<uint4*>(s_rec) + rq, r2, rq, wave, (int)(blockDim.x >> 6), lane);
+    }
     if (tid < 32) {
         const int dd = tid - P.plane_radius;
         s_band[tid] = tid <= 2 * P.plane_radius ? (int)((uint32_t)G.P[dd < 0 ? -dd : dd] << 16) : 0;
@@ -1440,123 +1302,68 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_match_walk(GroupDev G, MatchP
         int neg = 1;
         for (int dd = 0; dd <= P.plane_radius; dd++) neg &= G.P[dd] < 0 ? 1 : 0;
         s_neg = neg;
-        s_next = 0;
     }
-    if (tid >= 128 && tid < 128 + nitems) {
-        const WalkItem w = mw_item((int)blockIdx.x + (tid - 128) * stride, Q, P);
-        const int k = (w.row0 - w.cr * P.grid_size) / MW_ROWS;
-        const int act = G.hdr->active[w.pair] && !(Q.dbg & 4) ? 1 : 0;
-        int4 e;
-        e.x = w.pair | w.cr << 5 | k << 13 | w.nrows << 16 | act << 18;
-        e.y = w.pair ? G.hdr->tri_end[2 * w.pair - 1] : 0;
-        e.z = G.hdr->tri_end[2 * w.pair];
-        e.w = 0;
-        s_tab[tid - 128] = e;
+    const int half = blockDim.x >> 1;
+    const int side = tid >= half;                 // wave-uniform: half is a multiple of 64
+    const int z = 2 * pair + side;
+    const int x0 = tid - side * half;
+    // owner words of all of the thread's pixels, then (after the barrier drained them) their planes
+    int tk[kIters];
+    {
+        const int32_t* own_t = G.owner + (size_t)z * N + (size_t)v * P.W;
+#pragma unroll
+        for (int k = 0; k < kIters; k++) {
+            const int u = x0 + k * half;
+            tk[k] = own_t[u < P.W ? u : 0];
+        }
     }
+    const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
     __syncthreads();
-    const int nph = 2 * nitems;
-    if (loader) {
-        const uint4* desc = reinterpret_cast<const uint4*>(G.desc);
-        // pass ph scans image (1 - side)'s rows of row group ph / 2; they are landed during pass ph - 1
-        // iteration ph runs during pass ph - 1: it lands the rows of pass ph in the buffer pass ph - 2 used
-        // (free since barrier ph - 1) and then joins barrier ph, which opens pass ph
-        for (int ph = 0; ph <= nph; ph++) {
-            if (ph < nph) {
-                const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane(s_tab[ph >> 1].x);
-                const int side = ph & 1;
-                if (wt_active(pk) && !(Q.dbg & 2))
-                    mw_issue_rows(side ? bufL : bufR, desc + (size_t)(2 * wt_pair(pk) + 1 - side) * N,
-                                  wt_cr(pk) * P.grid_size + MW_ROWS * wt_k(pk), wt_rows(pk), P.W, P.H, Q.S, lane);
-            }
-            mw_barrier_loader();
-        }
-        return;
+    float4 plk[kIters];
+#pragma unroll
+    for (int k = 0; k < kIters; k++) {
+        const int u = x0 + k * half;
+        int t = tk[k] - G.owner_base - 1;
+        t = (u >= 2 && u < P.W - 2) ? t : -1;
+        tk[k] = t;
+        plk[k] = *reinterpret_cast<const float4*>(G.raster + (t >= 0 ? (uint32_t)(tri0 + t) : 0u));
     }
-    // ---- matching waves: tasks (pass, cell) are claimed from a block-wide counter two ahead of the
-    // one being matched, so that their loads are in flight across the barriers between passes
-    WalkLane L;
-    L.r = lane >= P.grid_size ? (lane >= 2 * P.grid_size ? 2 : 1) : 0;
-    L.col = lane - L.r * P.grid_size;
-    L.ok = L.col < P.grid_size;
-    L.off_px = L.r * P.W + L.col;
-    L.off_row = (uint32_t)(L.r * Q.S + L.col) * 16u;
-    L.off_raw = L.r * Q.Wr + L.col;
-    const int ntasks = nph * P.gw;
-    const uint32_t gw_magic = 0xFFFFFFFFu / (uint32_t)P.gw + 1u;   // n / gw == mulhi(n, magic) for n < 2^16
-    const uint32_t next_addr = lds_addr_of(&s_next);
-    auto claim = [&](WalkTask& T) {
-        int n = 0;
-        if (lane == 0)   // (plain asm: hipcc's atomic optimiser would wrap an atomicAdd in a ballot / mbcnt sequence)
-            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(n) : "v"(next_addr), "v"(1) : "memory");
-        n = __builtin_amdgcn_readfirstlane(n);
-        T.pk = 0u;
-        T.tri0 = 0;
-        T.ph = nph;
-        T.c = 0;
-        if (n < ntasks) {
-            T.ph = (int)__umulhi((uint32_t)n, gw_magic);
-            T.c = n - T.ph * P.gw;
-            const int4 e = s_tab[T.ph >> 1];
-            T.pk = (uint32_t)__builtin_amdgcn_readfirstlane(e.x);
-            T.tri0 = __builtin_amdgcn_readfirstlane((T.ph & 1) ? e.z : e.y);
-        }
-    };
-    const uint32_t addrR = lds_addr_of(bufR), addrL = lds_addr_of(bufL);
     const int neg_prior = s_neg;
-    WalkTask A, B, C;
-    claim(A);
-    mw_fetch1(A, L, G, P, lane);
-    claim(B);
-    mw_fetch1(B, L, G, P, lane);
-    mw_fetch2(A, G);
-    int cur = -1;                    // passes whose opening barrier this wave is through
-    auto lr_check = [&](int item) {
-        // E12 on the raw rows of a row group (they are not written again before the group after next)
-        const uint32_t pk = (uint32_t)s_tab[item].x;
-        if (!kLr || !wt_active(pk) || (Q.dbg & 8)) return;
-        const int16_t* raw = raws + (item & 1) * 2 * raw_side;
-        const int nrows = wt_rows(pk), row0 = wt_cr(pk) * P.grid_size + MW_ROWS * wt_k(pk);
-        int rs = 0, x = tid;
-        for (;;) {
-            while (x >= P.DW) {
-                x -= P.DW;
-                rs++;
+    const uint32_t rows_addr = lds_addr_of(s_rows), rec_addr = lds_addr_of(s_rec) + (uint32_t)(side * P.gw * ML_CAP * 2);
+    const uint32_t own_base = rows_addr + (uint32_t)(side * P.W) * 16u, oth_base = rows_addr + (uint32_t)((1 - side) * P.W) * 16u;
+    const uint32_t* cell_bits = G.mask + ((size_t)z * cells + (size_t)cr * P.gw) * P.gwords;
+    float* out_row = G.Draw + (size_t)z * P.DW * P.DH + (size_t)v * P.DW;
+#pragma unroll
+    for (int k = 0; k < kIters; k++) {
+        const int u = x0 + k * half;
+        if (u < P.DW) {
+            int res = -10;
+            const uint4 own = lds_read16(own_base + (uint32_t)(u < P.W ? u : 0) * 16u);
+            const bool live = tk[k] >= 0 && (int)texture16(own) >= P.match_texture;
+            if (live && !(Q.dbg & 1)) {
+                const uint32_t c = __umulhi((uint32_t)u, P.grid_magic);
+                const uint32_t lrec = rec_addr + c * (ML_CAP * 2);
+                const uint32_t* bits = cell_bits + c * (uint32_t)P.gwords;
+                res = side ? ml_pixel<1>(own, plk[k], u, v, oth_base + (uint32_t)u * 16u, lrec, s_band, neg_prior, P, bits)
+                           : ml_pixel<0>(own, plk[k], u, v, oth_base + (uint32_t)u * 16u, lrec, s_band, neg_prior, P, bits);
             }
-            if (rs >= 2 * nrows) break;
-            const int side = rs >= nrows, r = rs - side * nrows;
-            const int16_t* mine = raw + side * raw_side + r * Q.Wr;
-            const int16_t* other = raw + (1 - side) * raw_side + r * Q.Wr;
-            const int d = mine[x];
-            const int uw = side ? x + d : x - d;
-            float o = -10.f;
-            if (d >= 0 && uw >= 0 && uw < P.DW)
-                if (!(fabsf((float)other[uw] - (float)d) > lr_threshold)) o = (float)d;
-            (out.D[side] + (size_t)wt_pair(pk) * out.stride[side] + (size_t)(row0 + r) * P.DW)[x] = o;
-            x += (MW_WAVES - 1) * 64;
+            if (!kLr || write_raw) out_row[u] = (float)res;
+            if (kLr) s_raw[side * Q.Wr + u] = (int16_t)res;
         }
-    };
-    auto open_until = [&](int ph) {
-        while (cur < ph) {
-            mw_barrier_compute();    // the pass before is complete, the rows of this one have landed
-            cur++;
-            if (cur >= 2 && !(cur & 1)) lr_check(cur / 2 - 1);
-        }
-    };
-    for (;;) {
-        claim(C);
-        mw_fetch1(C, L, G, P, lane);
-        mw_fetch2(B, G);
-        open_until(A.ph);
-        if (A.ph >= nph) break;
-        if (wt_active(A.pk) && !(Q.dbg & 1)) {
-            int16_t* raw = raws + ((A.ph >> 1) & 1) * 2 * raw_side + (A.ph & 1) * raw_side;
-            if ((A.ph & 1) == 0)
-                mw_compute<0>(A, L, G, P, Q, addrR, raw, list, s_band, neg_prior, lane, write_raw);
-            else
-                mw_compute<1>(A, L, G, P, Q, addrL, raw, list, s_band, neg_prior, lane, write_raw);
-        }
-        A = B;
-        B = C;
+    }
+    if (!kLr) return;
+    __syncthreads();
+    // E12: keep d iff the other map, at the warped position, agrees within lr_threshold
+    float* D = out.D[side] + (size_t)pair * out.stride[side] + (size_t)v * P.DW;
+    const int16_t* mine = s_raw + side * Q.Wr;
+    const int16_t* other = s_raw + (1 - side) * Q.Wr;
+    for (int x = x0; x < P.DW; x += half) {
+        const int d = mine[x];
+        const int uw = side ? x + d : x - d;
+        float o = -10.f;
+        if (d >= 0 && uw >= 0 && uw < P.DW)
+            if (!(fabsf((float)other[uw] - (float)d) > lr_threshold)) o = (float)d;
+        D[x] = o;
     }
 }
 
@@ -2251,57 +2058,46 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
                                         (int)keyed_lds_max) == hipSuccess;
         if (!use_keyed) (void)hipGetLastError();
     }
-    // round 4: the row-group walker (cell-uniform waves, LDS-DMA double buffering) for the presets' geometry
-    static const bool walk_off = !(getenv("SVH_MATCH_WALK") && atoi(getenv("SVH_MATCH_WALK")) == 1);   // opt-in: measured slower (see DESIGN)
-    if (keyed_ok && !walk_off && !p.subsampling && d.gwords == 8 && p.grid_size >= 16 && p.grid_size <= 21 &&
-        G.prior_absmax < 28000 && d.W >= 64 && G.lists) {
-        MatchWalk Q;
-        Q.S = d.W + ((4 - d.W % 16) + 16) % 16;
+    // round 4: the list form of the keyed kernel (per-cell candidate records, v_sad_hi_u8 keys, LDS-DMA staging)
+    static const bool list_off = getenv("SVH_MATCH_LIST") && atoi(getenv("SVH_MATCH_LIST")) == 0;
+    if (keyed_ok && !list_off && !p.subsampling && d.gwords == 8 && G.lists && G.prior_absmax < 28000 &&
+        d.DW <= 8 * 256) {
+        MatchList Q;
         Q.Wr = (d.W + 7) / 8 * 8;
-        Q.gpc = (p.grid_size + MW_ROWS - 1) / MW_ROWS;
-        Q.full_cr = d.H / p.grid_size;
-        const int rem = d.H - Q.full_cr * p.grid_size;
-        Q.gpp = Q.full_cr * Q.gpc + (rem + MW_ROWS - 1) / MW_ROWS;
-        Q.total = Q.gpp * g;
-        Q.dbg = getenv("SVH_WALK_DBG") ? atoi(getenv("SVH_WALK_DBG")) : 0;
-        const size_t ldsw = (size_t)2 * MW_ROWS * Q.S * sizeof(uint4) + (size_t)4 * MW_ROWS * Q.Wr * sizeof(int16_t) +
-                            (size_t)MW_WAVES * (MW_LIST + 8) * sizeof(uint32_t);
-        constexpr size_t kWalkStatic = 2048;   // s_tab, s_band, s_neg, s_next (1.2 KB) with margin
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        struct PerDev { int cus = 0; int lds_ok = -1; };
-        static PerDev per_dev[64];
-        static std::mutex per_dev_mu;
-        bool ok = dev >= 0 && dev < 64;
-        int cus = 0;
-        if (ok) {
-            std::lock_guard<std::mutex> lk(per_dev_mu);
-            PerDev& pd = per_dev[dev];
-            if (pd.lds_ok < 0) {
-                // (hipDeviceAttributeMaxSharedMemoryPerBlock reports the 64 KB default; the opt-in decides)
-                (void)hipDeviceGetAttribute(&pd.cus, hipDeviceAttributeMultiprocessorCount, dev);
-                pd.lds_ok = pd.cus > 0 &&
-                            hipFuncSetAttribute((const void*)k_match_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                160 * 1024 - (int)kWalkStatic) == hipSuccess &&
-                            hipFuncSetAttribute((const void*)k_match_walk<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                160 * 1024 - (int)kWalkStatic) == hipSuccess;
-                if (!pd.lds_ok) (void)hipGetLastError();
-            }
-            ok = pd.lds_ok == 1 && ldsw + kWalkStatic <= 160 * 1024;
-            cus = pd.cus;
+        Q.dbg = getenv("SVH_MATCH_DBG") ? atoi(getenv("SVH_MATCH_DBG")) : 0;
+        const int iters = (d.DW + 255) / 256;
+        const int half = std::min(256, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
+        Q.kIters = iters <= 5 ? 5 : 8;
+        const size_t ldsl = (size_t)2 * d.W * sizeof(uint4) + (size_t)2 * d.gw * ML_CAP * sizeof(uint16_t) +
+                            (size_t)2 * Q.Wr * sizeof(int16_t);
+        constexpr size_t kListStatic = 256;   // s_band, s_neg
+        bool ok = ldsl + kListStatic <= 160 * 1024;
+        if (ok && ldsl + kListStatic > 64 * 1024) {
+            ok = hipFuncSetAttribute((const void*)k_match_list<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024 - (int)kListStatic) == hipSuccess &&
+                 hipFuncSetAttribute((const void*)k_match_list<false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024 - (int)kListStatic) == hipSuccess &&
+                 hipFuncSetAttribute((const void*)k_match_list<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024 - (int)kListStatic) == hipSuccess &&
+                 hipFuncSetAttribute((const void*)k_match_list<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024 - (int)kListStatic) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
         }
         if (ok) {
             Timed timed_(cx, "k_match");
-            static const int per_cu = getenv("SVH_MATCH_WALK_BLOCKS") ? atoi(getenv("SVH_MATCH_WALK_BLOCKS")) : 1;
-            const dim3 grid((unsigned)std::min(Q.total, std::max((Q.total + MW_ITEMS - 1) / MW_ITEMS, cus * per_cu))), block(MW_WAVES * 64);
+            const dim3 grid((unsigned)(d.DH * g)), block(2 * half);
             hipStream_t s = (hipStream_t)cx.stream;
+            DevMaps none{};
+            const DevMaps& o = lr_out ? *lr_out : none;
+            const int wr = lr_out ? (write_raw ? 1 : 0) : 1;
+            const float thr = lr_out ? (float)p.lr_threshold : 0.f;
             if (lr_out) {
-                hipLaunchKernelGGL(k_match_walk<true>, grid, block, ldsw, s, G, P, Q, *lr_out, write_raw ? 1 : 0,
-                                   (float)p.lr_threshold);
+                if (Q.kIters == 5) hipLaunchKernelGGL((k_match_list<true, 5>), grid, block, ldsl, s, G, P, Q, o, wr, thr);
+                else hipLaunchKernelGGL((k_match_list<true, 8>), grid, block, ldsl, s, G, P, Q, o, wr, thr);
                 return true;
             }
-            DevMaps none{};
-            hipLaunchKernelGGL(k_match_walk<false>, grid, block, ldsw, s, G, P, Q, none, 1, 0.f);
+            if (Q.kIters == 5) hipLaunchKernelGGL((k_match_list<false, 5>), grid, block, ldsl, s, G, P, Q, o, wr, thr);
+            else hipLaunchKernelGGL((k_match_list<false, 8>), grid, block, ldsl, s, G, P, Q, o, wr, thr);
             return false;
         }
     }

@@ -146,7 +146,7 @@ struct GroupDev {
     float* planes;             // 6 floats per triangle (t1a..t2c), packed like tri
     uint32_t* seed;            // [g][2][cells][gwords]
     uint32_t* mask;            // [g][2][cells][gwords] dilated
-    uint16_t* lists;           // [g][2][cells][64] candidate records of k_grid_list (disp_max <= 255), else null
+    uint16_t* lists;           // [g][2][cells][32] candidate records of k_grid_list (disp_max <= 255), else null
     const uint8_t* desc;       // [g][2][N*16]
     int32_t* owner;            // [g][2][N]
     float* Draw;               // [g][2][DN]
