@@ -1166,66 +1166,138 @@ __device__ __forceinline__ void dma_slots(uint4* dst, const uint4* src, int n, i
 struct MatchList {
     int kIters;      // pixels per thread (template argument of the launch)
     int Wr;          // raw-row stride (int16)
-    int dbg;
 };
 
-// the reference's scan of one pixel, list form.  rowaddr: LDS address of the other image's slot at this
-// pixel's column; lrec: LDS address of the cell's record
+// per-pixel quantities both forms of the scan need
+struct PixelPlan {
+    int valid, d_plane, dlo, dhi, n, dmax;
+    bool cell_in, band_in;
+};
 template <int kSide>
-__device__ __forceinline__ int ml_pixel(const uint4& own, const float4& pl, int u, int v, uint32_t rowaddr,
-                                        uint32_t lrec, const int* s_band, int neg_prior, const MatchParams& P,
-                                        const uint32_t* __restrict__ bits) {
-    const int valid = __float_as_int(pl.w);
-    const int d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pl.x, (float)u), __fmul_rn(pl.y, (float)v)), pl.z);
+__device__ __forceinline__ PixelPlan ml_plan(const float4& pl, int u, int v, uint32_t lrec, const MatchParams& P) {
+    PixelPlan q;
+    q.valid = __float_as_int(pl.w);
+    q.d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pl.x, (float)u), __fmul_rn(pl.y, (float)v)), pl.z);
     const int rad = P.plane_radius;
-    int dlo = d_plane - rad;
-    dlo = dlo > 0 ? dlo : 0;
-    int dhi = d_plane + rad;
-    dhi = dhi < P.disp_max ? dhi : P.disp_max;
-    const uint32_t blen = (uint32_t)(dhi - dlo);
-    const bool has_band = dhi >= dlo;
+    q.dlo = q.d_plane - rad;
+    q.dlo = q.dlo > 0 ? q.dlo : 0;
+    q.dhi = q.d_plane + rad;
+    q.dhi = q.dhi < P.disp_max ? q.dhi : P.disp_max;
     const uint32_t tail = lds_read4(lrec + 2 * (ML_CAP - 2));   // [30] last candidate, [31] count
-    const int n = (int)(tail >> 16), dmax = (int)(tail & 0xFFFFu) >> 4;
-    const bool cell_in = kSide ? u + dmax < P.W - 2 : u - dmax >= 2;
-    const bool band_in = d_plane - rad >= 0 && d_plane + rad <= P.disp_max &&
-                         (kSide ? u + d_plane + rad < P.W - 2 : u - d_plane - rad >= 2);
-    // wave-uniform choice of the loop forms (this function runs under "live" lanes only)
-    const bool big = __builtin_amdgcn_ballot_w64(n > ML_FAST) != 0;
-    const bool fast = !big && neg_prior && __builtin_amdgcn_ballot_w64(!(valid && cell_in && band_in)) == 0;
+    q.n = (int)(tail >> 16);
+    q.dmax = (int)(tail & 0xFFFFu) >> 4;
+    q.cell_in = kSide ? u + q.dmax < P.W - 2 : u - q.dmax >= 2;
+    q.band_in = q.d_plane - rad >= 0 && q.d_plane + rad <= P.disp_max &&
+                (kSide ? u + q.d_plane + rad < P.W - 2 : u - q.d_plane - rad >= 2);
+    return q;
+}
+
+// The reference's scan of one pixel, hot form: at most ML_FAST candidates in the cell and none of them warps
+// out of the row (anything else is redone by ml_pixel_checked).  Wave-uniform switches:
+//   excl     -- some lane's plane is invalid (its band has no prior) or a band prior is not negative: cell
+//               candidates inside the band are skipped as the reference does (elas.cpp:871), +3 operations each;
+//   band_ok  -- every lane's band lies inside [0, disp_max] and inside the row; otherwise the five band keys
+//               are masked one by one.
+// rowaddr: LDS address of the other image's slot at this pixel's column; lrec: LDS address of the cell's record.
+template <int kSide>
+__device__ __forceinline__ int ml_pixel_fast(const uint4& own, const PixelPlan& q, int u, uint32_t rowaddr,
+                                             uint32_t lrec, const int* s_band, const uint3& bp, bool excl,
+                                             bool band_ok, const MatchParams& P) {
+    const int rad = P.plane_radius;
     int best = 0x7FFFFFFF;
-    if (fast) {
-        // ---- cell candidates, four per trip; rank = list index (ascending d, the reference's order)
-        for (int i = 0; __builtin_amdgcn_ballot_w64(i < n) != 0; i += 4) {
-            if (i >= n) continue;   // (an empty record is padded with d = 0, which is not a candidate)
-            const uint2 cc = lds_read8(lrec + 2 * i);
-            const uint32_t c0 = cc.x & 0xFFFFu, c1 = cc.x >> 16, c2 = cc.y & 0xFFFFu, c3 = cc.y >> 16;
-            const uint4 o0 = lds_read16(kSide ? rowaddr + c0 : rowaddr - c0);
-            const uint4 o1 = lds_read16(kSide ? rowaddr + c1 : rowaddr - c1);
-            const uint4 o2 = lds_read16(kSide ? rowaddr + c2 : rowaddr - c2);
-            const uint4 o3 = lds_read16(kSide ? rowaddr + c3 : rowaddr - c3);
-            best = min3i(best, sad_hi16(own, o0, (uint32_t)i), sad_hi16(own, o1, (uint32_t)i + 1));
-            best = min3i(best, sad_hi16(own, o2, (uint32_t)i + 2), sad_hi16(own, o3, (uint32_t)i + 3));
+    // ---- cell candidates, four per trip; rank = list index (ascending d, the reference's order)
+    uint2 cc = lds_read8(lrec);
+    if (!excl) {
+        for (int i = 0; __builtin_amdgcn_ballot_w64(i < q.n) != 0; i += 4) {
+            const uint2 cn = lds_read8(lrec + 2 * i + 8);   // next trip's four ([28..31] at the end: read, not used)
+            if (i < q.n) {   // (an empty record is padded with d = 0, which is not a candidate)
+                const uint32_t c0 = cc.x & 0xFFFFu, c1 = cc.x >> 16, c2 = cc.y & 0xFFFFu, c3 = cc.y >> 16;
+                const uint4 o0 = lds_read16(kSide ? rowaddr + c0 : rowaddr - c0);
+                const uint4 o1 = lds_read16(kSide ? rowaddr + c1 : rowaddr - c1);
+                const uint4 o2 = lds_read16(kSide ? rowaddr + c2 : rowaddr - c2);
+                const uint4 o3 = lds_read16(kSide ? rowaddr + c3 : rowaddr - c3);
+                best = min3i(best, sad_hi16(own, o0, (uint32_t)i), sad_hi16(own, o1, (uint32_t)i + 1));
+                best = min3i(best, sad_hi16(own, o2, (uint32_t)i + 2), sad_hi16(own, o3, (uint32_t)i + 3));
+            }
+            cc = cn;
         }
-        // ---- the plane band with its prior, two disparities per trip; rank = 512 + d
+    } else {
+        const uint32_t lo16 = (uint32_t)q.dlo * 16u;
+        const uint32_t len16 = q.dhi >= q.dlo ? (uint32_t)(q.dhi - q.dlo) * 16u : 0u;
+        const uint32_t off16 = q.dhi >= q.dlo ? lo16 : 0x40000000u;   // empty band: nothing is inside
+        for (int i = 0; __builtin_amdgcn_ballot_w64(i < q.n) != 0; i += 4) {
+            const uint2 cn = lds_read8(lrec + 2 * i + 8);
+            if (i < q.n) {
+                const uint32_t c0 = cc.x & 0xFFFFu, c1 = cc.x >> 16, c2 = cc.y & 0xFFFFu, c3 = cc.y >> 16;
+                const uint4 o0 = lds_read16(kSide ? rowaddr + c0 : rowaddr - c0);
+                const uint4 o1 = lds_read16(kSide ? rowaddr + c1 : rowaddr - c1);
+                const uint4 o2 = lds_read16(kSide ? rowaddr + c2 : rowaddr - c2);
+                const uint4 o3 = lds_read16(kSide ? rowaddr + c3 : rowaddr - c3);
+                const int k0 = c0 - off16 <= len16 ? 0x7FFFFFFF : sad_hi16(own, o0, (uint32_t)i);
+                const int k1 = c1 - off16 <= len16 ? 0x7FFFFFFF : sad_hi16(own, o1, (uint32_t)i + 1);
+                const int k2 = c2 - off16 <= len16 ? 0x7FFFFFFF : sad_hi16(own, o2, (uint32_t)i + 2);
+                const int k3 = c3 - off16 <= len16 ? 0x7FFFFFFF : sad_hi16(own, o3, (uint32_t)i + 3);
+                best = min3i(best, k0, k1);
+                best = min3i(best, k2, k3);
+            }
+            cc = cn;
+        }
+    }
+    // ---- the plane band with its prior; rank = 512 + d
+    const uint32_t a0 = kSide ? rowaddr + (uint32_t)(q.d_plane - rad) * 16u : rowaddr - (uint32_t)(q.d_plane - rad) * 16u;
+    const uint32_t rk0 = (uint32_t)(512 + q.d_plane - rad);
+    if (rad == 2) {
+        // the presets' radius: five candidates at constant offsets from one address, priors in scalar registers
+        const uint32_t b = kSide ? a0 : a0 - 64u;
+        const uint4 o0 = lds_read16(b + (kSide ? 0u : 64u)), o1 = lds_read16(b + (kSide ? 16u : 48u));
+        const uint4 o2 = lds_read16(b + 32u), o3 = lds_read16(b + (kSide ? 48u : 16u));
+        const uint4 o4 = lds_read16(b + (kSide ? 64u : 0u));
+        const uint32_t p0 = q.valid ? bp.x : 0u, p1 = q.valid ? bp.y : 0u, p2 = q.valid ? bp.z : 0u;
+        int key0 = sad_hi16(own, o0, rk0 + p2), key1 = sad_hi16(own, o1, rk0 + 1u + p1);
+        int key2 = sad_hi16(own, o2, rk0 + 2u + p0), key3 = sad_hi16(own, o3, rk0 + 3u + p1);
+        int key4 = sad_hi16(own, o4, rk0 + 4u + p2);
+        if (!band_ok) {
+            const int d0 = q.d_plane - 2, w0 = kSide ? u + d0 - 2 : u - d0 - 2;   // warped column - 2 of the first one
+            const uint32_t dm = (uint32_t)P.disp_max, wm = (uint32_t)(P.W - 4);
+            key0 = (uint32_t)d0 <= dm && (uint32_t)w0 < wm ? key0 : 0x7FFFFFFF;
+            key1 = (uint32_t)(d0 + 1) <= dm && (uint32_t)(kSide ? w0 + 1 : w0 - 1) < wm ? key1 : 0x7FFFFFFF;
+            key2 = (uint32_t)(d0 + 2) <= dm && (uint32_t)(kSide ? w0 + 2 : w0 - 2) < wm ? key2 : 0x7FFFFFFF;
+            key3 = (uint32_t)(d0 + 3) <= dm && (uint32_t)(kSide ? w0 + 3 : w0 - 3) < wm ? key3 : 0x7FFFFFFF;
+            key4 = (uint32_t)(d0 + 4) <= dm && (uint32_t)(kSide ? w0 + 4 : w0 - 4) < wm ? key4 : 0x7FFFFFFF;
+        }
+        best = min3i(best, key0, key1);
+        best = min3i(best, key2, key3);
+        best = best < key4 ? best : key4;
+    } else {
+        // (other radii: the caller sends waves with a clipped band to the checked form)
         const int nb = 2 * rad + 1;
-        const uint32_t a0 = kSide ? rowaddr + (uint32_t)(d_plane - rad) * 16u : rowaddr - (uint32_t)(d_plane - rad) * 16u;
-        const uint32_t rk0 = (uint32_t)(512 + d_plane - rad);
         for (int k = 0; k < nb; k += 2) {
             const int k1 = k + 1 < nb ? k + 1 : k;
             const uint4 o0 = lds_read16(kSide ? a0 + 16u * k : a0 - 16u * k);
             const uint4 o1 = lds_read16(kSide ? a0 + 16u * k1 : a0 - 16u * k1);
-            const int key0 = sad_hi16(own, o0, rk0 + (uint32_t)k + (uint32_t)s_band[k]);
-            const int key1 = sad_hi16(own, o1, rk0 + (uint32_t)k1 + (uint32_t)s_band[k1]);
+            const int key0 = sad_hi16(own, o0, rk0 + (uint32_t)k + (q.valid ? (uint32_t)s_band[k] : 0u));
+            const int key1 = sad_hi16(own, o1, rk0 + (uint32_t)k1 + (q.valid ? (uint32_t)s_band[k1] : 0u));
             best = min3i(best, key0, key1);
         }
-        if (best == 0x7FFFFFFF) return -1;
-        const int rank = best & 0xFFFF;
-        return rank >= 512 ? rank - 512 : (int)(lds_read2(lrec + 2 * rank) >> 4);
     }
-    // ---- checked form: per-candidate range and band tests.  rank = d (cell), 512 + d (band)
-    if (!big) {
-        for (int i = 0; __builtin_amdgcn_ballot_w64(i < n) != 0; i += 2) {
-            if (i >= n) continue;
+    if (best == 0x7FFFFFFF) return -1;
+    const int rank = best & 0xFFFF;
+    return rank >= 512 ? rank - 512 : (int)(lds_read2(lrec + 2 * rank) >> 4);
+}
+
+// checked form: per-candidate range and band tests (waves next to the image border, invalid planes,
+// non-negative priors, cells with more candidates than a record).  rank = d (cell), 512 + d (band)
+template <int kSide>
+__device__ __forceinline__ int ml_pixel_checked(const uint4& own, const PixelPlan& q, int u, uint32_t rowaddr,
+                                                uint32_t lrec, const int* s_band, const MatchParams& P,
+                                                const uint32_t* __restrict__ bits) {
+    const uint32_t blen = (uint32_t)(q.dhi - q.dlo);
+    const bool has_band = q.dhi >= q.dlo;
+    const int dlo = q.dlo, rad = P.plane_radius;
+    int best = 0x7FFFFFFF;
+    if (__builtin_amdgcn_ballot_w64(q.n > ML_FAST) == 0) {
+        for (int i = 0; __builtin_amdgcn_ballot_w64(i < q.n) != 0; i += 2) {
+            if (i >= q.n) continue;
             const uint32_t cc = lds_read4(lrec + 2 * i);
             const uint32_t c0 = cc & 0xFFFFu, c1 = cc >> 16;
             const int d0 = (int)(c0 >> 4), d1 = (int)(c1 >> 4);
@@ -1240,10 +1312,11 @@ __device__ __forceinline__ int ml_pixel(const uint4& own, const float4& pl, int 
         }
     } else {
         // a cell of the wave holds more candidates than a record: every lane decodes its cell's bit set
-        for (int q = 0; q < 8; q++) {
-            uint32_t b = bits[q];
+#pragma unroll 1
+        for (int w = 0; w < 8; w++) {
+            uint32_t b = bits[w];
             while (b) {
-                const int dc = q * 32 + __builtin_ctz(b);
+                const int dc = w * 32 + __builtin_ctz(b);
                 b &= b - 1;
                 const int uw = kSide ? u + dc : u - dc;
                 if ((uint32_t)(uw - 2) >= (uint32_t)(P.W - 4) || (has_band && (uint32_t)(dc - dlo) <= blen)) continue;
@@ -1253,13 +1326,13 @@ __device__ __forceinline__ int ml_pixel(const uint4& own, const float4& pl, int 
             }
         }
     }
-    for (int dc = dlo; dc <= dhi; dc++) {
+    for (int dc = q.dlo; dc <= q.dhi; dc++) {
         const int uw = kSide ? u + dc : u - dc;
         const bool ok = (uint32_t)(uw - 2) < (uint32_t)(P.W - 4);
         const uint4 o = lds_read16(ok ? (kSide ? rowaddr + 16u * dc : rowaddr - 16u * dc) : rowaddr);
-        int dd = dc - d_plane;
+        int dd = dc - q.d_plane;
         dd = dd < 0 ? -dd : dd;
-        const uint32_t pr = valid ? (uint32_t)s_band[rad + dd] : 0u;
+        const uint32_t pr = q.valid ? (uint32_t)s_band[rad + dd] : 0u;
         const int key = sad_hi16(own, o, (uint32_t)(512 + dc) + pr);
         best = ok && key < best ? key : best;
     }
@@ -1267,13 +1340,13 @@ __device__ __forceinline__ int ml_pixel(const uint4& own, const float4& pl, int 
 }
 
 template <bool kLr, int kIters>
-__global__ __launch_bounds__(512) void k_match_list(GroupDev G, MatchParams P, MatchList Q, DevMaps out,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(kIters <= 5 ? 6 : 4, 8))) void k_match_list(GroupDev G, MatchParams P, MatchList Q, DevMaps out,
                                                     int write_raw, float lr_threshold) {
     extern __shared__ uint4 s_dyn[];   // rows [2][W] | cell records [2][gw][ML_CAP] u16 | raw [2][Wr] int16
     __shared__ int s_band[32];         // P[|k - radius|] << 16
     __shared__ int s_neg;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
     const int row_id = blockIdx.x;
     const int pair = row_id / P.DH, v = row_id - pair * P.DH;
     if (!G.hdr->active[pair]) return;
@@ -1286,13 +1359,13 @@ __global__ __launch_bounds__(512) void k_match_list(GroupDev G, MatchParams P, M
     const int cr = v / P.grid_size, cells = P.gw * P.gh;
     {
         const uint4* l1 = reinterpret_cast<const uint4*>(G.desc) + (size_t)(2 * pair) * N + (size_t)line * P.W;
-        dma_slots(s_rows, l1, P.W, wave, (int)(blockDim.x >> 6), lane);
-        dma_slots(s_rows + P.W, l1 + N, P.W, wave, (int)(blockDim.x >> 6), lane);
+        dma_slots(s_rows, l1, P.W, wave, nwaves, lane);
+        dma_slots(s_rows + P.W, l1 + N, P.W, wave, nwaves, lane);
         const int rq = P.gw * ML_CAP * 2 / 16;   // uint4 per side
         const uint4* r1 = reinterpret_cast<const uint4*>(G.lists + ((size_t)(2 * pair) * cells + (size_t)cr * P.gw) * ML_CAP);
         const uint4* r2 = reinterpret_cast<const uint4*>(G.lists + ((size_t)(2 * pair + 1) * cells + (size_t)cr * P.gw) * ML_CAP);
-        dma_slots(reinterpret_cast<uint4*>(s_rec), r1, rq, wave, (int)(blockDim.x >> 6), lane);
-        dma_slots(reinterpret_cast<uint4*>(s_rec) + rq, r2, rq, wave, (int)(blockDim.x >> 6), lane);
+        dma_slots(reinterpret_cast<uint4*>(s_rec), r1, rq, wave, nwaves, lane);
+        dma_slots(reinterpret_cast<uint4*>(s_rec) + rq, r2, rq, wave, nwaves, lane);
     }
     if (tid < 32) {
         const int dd = tid - P.plane_radius;
@@ -1307,58 +1380,101 @@ __global__ __launch_bounds__(512) void k_match_list(GroupDev G, MatchParams P, M
     const int side = tid >= half;                 // wave-uniform: half is a multiple of 64
     const int z = 2 * pair + side;
     const int x0 = tid - side * half;
+    const int32_t* own_t = G.owner + (size_t)z * N + (size_t)v * P.W;
     // owner words of all of the thread's pixels, then (after the barrier drained them) their planes
     int tk[kIters];
-    {
-        const int32_t* own_t = G.owner + (size_t)z * N + (size_t)v * P.W;
 #pragma unroll
-        for (int k = 0; k < kIters; k++) {
-            const int u = x0 + k * half;
-            tk[k] = own_t[u < P.W ? u : 0];
-        }
+    for (int k = 0; k < kIters; k++) {
+        const int u = x0 + k * half;
+        tk[k] = own_t[u < P.W ? u : 0];
     }
     const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
     __syncthreads();
-    float4 plk[kIters];
 #pragma unroll
     for (int k = 0; k < kIters; k++) {
         const int u = x0 + k * half;
-        int t = tk[k] - G.owner_base - 1;
-        t = (u >= 2 && u < P.W - 2) ? t : -1;
-        tk[k] = t;
-        plk[k] = *reinterpret_cast<const float4*>(G.raster + (t >= 0 ? (uint32_t)(tri0 + t) : 0u));
+        const int t = tk[k] - G.owner_base - 1;
+        tk[k] = (u >= 2 && u < P.W - 2) ? t : -1;
     }
-    const int neg_prior = s_neg;
+    // the plane of the owning triangle is requested one pixel ahead (all of them at once would cost a sixth wave per SIMD)
+    float4 pl_next = *reinterpret_cast<const float4*>(G.raster + (tk[0] >= 0 ? (uint32_t)(tri0 + tk[0]) : 0u));
+    const int neg_prior = s_neg, rad = P.plane_radius;
+    // P[0], P[1], P[2] << 16 (uniform): the band priors of the presets' plane radius
+    const uint3 bp = make_uint3((uint32_t)__builtin_amdgcn_readfirstlane(s_band[rad]),
+                                (uint32_t)__builtin_amdgcn_readfirstlane(s_band[rad + 1]),
+                                (uint32_t)__builtin_amdgcn_readfirstlane(s_band[rad + 2]));
     const uint32_t rows_addr = lds_addr_of(s_rows), rec_addr = lds_addr_of(s_rec) + (uint32_t)(side * P.gw * ML_CAP * 2);
     const uint32_t own_base = rows_addr + (uint32_t)(side * P.W) * 16u, oth_base = rows_addr + (uint32_t)((1 - side) * P.W) * 16u;
-    const uint32_t* cell_bits = G.mask + ((size_t)z * cells + (size_t)cr * P.gw) * P.gwords;
     float* out_row = G.Draw + (size_t)z * P.DW * P.DH + (size_t)v * P.DW;
+    int16_t* raw_row = s_raw + side * Q.Wr;
+    uint32_t cold = 0;     // pixels (bit k) of this wave that need the checked form
 #pragma unroll
     for (int k = 0; k < kIters; k++) {
         const int u = x0 + k * half;
+        const float4 pl = pl_next;
+        if (k + 1 < kIters)
+            pl_next = *reinterpret_cast<const float4*>(G.raster + (tk[k + 1] >= 0 ? (uint32_t)(tri0 + tk[k + 1]) : 0u));
         if (u < P.DW) {
             int res = -10;
             const uint4 own = lds_read16(own_base + (uint32_t)(u < P.W ? u : 0) * 16u);
             const bool live = tk[k] >= 0 && (int)texture16(own) >= P.match_texture;
-            if (live && !(Q.dbg & 1)) {
-                const uint32_t c = __umulhi((uint32_t)u, P.grid_magic);
-                const uint32_t lrec = rec_addr + c * (ML_CAP * 2);
-                const uint32_t* bits = cell_bits + c * (uint32_t)P.gwords;
-                res = side ? ml_pixel<1>(own, plk[k], u, v, oth_base + (uint32_t)u * 16u, lrec, s_band, neg_prior, P, bits)
-                           : ml_pixel<0>(own, plk[k], u, v, oth_base + (uint32_t)u * 16u, lrec, s_band, neg_prior, P, bits);
+            if (__builtin_amdgcn_ballot_w64(live) != 0) {
+                const uint32_t lrec = rec_addr + __umulhi((uint32_t)(u < P.W ? u : 0), P.grid_magic) * (ML_CAP * 2);
+                const uint32_t rowaddr = oth_base + (uint32_t)u * 16u;
+                // (the plan is evaluated on every lane so that the choice of the form is made outside the
+                // divergent part; lanes that are not live hold a valid record address and plane 0)
+                if (side) {
+                    const PixelPlan q = ml_plan<1>(pl, u, v, lrec, P);
+                    const bool band_ok = __builtin_amdgcn_ballot_w64(live && !q.band_in) == 0;
+                    if (__builtin_amdgcn_ballot_w64(live && !(q.cell_in && q.n <= ML_FAST)) == 0 && (band_ok || rad == 2)) {
+                        const bool excl = !neg_prior || __builtin_amdgcn_ballot_w64(live && !q.valid) != 0;
+                        if (live) res = ml_pixel_fast<1>(own, q, u, rowaddr, lrec, s_band, bp, excl, band_ok, P);
+                    } else {
+                        cold |= 1u << k;
+                    }
+                } else {
+                    const PixelPlan q = ml_plan<0>(pl, u, v, lrec, P);
+                    const bool band_ok = __builtin_amdgcn_ballot_w64(live && !q.band_in) == 0;
+                    if (__builtin_amdgcn_ballot_w64(live && !(q.cell_in && q.n <= ML_FAST)) == 0 && (band_ok || rad == 2)) {
+                        const bool excl = !neg_prior || __builtin_amdgcn_ballot_w64(live && !q.valid) != 0;
+                        if (live) res = ml_pixel_fast<0>(own, q, u, rowaddr, lrec, s_band, bp, excl, band_ok, P);
+                    } else {
+                        cold |= 1u << k;
+                    }
+                }
             }
             if (!kLr || write_raw) out_row[u] = (float)res;
-            if (kLr) s_raw[side * Q.Wr + u] = (int16_t)res;
+            if (kLr) raw_row[u] = (int16_t)res;
         }
+    }
+    // the waves that could not take the fast form redo those pixels (everything reloaded: this is the cold path)
+    cold = (uint32_t)__builtin_amdgcn_readfirstlane((int)cold);   // (uniform already: set under a wave-wide vote)
+#pragma unroll 1
+    for (int k = 0; cold >> k; k++) {
+        if (!((cold >> k) & 1)) continue;
+        const int u = x0 + k * half;
+        if (u >= P.DW) continue;
+        int t = own_t[u < P.W ? u : 0] - G.owner_base - 1;
+        t = (u >= 2 && u < P.W - 2) ? t : -1;
+        const uint4 own = lds_read16(own_base + (uint32_t)(u < P.W ? u : 0) * 16u);
+        if (!(t >= 0 && (int)texture16(own) >= P.match_texture)) continue;
+        const float4 pl = *reinterpret_cast<const float4*>(G.raster + (tri0 + t));
+        const uint32_t c = __umulhi((uint32_t)u, P.grid_magic);
+        const uint32_t lrec = rec_addr + c * (ML_CAP * 2);
+        const uint32_t rowaddr = oth_base + (uint32_t)u * 16u;
+        const uint32_t* bits = G.mask + ((size_t)z * cells + (size_t)cr * P.gw + c) * P.gwords;
+        const int res = side ? ml_pixel_checked<1>(own, ml_plan<1>(pl, u, v, lrec, P), u, rowaddr, lrec, s_band, P, bits)
+                             : ml_pixel_checked<0>(own, ml_plan<0>(pl, u, v, lrec, P), u, rowaddr, lrec, s_band, P, bits);
+        if (!kLr || write_raw) out_row[u] = (float)res;
+        if (kLr) raw_row[u] = (int16_t)res;
     }
     if (!kLr) return;
     __syncthreads();
     // E12: keep d iff the other map, at the warped position, agrees within lr_threshold
     float* D = out.D[side] + (size_t)pair * out.stride[side] + (size_t)v * P.DW;
-    const int16_t* mine = s_raw + side * Q.Wr;
     const int16_t* other = s_raw + (1 - side) * Q.Wr;
     for (int x = x0; x < P.DW; x += half) {
-        const int d = mine[x];
+        const int d = raw_row[x];
         const int uw = side ? x + d : x - d;
         float o = -10.f;
         if (d >= 0 && uw >= 0 && uw < P.DW)
@@ -2064,7 +2180,6 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
         d.DW <= 8 * 256) {
         MatchList Q;
         Q.Wr = (d.W + 7) / 8 * 8;
-        Q.dbg = getenv("SVH_MATCH_DBG") ? atoi(getenv("SVH_MATCH_DBG")) : 0;
         const int iters = (d.DW + 255) / 256;
         const int half = std::min(256, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
         Q.kIters = iters <= 5 ? 5 : 8;
