@@ -663,8 +663,15 @@ def main():
               "host_core_ceiling_pairs_per_s": round(cores_per_rank / x[5]) if x[5] > 0 else None,
               "d1_valid_px_first_pair": int(x[1])} for r, x in enumerate(recs)]
 
-    # ---- roofline of the dominant kernel from HIP events recorded on its own stream
-    # during the timed steps (only that kernel is bracketed there: <1 % of value)
+    # ---- roofline of the dominant kernel.  Three measurements, kept apart:
+    #   in_run     HIP events around its launches DURING the timed steps: ~10 kernels of different workers
+    #              share the device, so a launch's duration there is a residency, not a rate;
+    #   isolated   the same launch (one group of pairs, one worker, nothing else on the device) timed with
+    #              HIP events in a probe after the timed region, on this box and this build: THIS is
+    #              `achieved` / `frac` (algorithmic bytes of the launch / its duration);
+    #   counters   rocprofv3 --pmc passes committed under profiles/ (quoted only when their build stamp is
+    #              the loaded library's): measured HBM bytes (`traffic`) and VALU instructions.
+    # The machine-share model of round 3 stays as `modelled_share_normalised`, never as `frac`.
     roofline = None
     if rank == 0:
         prof = read_profile(S) if in_region else prof_all
@@ -673,60 +680,90 @@ def main():
             dom = max(prof, key=lambda k: prof[k][0])
             ms, cnt = prof[dom]
             avg_s = ms / cnt / 1e3
-            # one launch covers a whole group of pairs
-            abytes = ALG_BYTES_PER_PIXEL.get(dom, 8.0) * N_PIX * min(group, B)
-            achieved = abytes / avg_s / 1e9
-            # Workers overlap: ~5 kernels share the device at any time, so a launch's in-run duration is
-            # not a rate (launches x duration exceeds the wall time).  The headline figure charges the
-            # kernel its SHARE of the machine instead: share = its part of the summed kernel time of the
-            # fully bracketed step, machine time = share x wall of the timed region, bytes = algorithmic
-            # bytes of every launch in the region.  The literal per-launch figure stays in `per_launch_in_run`.
+            gl = min(group, B)                       # pairs one launch covers
+            abytes = ALG_BYTES_PER_PIXEL.get(dom, 8.0) * N_PIX * gl
+            in_run = abytes / avg_s / 1e9
+            # isolated probe: ONE group on ONE worker -> the kernels of the group run one after the other
+            S.set_lanes(1)
+            S.lib().svh_profile_only(None)
+            S.lib().svh_profile_reset()
+            S.lib().svh_profile_enable(1)
+            probe_reps = 5
+            for _ in range(probe_reps + 1):
+                stp = e.process_batch_device(gl, dI1.data_ptr(), dI2.data_ptr(), W * H, dD1.data_ptr(),
+                                             dD2.data_ptr(), W * H * 4, W, H, W)
+                if _ == 0:                            # (the first repetition re-sizes the lane pool)
+                    S.lib().svh_profile_reset()
+            torch.cuda.synchronize()
+            S.lib().svh_profile_enable(0)
+            prof_iso = read_profile(S)
+            S.set_lanes(lanes)
+            iso_us = {k: 1e3 * v[0] / v[1] for k, v in prof_iso.items()}
+            iso_s = iso_us.get(dom, 1e6 * avg_s) / 1e6
+            achieved = abytes / iso_s / 1e9
             tot_ms = sum(v[0] for v in prof_all.values()) or 1.0
             share = prof_all.get(dom, (ms, cnt))[0] / tot_ms
             region_bytes = ALG_BYTES_PER_PIXEL.get(dom, 8.0) * N_PIX * B * args.steps
             norm = region_bytes / (share * elapsed_local) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": norm, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": norm / HBM_PEAK_GBS, "traffic": None,
-                        "definition": "machine-share normalised: algorithmic bytes of all launches in the timed "
-                                      "region / (kernel's share of summed kernel time x wall time)",
-                        "machine_share": round(share, 4), "alg_bytes_timed_region": region_bytes,
-                        "per_launch_in_run": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
-                                              "avg_launch_us": 1e6 * avg_s, "alg_bytes_per_launch": abytes,
-                                              "note": "HIP events around each launch during the timed steps; "
-                                                      "launches of different workers overlap, so this understates "
-                                                      "the kernel's rate"},
-                        "avg_launch_us": 1e6 * avg_s, "alg_bytes_per_launch": abytes,
-                        "timed_region": bool(in_region), "launches_timed": int(cnt),
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "definition": "algorithmic bytes of one launch (SURVEY 8d: %.1f B/pixel x %d pixels x %d pairs) / "
+                                      "duration of that launch alone on the device, HIP events on its stream, "
+                                      "average of %d launches in a probe after the timed region"
+                                      % (ALG_BYTES_PER_PIXEL.get(dom, 8.0), N_PIX, gl, probe_reps),
+                        "avg_launch_us": 1e6 * iso_s, "alg_bytes_per_launch": abytes, "pairs_per_launch": gl,
+                        "isolated_kernels_us": {k: round(v, 2) for k, v in sorted(iso_us.items())},
+                        "isolated_sum_us": round(sum(iso_us.values()), 1),
+                        "in_run": {"achieved": in_run, "frac": in_run / HBM_PEAK_GBS, "avg_launch_us": 1e6 * avg_s,
+                                   "launches_timed": int(cnt), "timed_region": bool(in_region),
+                                   "note": "HIP events around each launch during the timed steps; the launches of "
+                                           "the workers overlap (sum of kernel time / wall = %.1f in the probe "
+                                           "step), so this is a residency, not a rate"
+                                           % (tot_ms / 1e3 / max(elapsed_local / args.steps, 1e-9))},
+                        "modelled_share_normalised": {
+                            "achieved": norm, "frac": norm / HBM_PEAK_GBS, "machine_share": round(share, 4),
+                            "definition": "MODEL (round 3's headline, kept for continuity): algorithmic bytes of all "
+                                          "launches in the timed region / (kernel's share of summed kernel time x wall)"},
                         "kernels_us_probe_step": {k: round(1e3 * v[0] / v[1], 2)
                                                   for k, v in sorted(prof_all.items())}}
             if pmc["notes"]:
                 roofline["pmc_notes"] = pmc["notes"]
             tr, iss = pmc["traffic"], pmc["issue"]
+            alias_back = {"k_support": "k_support_lds", "k_match": "k_match_list", "k_descriptor": "k_descriptor_stream"}
+            alias = {v: k for k, v in alias_back.items()}
+            alias["k_match_keyed"] = "k_match"
             # measured HBM traffic of that kernel (rocprofv3 --pmc passes, taken on the KITTI workload)
             if tr and args.workload != "hd1080":
                 kk = tr["kernels"].get(dom)
                 if kk:
-                    roofline["traffic"] = kk["hbm_bytes"] * min(group, B) / tr["pairs_per_launch"]
+                    roofline["traffic"] = kk["hbm_bytes"] * gl / tr["pairs_per_launch"]
+                    roofline["frac_on_measured_traffic"] = roofline["traffic"] / iso_s / 1e9 / HBM_PEAK_GBS
                     roofline["traffic_source"] = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate " \
                                                  "passes), read = 2*FETCH_SIZE*1024 (gfx950), scaled to pairs " \
                                                  "per launch" % pmc["traffic_file"]
-            # The two matching kernels are integer-SAD work: what bounds them is VALU issue, not HBM
-            # (SURVEY 8d "reality check").  Issue-slot view of the same launches: wave-level VALU
-            # instructions of one launch (SQ_INSTS_VALU of the isolated PMC pass, scaled to the pairs
-            # per launch) against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction.
+            # Issue-slot view of the same launch: wave-level VALU instructions (SQ_INSTS_VALU of the PMC
+            # pass, scaled to the pairs per launch) against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64
+            # instruction of the SAD / min / compare class (profiles/r03_microbench_valu.txt).
             if iss and args.workload != "hd1080":
-                alias_back = {"k_support": "k_support_lds", "k_match": "k_match_keyed", "k_descriptor": "k_descriptor_stream"}
-                kk = iss["kernels"].get(alias_back.get(dom, dom))
+                kk = iss["kernels"].get(alias_back.get(dom, dom)) or iss["kernels"].get(dom)
                 if kk:
                     peak = 1024 * 2.4e9 / 4
-                    instr = kk["valu_wave_instr"] * min(group, B) / float(tr["pairs_per_launch"] if tr else 4)
+                    instr = kk["valu_wave_instr"] * gl / float(tr["pairs_per_launch"] if tr else 4)
+                    vfrac = instr / iso_s / peak
                     roofline["valu_issue_dominant_kernel"] = {
                         "wave_instr_per_launch": round(instr), "peak_wave_instr_per_s": peak,
-                        "frac_in_run": round(instr / avg_s / peak, 3),
-                        "frac_isolated": round(kk["valu_wave_instr"] / (kk["launch_us_under_pmc"] * 1e-6) / peak, 3),
-                        "note": "instruction count x 4 cycles (model, see valu_issue.note) over the launch time; in "
-                                "run the launch shares the device with ~5 other kernels in flight, which "
-                                "stretches its duration; isolated = the PMC pass, one kernel at a time"}
+                        "frac_isolated": round(vfrac, 3),
+                        "frac_isolated_pmc_launch": round(kk["valu_wave_instr"] / (kk["launch_us_under_pmc"] * 1e-6) / peak, 3),
+                        "lds_bank_conflict_cycles": kk.get("lds_bank_conflict_cycles"),
+                        "waves_per_simd": kk.get("waves_per_simd"), "parked": kk.get("parked"),
+                        "note": "SQ_INSTS_VALU x 4 cycles over the isolated launch time (issue-slot model backed by "
+                                "the opcode microbenchmark); parked = share of wave time waiting (SQ_WAIT_ANY)"}
+                    # what binds this kernel: the larger of its two utilisations, if either is telling
+                    hfrac = roofline.get("frac_on_measured_traffic") or roofline["frac"]
+                    roofline["bound"] = "valu_issue" if vfrac > hfrac else "hbm"
+                    roofline["bound_evidence"] = {"valu_issue_frac": round(vfrac, 3), "hbm_frac": round(hfrac, 3),
+                                                  "note": "isolated launch; neither roof is reached: the rest is LDS "
+                                                          "and memory latency that 6 waves per SIMD do not cover"}
             # whole-path view: staged-model bytes of all pairs / wall time
             e2e = ALG_BYTES_PER_PIXEL_PAIR * N_PIX * B * args.steps / elapsed_local / 1e9
             roofline["end_to_end"] = {"alg_bytes_per_pair": ALG_BYTES_PER_PIXEL_PAIR * N_PIX,
@@ -751,11 +788,10 @@ def main():
             copy_gbs = 10 * 2 * src.numel() / (time.perf_counter() - tc) / 1e9
             del src, dst
             roofline["measured_copy_GBps"] = copy_gbs
-            roofline["frac_of_measured_copy"] = norm / copy_gbs
+            roofline["frac_of_measured_copy"] = achieved / copy_gbs
             if tr and iss:
-                # the streaming (HBM-bound) kernels, from the committed isolated measurements:
+                # every kernel of the pipeline from the committed isolated counter passes:
                 # measured HBM bytes per launch (FETCH/WRITE_SIZE passes) / its duration
-                alias = {"k_support_lds": "k_support", "k_match_keyed": "k_match"}
                 rows = []
                 for sym, v in iss["kernels"].items():
                     tk = tr["kernels"].get(alias.get(sym, sym))

@@ -32,7 +32,7 @@ for k,v in sorted(d["kernels"].items(), key=lambda kv:-kv[1]["valu_wave_instr"])
     tot+=v["valu_wave_instr"]
     print("%-22s us %7.1f valu %9d busy(model) %.2f active(meas) %s cyc/valu %s salu %s lds %.2f w/simd %s parked %s stalled %s conf %s" % (k, v["launch_us_under_pmc"], v["valu_wave_instr"], v["valu_busy"], v.get("valu_active"), v.get("cyc_per_valu"), v.get("salu_cycles"), v["lds_busy"], v["waves_per_simd"], v["parked"], v["stalled"], v["lds_bank_conflict_cycles"]))
 print("valu per pair", tot/4)
-alias={"k_support_lds":"k_support","k_match_keyed":"k_match"}
+alias={"k_support_lds":"k_support","k_match_keyed":"k_match","k_match_list":"k_match"}
 for k,v in t["kernels"].items():
     us=[x["launch_us_under_pmc"] for n,x in d["kernels"].items() if alias.get(n,n)==k]
     gbs=v["hbm_bytes"]/us[0]/1e3 if us and us[0]>0 else 0

@@ -26,7 +26,7 @@ def build_stamp():
     return lib.svh_version().decode()
 
 
-ALIAS = {"k_support_lds": "k_support", "k_match_keyed": "k_match"}   # symbol -> bench.py profile name
+ALIAS = {"k_support_lds": "k_support", "k_match_keyed": "k_match", "k_match_list": "k_match"}   # symbol -> bench.py profile name
 
 
 def per_kernel(path, counter):
