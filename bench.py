@@ -448,6 +448,12 @@ def main():
                          "with one rank: one execution of the RCCL path on a 1-GPU box")
     ap.add_argument("--stage", choices=("auto", "host", "device"), default="auto",
                     help="where lattice filters + Delaunay run (svh_elas_set_stage): auto = device for batches")
+    ap.add_argument("--api", choices=("auto", "batch", "stream"), default="auto",
+                    help="batch: one svh_elas_process_batch_device call per step (drains at its end); stream: "
+                         "svh_elas_stream_* -- a producer thread pushes the steps' pairs, this thread pops "
+                         "them, the lanes stay full across steps.  auto = stream for the workloads whose "
+                         "step is shorter than the pipeline is deep (sequence, hd1080), batch for kitti")
+    ap.add_argument("--depth", type=int, default=0, help="stream: pairs in flight (0: lanes x 2 groups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary legs (synthetic, host buffers, latency, Matcher, VO, map)")
@@ -493,8 +499,8 @@ def main():
         # kernels -- 8 pairs per step as 4 lanes x 2 pairs: 2.2 k pairs/s against 1.7 k as 8 x 1)
         if args.workload != "hd1080":
             args.group = 32
-        elif args.batch >= 32 and args.stage != "host":
-            args.group = 8            # a deep step: the library's automatic mode takes the device stage
+        elif (args.batch >= 32 or args.api in ("auto", "stream")) and args.stage != "host":
+            args.group = 8            # a deep step / a stream: the library's automatic mode takes the device stage
         else:
             args.group = 2 if args.stage == "device" else 1
 
@@ -550,7 +556,15 @@ def main():
     cores_per_rank = avail / max(world, 1)
     # (with the device stage the workers only enqueue and sleep: 6 of them, 12 streams, already
     # saturate the device; more only stretches every kernel's in-run duration)
-    dev_stage = args.stage != "host" and (args.workload != "hd1080" or args.stage == "device" or args.batch >= 32)
+    api = args.api if args.api != "auto" else ("batch" if args.workload == "kitti" else "stream")
+    # (a stream always asks for the device stage where the geometry allows it: its workers only enqueue and
+    # sleep; so does a rank with fewer than 4 cores to itself -- the host stage of 1920x1080 pairs needs 5-7:
+    # the first 8-rank run on a 16-core quota must not be a host-starvation artefact)
+    dev_stage = args.stage != "host" and (args.workload != "hd1080" or args.stage == "device" or args.batch >= 32
+                                          or api == "stream" or cores_per_rank < 4)
+    if dev_stage and args.stage == "auto" and args.workload == "hd1080" and api == "batch" and args.batch < 32:
+        S.set_stage(1)     # the library's automatic mode would take the host stage for a shallow batch of large images
+        args.stage = "device (auto: %.1f cores per rank)" % cores_per_rank
     # device stage: 6 workers whatever the core count (they use ~0.03 cores each; 8 ranks on a 16-core
     # quota keep the depth the single-GPU number was measured with); host stage: by cores
     lanes = args.lanes or (6 if dev_stage else int(max(2, min(24, round(1.5 * cores_per_rank)))))
@@ -587,10 +601,40 @@ def main():
         dI1, dI2 = tile_to_device(I1, I2)
         data = "synthetic"
         what = "the bench's own %dx%d synthetic pairs" % (W, H)
-    dD1 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    dD2 = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    depth = args.depth or lanes * 2 * group
+    # stream: several steps are in flight at once, each writes its own slice of a ring of output buffers
+    nring = 1 if api == "batch" else (depth + B - 1) // B + 1
+    dDr1 = torch.empty((nring * B, H, W), dtype=torch.float32, device=dev)
+    dDr2 = torch.empty((nring * B, H, W), dtype=torch.float32, device=dev)
+    dD1, dD2 = dDr1[:B], dDr2[:B]
     torch.cuda.synchronize()
     e = S.Elas(params)
+    # (opened after the spin-up and the probe step: a stream holds its workers' lanes while it is open,
+    # the batch entry would wait for them)
+    stm_box = [None]
+    stream_steps = [0]
+
+    def run_stream(k):
+        """k steps through the stream: a producer thread pushes k x B pairs, this thread pops them"""
+        import threading
+        if stm_box[0] is None:
+            stm_box[0] = e.stream(W, H, W, depth)
+        stm = stm_box[0]
+        base = stream_steps[0]
+
+        def produce():
+            for j in range(k):
+                sl = ((base + j) % nring) * B
+                stm.push_device_n(B, dI1.data_ptr(), dI2.data_ptr(), W * H, dDr1[sl].data_ptr(),
+                                  dDr2[sl].data_ptr(), W * H * 4)
+            stm.flush()
+        th = threading.Thread(target=produce)
+        th.start()
+        for j in range(k):
+            st = stm.pop_n(B)
+            assert len(st) == B and all(x == 0 for x in st), ("stream statuses", [x for x in st if x][:8], S.last_error())
+        th.join()
+        stream_steps[0] = base + k
 
     def step():
         st = e.process_batch_device(B, dI1.data_ptr(), dI2.data_ptr(), W * H, dD1.data_ptr(),
@@ -608,8 +652,9 @@ def main():
     step()
     while time.perf_counter() - t_spin < args.spinup:   # untimed: clocks up, lanes allocated
         step()
-    for _ in range(args.warmup):
-        step()
+    if api != "stream":
+        for _ in range(args.warmup):
+            step()
     # which kernel dominates?  one profiled, untimed step with every kernel bracketed
     in_region = bool(args.profile_in_timed_region) and rank == 0
     prof_all = {}
@@ -627,14 +672,24 @@ def main():
         S.lib().svh_profile_only(dom0.encode())
         S.lib().svh_profile_reset()
         S.lib().svh_profile_enable(1)
+    if api == "stream":
+        run_stream(max(1, args.warmup))      # opens the stream; its workers and lanes stay up from here on
     barrier()
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if api == "stream":
+        run_stream(args.steps)       # returns when the last pair of the last step has been popped
+        sl = ((stream_steps[0] - 1) % nring) * B
+        dD1, dD2 = dDr1[sl:sl + B], dDr2[sl:sl + B]     # the maps of the last step (self-check below)
+    else:
+        for _ in range(args.steps):
+            step()
     torch.cuda.synchronize()
     elapsed_local = time.perf_counter() - t0
+    if stm_box[0] is not None:
+        stm_box[0].close()
+        stm_box[0] = None
     barrier()
     elapsed = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
@@ -646,8 +701,17 @@ def main():
     # the only collective on the path: a small per-rank result record (RCCL over xGMI, or gloo)
     from svhip import shard
     my_pairs = B * args.steps
+    # hd1080 has no committed goldens (synthetic pairs): every rank compares the maps of its first two pairs,
+    # as the last timed step left them, with the reference's Elas::process run here on the same inputs
+    # (oracle/_ref, the checker -- after the timed region), every pixel
+    oracle_bad = -1.0
+    if args.workload == "hd1080" and data == "synthetic" and Hh.have_ref_elas():
+        oracle_bad = 0.0
+        for k in sorted(set((0, min(1, B - 1)))):
+            R1, R2 = Hh.ref_elas_process(params, I1[k % U], I2[k % U])
+            oracle_bad += float((dD1[k].cpu().numpy() != R1).sum() + (dD2[k].cpu().numpy() != R2).sum())
     rec = [float(my_pairs), float((dD1[0] >= 0).sum().item()), host_cores_used, float(lanes),
-           elapsed_local, cpu_s / my_pairs, float(device_index)]
+           elapsed_local, cpu_s / my_pairs, float(device_index), oracle_bad]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -661,7 +725,8 @@ def main():
               "host_cpu_us_per_pair": round(1e6 * x[5], 1),
               # what this rank's share of the host cores could feed at that CPU cost per pair
               "host_core_ceiling_pairs_per_s": round(cores_per_rank / x[5]) if x[5] > 0 else None,
-              "d1_valid_px_first_pair": int(x[1])} for r, x in enumerate(recs)]
+              "d1_valid_px_first_pair": int(x[1]),
+              "oracle_mismatch_px_first_two_pairs": (int(x[7]) if x[7] >= 0 else None)} for r, x in enumerate(recs)]
 
     # ---- roofline of the dominant kernel.  Three measurements, kept apart:
     #   in_run     HIP events around its launches DURING the timed steps: ~10 kernels of different workers
@@ -903,13 +968,18 @@ def main():
                        "pairs_per_launch": group, "host_cores_used": round(float(recs[:, 2].sum()), 1),
                        "host_cpu_quota": _cpu_quota(), "host_cores_per_rank": round(cores_per_rank, 2),
                        "dist_backend": args.dist_backend if world > 1 else None,
-                       "gpus_visible": ndev, "build": build, "stage": args.stage,
+                       "gpus_visible": ndev, "build": build, "stage": args.stage, "api": api,
+                       "stream_depth_pairs": depth if api == "stream" else None,
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "stage_groups_device_handed_back": list(S.stage_stats()),
                        "d1_valid_fraction": round(valid, 4)},
             "ranks": ranks,
             "roofline": roofline,
         }
+        if args.workload == "hd1080" and all(r_["oracle_mismatch_px_first_two_pairs"] is not None for r_ in ranks):
+            out["outputs_match_oracle"] = all(r_["oracle_mismatch_px_first_two_pairs"] == 0 for r_ in ranks)
+            out["oracle_check"] = "every rank: D1 and D2 of its first two pairs after the last timed step == the " \
+                                  "reference's Elas::process (oracle/_ref) on the same synthetic inputs, every pixel"
         if golden_check is not None:
             out["outputs_match_golden"] = (len(golden_check["mismatches"]) == 0 and golden_check["copies_differing"] == 0
                                            and (golden_check["soak"] is None or golden_check["soak"]["maps_differing"] == 0))

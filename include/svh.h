@@ -111,6 +111,52 @@ int32_t svh_elas_process_batch_device(svh_elas* e, int32_t n,
                                       float* dD1, float* dD2, size_t out_stride,
                                       const int32_t* dims, int32_t* status);
 
+/* ---- streaming submission (round 4) -----------------------------------------
+ * The reference's producer hands over ONE pair at a time (stereomapper/
+ * readfromfilesthread.cpp:63,104 -> stereothread.cpp:68-176, maindialog.cpp:456-465) and
+ * BASELINE configs[2] is a sequence "streamed" frame by frame.  A stream keeps the
+ * engine's lanes full ACROSS calls: pairs enter a bounded queue, are cut into groups of
+ * consecutive pairs (svh_elas_set_group) that workers pipeline over their lanes exactly
+ * as the batch entries do, and come back in submission order with a status each.
+ * Elas::process semantics per pair are unchanged (same maps, same "<3 support points"
+ * message and status, outputs untouched then).
+ *   open   dims = {width, height, bytes_per_line}; depth = pairs that may be in flight
+ *          (0: lanes x 2 groups).  NULL on error (svh_last_error()).
+ *   push   host buffers (any kind, pinned is faster): they must stay valid, and D1/D2
+ *          unread, until the pair is popped.  Blocks while `depth` pairs are in flight.
+ *          *ticket (may be NULL) receives the pair's sequence number, 0, 1, 2 ...
+ *   push_device  the same with images / maps resident in device memory; pairs whose four
+ *          pointers continue an arithmetic progression share a kernel launch.
+ *   flush  the pairs pushed so far start now (a group otherwise starts when it is full
+ *          or when pop has nothing older to wait for).
+ *   pop    the next pair in submission order: blocks until it is done.  Returns SVH_OK
+ *          and fills *ticket / *status, SVH_ERR_EMPTY when nothing is in flight,
+ *          SVH_ERR_TIMEOUT after timeout_ms (< 0: no limit).
+ *   close  drains (every pushed pair completes), then frees the stream.
+ * push / flush / pop may be called from different threads (a producer and a consumer, or
+ * several producers: tickets define the order).                                          */
+#define SVH_ERR_EMPTY         -5
+#define SVH_ERR_TIMEOUT       -6
+typedef struct svh_elas_stream svh_elas_stream;
+svh_elas_stream* svh_elas_stream_open(svh_elas* e, const int32_t* dims, int32_t depth);
+int32_t svh_elas_stream_push(svh_elas_stream* s, const uint8_t* I1, const uint8_t* I2,
+                             float* D1, float* D2, uint64_t* ticket);
+int32_t svh_elas_stream_push_device(svh_elas_stream* s, const uint8_t* dI1, const uint8_t* dI2,
+                                    float* dD1, float* dD2, uint64_t* ticket);
+int32_t svh_elas_stream_flush(svh_elas_stream* s);
+int32_t svh_elas_stream_pop(svh_elas_stream* s, uint64_t* ticket, int32_t* status, int32_t timeout_ms);
+int32_t svh_elas_stream_close(svh_elas_stream* s);
+/* n pairs in one call (n images spaced in_stride bytes apart, n maps out_stride bytes apart, as in
+ * svh_elas_process_batch_device): push_device_n blocks while the stream is full, pop_n until n pairs
+ * are done -- it WAITS for pairs that have not been pushed yet, so the consumer may start before the
+ * producer (status may be NULL; returns the first non-OK status; *popped says how many came back).
+ * A producer thread in push_device_n and a consumer in pop_n keep the lanes full without a call per
+ * frame.                                                                                             */
+int32_t svh_elas_stream_push_device_n(svh_elas_stream* s, int32_t n, const uint8_t* dI1, const uint8_t* dI2,
+                                      size_t in_stride, float* dD1, float* dD2, size_t out_stride,
+                                      uint64_t* first_ticket);
+int32_t svh_elas_stream_pop_n(svh_elas_stream* s, int32_t n, int32_t* status, int32_t* popped);
+
 /* Device buffers, pinned staging, streams and events live in a per-device pool of "lanes" that
  * outlives the svh_elas handles (callers build an Elas per frame).  svh_elas_trim() releases
  * every lane that is not in use at the moment -- e.g. after one large batch in a long-lived

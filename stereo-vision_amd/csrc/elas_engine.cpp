@@ -33,6 +33,7 @@
 #include <functional>
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -356,7 +357,7 @@ static Pool* pool_for(int device) {
 static void acquire_lanes(int device, int count, Lane** out) {
     Pool* p = pool_for(device);
     std::unique_lock<std::mutex> lk(p->mu);
-    p->max_lanes = 2 * g_lanes.load();
+    p->max_lanes = 2 * g_lanes.load() + 2;   // (+2: single calls still find a lane while a stream holds its workers' lanes)
     for (;;) {
         const int can_make = p->max_lanes - (int)p->lanes.size();
         if ((int)p->free_list.size() + std::max(can_make, 0) >= count) {
@@ -939,6 +940,41 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
 
 }  // namespace svh
 
+// ---------------------------------------------------------------------------
+// streaming submission (svh_elas_stream_*): a bounded queue of groups in front of workers that
+// pipeline them over two lanes each, exactly as a batch worker does -- but the workers and their
+// lanes live as long as the stream, so nothing ramps up or drains between calls
+// ---------------------------------------------------------------------------
+struct StreamGroup {
+    uint64_t first = 0;              // ticket of its first pair
+    int32_t n = 0;
+    bool device = false, closed = false, done = false;
+    int rc = SVH_OK;                 // < 0: the whole group failed (err has the text)
+    std::string err;
+    int32_t status[svh::kMaxGroup];
+    const uint8_t* hI[2][svh::kMaxGroup];
+    float* hD[2][svh::kMaxGroup];
+    const uint8_t* dI[2] = {nullptr, nullptr};
+    float* dD[2] = {nullptr, nullptr};
+    ptrdiff_t in_stride = 0, out_stride = 0;   // bytes / floats between consecutive pairs (device form)
+};
+
+struct svh_elas_stream {
+    svh_elas_params p;
+    int device = 0;
+    int32_t dims[3] = {0, 0, 0};
+    int32_t G = 1, depth = 0;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done, cv_space, cv_push;
+    std::deque<std::shared_ptr<StreamGroup>> order;   // every group with pairs that were not popped yet
+    std::deque<std::shared_ptr<StreamGroup>> ready;   // closed, waiting for a worker
+    std::shared_ptr<StreamGroup> open;                // the group being filled (also order.back())
+    uint64_t next_ticket = 0;
+    int32_t popped_in_head = 0, inflight = 0;
+    bool stop = false;
+    std::vector<std::thread> workers;
+};
+
 // Parked worker threads for the batch entries: grown on demand, never torn down (they sleep on
 // a condition variable between batches).
 namespace {
@@ -1323,6 +1359,282 @@ int32_t svh_elas_process_batch_device(svh_elas* e, int32_t n, const uint8_t* dI1
         io.out_stride = out_stride / sizeof(float);
         return io;
     });
+}
+
+// ---- streaming submission ----------------------------------------------------------------
+static GroupIO stream_io(const StreamGroup& g, int32_t pitch) {
+    GroupIO io{};
+    io.g = g.n;
+    io.pitch = pitch;
+    io.in_device = io.out_device = g.device;
+    if (g.device) {
+        io.dI[0] = g.dI[0]; io.dI[1] = g.dI[1];
+        io.in_stride = (size_t)g.in_stride;
+        io.dD[0] = g.dD[0]; io.dD[1] = g.dD[1];
+        io.out_stride = (size_t)g.out_stride;
+    } else {
+        io.hI[0] = g.hI[0]; io.hI[1] = g.hI[1];
+        io.hD[0] = g.hD[0]; io.hD[1] = g.hD[1];
+    }
+    return io;
+}
+
+// (mu held) the open group goes to the workers
+static void stream_close_open(svh_elas_stream* s) {
+    if (!s->open) return;
+    s->open->closed = true;
+    s->ready.push_back(s->open);
+    s->open.reset();
+    s->cv_work.notify_one();
+}
+
+static void stream_worker(svh_elas_stream* s) {
+    t_device = s->device;
+    (void)hipSetDevice(s->device);
+    Lane* slot[2] = {nullptr, nullptr};
+    acquire_lanes(s->device, 2, slot);
+    for (Lane* L : slot)
+        if (L) {
+            L->parallel_host = false;
+            L->poll_wait = true;      // the workers sleep between polls: a stream must not cost a core per lane
+            (void)L->ensure(s->p, s->dims[0], s->dims[1], s->G);
+        }
+    auto take = [&](bool block) -> std::shared_ptr<StreamGroup> {
+        std::unique_lock<std::mutex> lk(s->mu);
+        if (block) s->cv_work.wait(lk, [&] { return s->stop || !s->ready.empty(); });
+        if (s->ready.empty()) return nullptr;
+        std::shared_ptr<StreamGroup> g = s->ready.front();
+        s->ready.pop_front();
+        return g;
+    };
+    auto note = [&](StreamGroup& g, int rc) {
+        if (rc != SVH_OK && g.rc == SVH_OK) {
+            g.rc = rc;
+            if (rc < 0) g.err = t_error;
+        }
+    };
+    std::shared_ptr<StreamGroup> pend[2];
+    auto finish = [&](int q) {
+        if (!pend[q]) return;
+        StreamGroup& g = *pend[q];
+        note(g, run_group(*slot[q], s->p, s->dims, stream_io(g, s->dims[2]), g.status, nullptr, nullptr, RG_FINISH));
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            g.done = true;
+        }
+        s->cv_done.notify_all();
+        pend[q].reset();
+    };
+    for (;;) {
+        std::shared_ptr<StreamGroup> cur = take(true);
+        if (!cur) break;
+        int k = 0;
+        note(*cur, run_group(*slot[k], s->p, s->dims, stream_io(*cur, s->dims[2]), cur->status, nullptr, nullptr, RG_A, 2));
+        while (cur) {
+            std::shared_ptr<StreamGroup> nxt = slot[1] ? take(false) : nullptr;
+            if (nxt) {
+                finish(1 - k);
+                note(*nxt, run_group(*slot[1 - k], s->p, s->dims, stream_io(*nxt, s->dims[2]), nxt->status, nullptr,
+                                     nullptr, RG_A, 2));
+            }
+            if (cur->rc == SVH_OK)
+                note(*cur, run_group(*slot[k], s->p, s->dims, stream_io(*cur, s->dims[2]), cur->status, nullptr, nullptr,
+                                     RG_HOST_B));
+            pend[k] = cur;
+            if (nxt) {
+                k = 1 - k;
+            } else {   // nothing queued right now: complete what is on the lanes, then wait for work
+                finish(k);
+                finish(1 - k);
+            }
+            cur = nxt;
+        }
+    }
+    for (Lane* L : slot)
+        if (L) {
+            L->poll_wait = false;
+            L->parallel_host = true;
+            release_lane(L);
+        }
+}
+
+svh_elas_stream* svh_elas_stream_open(svh_elas* e, const int32_t* dims, int32_t depth) {
+    if (!e || !dims) {
+        fail(SVH_ERR_BAD_ARG, "null argument");
+        return nullptr;
+    }
+    if (require_device(e->device) || check_params(e->p, dims[0], dims[1])) return nullptr;
+    svh_elas_stream* s = new svh_elas_stream();
+    s->p = e->p;
+    s->device = e->device;
+    for (int k = 0; k < 3; k++) s->dims[k] = dims[k];
+    s->G = group_for((size_t)dims[0] * dims[1]);
+    const int lanes = std::max(1, g_lanes.load());
+    s->depth = depth > 0 ? depth : lanes * 2 * s->G;
+    // a worker keeps two groups in flight: no more workers than the depth can feed
+    const int nw = std::max(1, std::min(lanes, (s->depth + 2 * s->G - 1) / (2 * s->G)));
+    for (int w = 0; w < nw; w++) s->workers.emplace_back(stream_worker, s);
+    return s;
+}
+
+static int32_t stream_push(svh_elas_stream* s, bool device, const uint8_t* I1, const uint8_t* I2, float* D1,
+                           float* D2, uint64_t* ticket) {
+    if (!s || !I1 || !I2 || !D1 || !D2) return fail(SVH_ERR_BAD_ARG, "null argument");
+    std::unique_lock<std::mutex> lk(s->mu);
+    if (s->stop) return fail(SVH_ERR_BAD_ARG, "stream is closing");
+    s->cv_space.wait(lk, [&] { return s->inflight < s->depth; });
+    StreamGroup* g = s->open.get();
+    if (g && g->device != device) {
+        stream_close_open(s);
+        g = nullptr;
+    }
+    if (g && device) {
+        // pairs of one launch lie at base + j * stride: the new pair must continue the progression
+        const ptrdiff_t di1 = I1 - (g->dI[0] + (g->n - 1) * g->in_stride), di2 = I2 - (g->dI[1] + (g->n - 1) * g->in_stride);
+        const ptrdiff_t dd1 = D1 - (g->dD[0] + (g->n - 1) * g->out_stride), dd2 = D2 - (g->dD[1] + (g->n - 1) * g->out_stride);
+        bool fits;
+        if (g->n == 1) {
+            fits = di1 > 0 && di1 == di2 && dd1 > 0 && dd1 == dd2;
+            if (fits) {
+                g->in_stride = di1;
+                g->out_stride = dd1;
+            }
+        } else {
+            fits = di1 == g->in_stride && di2 == g->in_stride && dd1 == g->out_stride && dd2 == g->out_stride;
+        }
+        if (!fits) {
+            stream_close_open(s);
+            g = nullptr;
+        }
+    }
+    if (!g) {
+        s->open = std::make_shared<StreamGroup>();
+        g = s->open.get();
+        g->first = s->next_ticket;
+        g->device = device;
+        s->order.push_back(s->open);
+    }
+    const int32_t j = g->n++;
+    g->status[j] = SVH_OK;
+    if (device) {
+        if (j == 0) {
+            g->dI[0] = I1; g->dI[1] = I2;
+            g->dD[0] = D1; g->dD[1] = D2;
+        }
+    } else {
+        g->hI[0][j] = I1; g->hI[1][j] = I2;
+        g->hD[0][j] = D1; g->hD[1][j] = D2;
+    }
+    if (ticket) *ticket = s->next_ticket;
+    s->next_ticket++;
+    s->inflight++;
+    if (g->n >= s->G) stream_close_open(s);
+    lk.unlock();
+    s->cv_push.notify_all();
+    return SVH_OK;
+}
+
+int32_t svh_elas_stream_push(svh_elas_stream* s, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,
+                             uint64_t* ticket) {
+    return stream_push(s, false, I1, I2, D1, D2, ticket);
+}
+
+int32_t svh_elas_stream_push_device(svh_elas_stream* s, const uint8_t* dI1, const uint8_t* dI2, float* dD1,
+                                    float* dD2, uint64_t* ticket) {
+    return stream_push(s, true, dI1, dI2, dD1, dD2, ticket);
+}
+
+int32_t svh_elas_stream_flush(svh_elas_stream* s) {
+    if (!s) return fail(SVH_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    stream_close_open(s);
+    return SVH_OK;
+}
+
+int32_t svh_elas_stream_pop(svh_elas_stream* s, uint64_t* ticket, int32_t* status, int32_t timeout_ms) {
+    if (!s) return fail(SVH_ERR_BAD_ARG, "null argument");
+    std::unique_lock<std::mutex> lk(s->mu);
+    if (s->order.empty()) return SVH_ERR_EMPTY;
+    std::shared_ptr<StreamGroup> g = s->order.front();
+    if (!g->closed) stream_close_open(s);   // nothing older to wait for: the partial group starts now
+    auto ready = [&] { return g->done; };
+    if (timeout_ms < 0) {
+        s->cv_done.wait(lk, ready);
+    } else if (!s->cv_done.wait_for(lk, std::chrono::milliseconds(timeout_ms), ready)) {
+        return SVH_ERR_TIMEOUT;
+    }
+    const int32_t j = s->popped_in_head++;
+    if (ticket) *ticket = g->first + (uint64_t)j;
+    if (status) *status = g->rc != SVH_OK ? g->rc : g->status[j];
+    if (g->rc < 0) t_error = g->err;
+    if (s->popped_in_head >= g->n) {
+        s->order.pop_front();
+        s->popped_in_head = 0;
+    }
+    s->inflight--;
+    lk.unlock();
+    s->cv_space.notify_all();
+    return SVH_OK;
+}
+
+int32_t svh_elas_stream_push_device_n(svh_elas_stream* s, int32_t n, const uint8_t* dI1, const uint8_t* dI2,
+                                      size_t in_stride, float* dD1, float* dD2, size_t out_stride,
+                                      uint64_t* first_ticket) {
+    if (n < 0 || out_stride % sizeof(float)) return fail(SVH_ERR_BAD_ARG, "bad count / out_stride must be a multiple of 4");
+    for (int32_t i = 0; i < n; i++) {
+        uint64_t t = 0;
+        const int32_t rc = stream_push(s, true, dI1 + (size_t)i * in_stride, dI2 + (size_t)i * in_stride,
+                                       dD1 + (size_t)i * (out_stride / sizeof(float)),
+                                       dD2 + (size_t)i * (out_stride / sizeof(float)), &t);
+        if (rc) return rc;
+        if (i == 0 && first_ticket) *first_ticket = t;
+    }
+    return SVH_OK;
+}
+
+int32_t svh_elas_stream_pop_n(svh_elas_stream* s, int32_t n, int32_t* status, int32_t* popped) {
+    int32_t first_bad = SVH_OK, k = 0;
+    for (; k < n; k++) {
+        int32_t st = SVH_OK;
+        int32_t rc = svh_elas_stream_pop(s, nullptr, &st, -1);
+        while (rc == SVH_ERR_EMPTY) {
+            // the consumer got ahead of the producer: wait for the next push (a closing stream ends the wait)
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv_push.wait(lk, [&] { return s->stop || !s->order.empty(); });
+            if (s->stop && s->order.empty()) break;
+            lk.unlock();
+            rc = svh_elas_stream_pop(s, nullptr, &st, -1);
+        }
+        if (rc) {
+            if (popped) *popped = k;
+            return rc;
+        }
+        if (status) status[k] = st;
+        if (first_bad == SVH_OK && st != SVH_OK) first_bad = st;
+    }
+    if (popped) *popped = k;
+    return first_bad;
+}
+
+int32_t svh_elas_stream_close(svh_elas_stream* s) {
+    if (!s) return fail(SVH_ERR_BAD_ARG, "null argument");
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        stream_close_open(s);
+        // every pushed pair completes (the callers' buffers are written or left untouched as promised)
+        s->cv_done.wait(lk, [&] {
+            for (auto& g : s->order)
+                if (!g->done) return false;
+            return true;
+        });
+        s->stop = true;
+    }
+    s->cv_work.notify_all();
+    s->cv_space.notify_all();
+    s->cv_push.notify_all();
+    for (std::thread& t : s->workers) t.join();
+    delete s;
+    return SVH_OK;
 }
 
 int32_t svh_elas_support_from_candidates(const svh_elas_params* p, int32_t width, int32_t height,

@@ -63,6 +63,16 @@ def lib():
         L.svh_elas_process_batch_device.argtypes = [
             C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
             C.c_size_t, C.c_void_p, C.c_void_p]
+        L.svh_elas_stream_open.restype = C.c_void_p
+        L.svh_elas_stream_open.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.svh_elas_stream_push.argtypes = [C.c_void_p] * 5 + [C.POINTER(C.c_uint64)]
+        L.svh_elas_stream_push_device.argtypes = [C.c_void_p] * 5 + [C.POINTER(C.c_uint64)]
+        L.svh_elas_stream_flush.argtypes = [C.c_void_p]
+        L.svh_elas_stream_pop.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.c_int32]
+        L.svh_elas_stream_close.argtypes = [C.c_void_p]
+        L.svh_elas_stream_push_device_n.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                    C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+        L.svh_elas_stream_pop_n.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
         L.svh_elas_set_taps.argtypes = [C.c_void_p, C.c_int32]
         L.svh_elas_get_stage.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
                                          C.POINTER(C.c_size_t)]
@@ -70,6 +80,87 @@ def lib():
         L.svh_delaunay.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         _lib = L
     return _lib
+
+
+SVH_ERR_EMPTY, SVH_ERR_TIMEOUT = -5, -6
+
+
+class SvhTimeout(SvhError):
+    """svh_elas_stream_pop: the next pair was not done within timeout_ms (it stays queued)"""
+
+
+class ElasStream:
+    """svh_elas_stream_*: a bounded, ordered queue of pairs in front of the engine's lanes
+    (include/svh.h).  Host arrays pushed here must stay alive until their pair is popped: the
+    stream keeps a reference to them."""
+
+    def __init__(self, elas, w, h, pitch, depth=0):
+        dims = (C.c_int32 * 3)(w, h, pitch)
+        self._h = lib().svh_elas_stream_open(elas._h, dims, depth)
+        if not self._h:
+            raise SvhError(-1, last_error())
+        self._keep = {}
+
+    def push(self, I1, I2, D1, D2):
+        """host arrays (uint8 [H,W] with the stream's pitch; float32 maps written in place)"""
+        t = C.c_uint64(0)
+        rc = lib().svh_elas_stream_push(self._h, I1.ctypes.data, I2.ctypes.data, D1.ctypes.data,
+                                        D2.ctypes.data, C.byref(t))
+        if rc < 0:
+            raise SvhError(rc, last_error())
+        self._keep[t.value] = (I1, I2, D1, D2)
+        return t.value
+
+    def push_device(self, dI1, dI2, dD1, dD2):
+        """raw device pointers (ints)"""
+        t = C.c_uint64(0)
+        rc = lib().svh_elas_stream_push_device(self._h, dI1, dI2, dD1, dD2, C.byref(t))
+        if rc < 0:
+            raise SvhError(rc, last_error())
+        return t.value
+
+    def push_device_n(self, n, dI1, dI2, in_stride, dD1, dD2, out_stride):
+        """n consecutive device-resident pairs in one call (blocks while the stream is full)"""
+        t = C.c_uint64(0)
+        rc = lib().svh_elas_stream_push_device_n(self._h, n, dI1, dI2, in_stride, dD1, dD2, out_stride, C.byref(t))
+        if rc < 0:
+            raise SvhError(rc, last_error())
+        return t.value
+
+    def pop_n(self, n):
+        """statuses of the next n pairs (blocks until they are done)"""
+        st = (C.c_int32 * n)()
+        got = C.c_int32(0)
+        rc = lib().svh_elas_stream_pop_n(self._h, n, st, C.byref(got))
+        if rc < 0:
+            raise SvhError(rc, last_error())
+        return list(st)[:got.value]
+
+    def flush(self):
+        lib().svh_elas_stream_flush(self._h)
+
+    def pop(self, timeout_ms=-1):
+        """(ticket, status) of the next pair in submission order; None when nothing is in flight"""
+        t, st = C.c_uint64(0), C.c_int32(0)
+        rc = lib().svh_elas_stream_pop(self._h, C.byref(t), C.byref(st), timeout_ms)
+        if rc == SVH_ERR_EMPTY:
+            return None
+        if rc == SVH_ERR_TIMEOUT:
+            raise SvhTimeout(rc, "timeout")
+        if rc < 0:
+            raise SvhError(rc, last_error())
+        self._keep.pop(t.value, None)
+        return t.value, st.value
+
+    def close(self):
+        h, self._h = self._h, None
+        if h:
+            lib().svh_elas_stream_close(h)
+        self._keep.clear()
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            self.close()
 
 
 def last_error():
@@ -181,6 +272,10 @@ class Elas:
         if rc < 0:
             raise SvhError(rc, last_error())
         return list(st)
+
+    def stream(self, w, h, pitch=None, depth=0):
+        """streaming submission (svh_elas_stream_*): pairs in one at a time, results in order"""
+        return ElasStream(self, w, h, pitch if pitch is not None else w, depth)
 
     # ---- parity taps -----------------------------------------------------
     def set_taps(self, enable=True):
