@@ -81,6 +81,12 @@ int32_t     svh_set_device(int32_t device);
 /* ------------------------------------------------------------------------ */
 typedef struct svh_elas svh_elas;
 
+/* Environment switches read by the library (all optional):
+ *   SVH_MATCHER_WAIT=0|1   Matcher / visual odometry waits: 0 spin in the driver, 1 sleep between polls
+ *                          (default: spin while at most two threads are inside the library, poll otherwise)
+ *   SVH_WAIT_US=n          sleep of the ELAS batch / stream workers between completion polls (40; 0 = spin)
+ *   SVH_H2D_STRIDED=0, SVH_D2H_STRIDED=0   one copy per image / map instead of one strided copy per group
+ *   SVH_MATCH_LIST=0       dense matching with round 3's k_match_keyed instead of k_match_list (A/B runs)   */
 /* Elas::Elas(parameters) -- libelas/src/elas.h:151.  Cheap: callers build one
  * per frame (stereomapper/stereothread.cpp:113); device buffers live in a
  * process-wide pool keyed by (device, width, height).                        */

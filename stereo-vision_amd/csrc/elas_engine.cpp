@@ -729,7 +729,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
             if (pinned) {
                 // packed images whose buffers follow one another go up as one strided copy per camera
                 // (device layout: I1, I2 of a pair interleaved)
-                static const bool strided_up = !(getenv("SVH_D2H_STRIDED") && atoi(getenv("SVH_D2H_STRIDED")) == 0);
+                static const bool strided_up = !(getenv("SVH_H2D_STRIDED") && atoi(getenv("SVH_H2D_STRIDED")) == 0);
                 for (int k = 0; k < 2; k++)
                     for (int32_t j = 0; j < g;) {
                         uint8_t* dst = L.img + ((size_t)2 * j + k) * N;
@@ -1232,6 +1232,8 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
                 // the driver; otherwise every core already has a worker and the waits sleep-poll
                 L->parallel_host = ngroups <= lanes;
                 L->poll_wait = !L->parallel_host;
+                // (a failure here -- out of device memory -- is reported by the first run_group on this lane,
+                // which sizes it again and returns the error for its group)
                 if (hipSetDevice(L->device) == hipSuccess) (void)L->ensure(e->p, dims[0], dims[1], G);
             }
         struct Job { int32_t gi = -1; GroupIO io{}; int32_t first = 0; };

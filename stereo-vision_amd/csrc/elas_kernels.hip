@@ -2089,12 +2089,19 @@ void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d
     // launch.  A whole lattice row per 1024-thread block (79 KB of LDS) is faster alone (304 us) and slower
     // in the pipeline (29.1 vs 29.5 k pairs/s): two such blocks take a CU's LDS away from everything else.
     static const int sb_env = getenv("SVH_SUPPORT_SB") ? atoi(getenv("SVH_SUPPORT_SB")) : 64;
-    const int sb = sb_env == 32 ? 32 : 64;
-    const int span = (sb - 1) * d.step;
-    const size_t wl = (size_t)std::min(d.W, span + 2 * p.disp_max + 5);
-    const size_t wr = (size_t)std::min(d.W, span + p.disp_max + 5);
-    const size_t lds = 2 * (wl + wr) * sizeof(uint4);
-    if (lds <= 64 * 1024) {
+    // strip by fit: 64 candidates per block, else 32 (large candidate_stepsize or disp_max), else the generic
+    // kernel; the kernel's static LDS (s_fwd, s_todo, s_ntodo) counts against the 64 KB limit
+    constexpr size_t kSupportStatic = 512;
+    auto strip_lds = [&](int sb) {
+        const int span = (sb - 1) * d.step;
+        const size_t wl = (size_t)std::min(d.W, span + 2 * p.disp_max + 5);
+        const size_t wr = (size_t)std::min(d.W, span + p.disp_max + 5);
+        return 2 * (wl + wr) * sizeof(uint4);
+    };
+    int sb = sb_env == 32 ? 32 : 64;
+    if (sb == 64 && strip_lds(64) + kSupportStatic > 64 * 1024) sb = 32;
+    const size_t lds = strip_lds(sb);
+    if (lds + kSupportStatic <= 64 * 1024) {
         Timed timed_(cx, "k_support");
         // (pairs * lattice rows rounded up to 8) * chunks blocks: XCD-aware order, see the kernel
         const int chunks = (d.Wc + sb - 1) / sb;

@@ -43,6 +43,8 @@
 //     the pair and the engine reruns that group through the host path.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <algorithm>
 
 #include "svh_internal.h"
@@ -1241,9 +1243,25 @@ static int dt_columns(const svh_elas_params& p, const Dims& d) { return d.W + 2 
 // large lattices (1920x1080: 83 k cells, 6-12 k support points per side) get the whole LDS of a CU: the
 // rank lists of the cut-order phase take 16 bytes per point
 static bool dt_large(const Dims& d) { return (size_t)d.Wc * d.Hc / 8 * 16 > 63 * 1024; }
-static size_t dt_lds_bytes(const svh_elas_params& p, const Dims& d) {
+// the 1024-thread form needs the 159 KB opt-in of the CURRENT device: asked once per device, and a refusal
+// (a part with 64 KB of LDS per workgroup) sends large lattices through the 256-thread / 63 KB form instead
+static bool dt_big_lds_ok() {
+    static std::mutex mu;
+    static int state[64];   // 0 unknown, 1 granted, 2 refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (state[dev] == 0) {
+        const bool ok = hipFuncSetAttribute((const void*)k_delaunay<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            159 * 1024) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        state[dev] = ok ? 1 : 2;
+    }
+    return state[dev] == 1;
+}
+static size_t dt_lds_bytes(const svh_elas_params& p, const Dims& d, bool big) {
     const size_t hist = 4 * (size_t)(2 * (dt_columns(p, d) + d.H) + 2);
-    return dt_large(d) ? std::max<size_t>(hist, 159 * 1024) : std::max<size_t>(hist, 63 * 1024);
+    return big ? std::max<size_t>(hist, 159 * 1024) : std::max<size_t>(hist, 63 * 1024);
 }
 
 bool stage_device_ok(const svh_elas_params& p, const Dims& d) {
@@ -1290,15 +1308,13 @@ void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Di
     DtParams D;
     D.W = dt_columns(p, d); D.H = d.H; D.sup_cap = S.sup_cap; D.rec_cap = S.rec_cap;
     D.xoff = std::max(p.disp_max, 0);
-    const size_t dt_lds = dt_lds_bytes(p, d);
+    const bool big = dt_large(d) && dt_big_lds_ok();
+    const size_t dt_lds = dt_lds_bytes(p, d, big);
     D.lds_ints = (int)(dt_lds / 4);
     D.lds_cap = (int)std::min<size_t>((dt_lds - 32) / 28 - 1, 8000);   // 16-bit handles: < 8191 points
     {
         Timed t(cx, "k_delaunay");
-        if (dt_large(d)) {
-            static const bool ok = hipFuncSetAttribute((const void*)k_delaunay<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       159 * 1024) == hipSuccess;
-            (void)ok;
+        if (big) {
             hipLaunchKernelGGL(k_delaunay<1024>, dim3(2 * g), dim3(1024), dt_lds, s, S, D);
         } else {
             hipLaunchKernelGGL(k_delaunay<256>, dim3(2 * g), dim3(256), dt_lds, s, S, D);

@@ -36,11 +36,24 @@ namespace svh {
 int fail(int code, const std::string& msg);   // elas_engine.cpp: sets svh_last_error()
 static int mfail(int code, const std::string& msg) { return fail(code, msg); }
 
-static std::atomic<int> g_live_matchers{0};
+// Threads that are inside a compute entry of the Matcher / visual odometry right now (svh_matcher_push_back,
+// svh_matcher_match_features, svh_vo_process, svh_vo_estimate_motion).  One or two = a single sequence (the
+// latency path: spin on the stream, triangulate the outlier vote on the helper pool); more = several sequences
+// share this GPU and the host cores: waits sleep between polls and the helper pool is left alone.  What counts
+// is concurrent ACTIVITY, not how many objects exist (a process may hold many Matchers and drive one).
+// SVH_MATCHER_WAIT=0 (spin) / 1 (sleep-poll) overrides the choice.
+static std::atomic<int> g_active_callers{0};
+static thread_local int t_entry_depth = 0;   // svh_vo_process calls the Matcher's entries: a thread counts once
+ActiveCaller::ActiveCaller() {
+    if (t_entry_depth++ == 0) g_active_callers.fetch_add(1, std::memory_order_relaxed);
+}
+ActiveCaller::~ActiveCaller() {
+    if (--t_entry_depth == 0) g_active_callers.fetch_sub(1, std::memory_order_relaxed);
+}
 int wait_stream(void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static const int forced = getenv("SVH_MATCHER_WAIT") ? atoi(getenv("SVH_MATCHER_WAIT")) : -1;   // 0 spin, 1 sleep-poll
-    const bool poll = forced >= 0 ? forced == 1 : g_live_matchers.load(std::memory_order_relaxed) > 2;
+    const bool poll = forced >= 0 ? forced == 1 : g_active_callers.load(std::memory_order_relaxed) > 2;
     if (!poll) return (int)hipStreamSynchronize(s);
     for (;;) {
         const hipError_t e = hipStreamQuery(s);
@@ -324,9 +337,9 @@ static int remove_outliers(const svh_matcher_params& p, std::vector<svh_p_match>
     std::vector<int32_t> tri((size_t)3 * (2 * n + 16));
     // the Matcher is a single-stream, latency-bound path: large votes triangulate on 4 threads
     static const int par = getenv("SVH_DELAUNAY_PAR") ? atoi(getenv("SVH_DELAUNAY_PAR")) : 2;
-    // (several live Matcher objects = several sequences on this GPU: their host threads already fill the
+    // (several callers at once = several sequences on this GPU: their host threads already fill the
     // cores, the helper pool would only be fought over)
-    const bool alone = g_live_matchers.load(std::memory_order_relaxed) <= 2;
+    const bool alone = g_active_callers.load(std::memory_order_relaxed) <= 2;
     const int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 16, (n >= 1500 && alone) ? par : 0);
     if (nt < 0) return mfail(SVH_ERR_UNSUPPORTED, "outlier triangulation failed");
     std::vector<int32_t> votes(n, 0);
@@ -512,7 +525,6 @@ void svh_matcher_params_default(svh_matcher_params* p) {
 svh_matcher* svh_matcher_create(const svh_matcher_params* p) {
     if (!p) return nullptr;
     svh_matcher* m = new svh_matcher();
-    g_live_matchers++;
     m->p = *p;
     m->margin = 8 + 1;                                      // matcher.cpp:56
     if (p->half_resolution) m->p.match_radius /= 2;         // matcher.cpp:59-62
@@ -526,7 +538,6 @@ svh_matcher* svh_matcher_create(const svh_matcher_params* p) {
 
 void svh_matcher_destroy(svh_matcher* m) {
     if (!m) return;
-    g_live_matchers--;
     if (g_mtiming && m->tcalls[0] && m->tcalls[1]) {
         const double a = 1.0 / (double)m->tcalls[0], b = 1.0 / (double)m->tcalls[1];
         fprintf(stderr, "[svh matcher timing] pushBack: pack+enqueue %.3f ms, gpu wait %.3f ms | matchFeatures: "
@@ -566,6 +577,7 @@ void svh_matcher_set_intrinsics(svh_matcher* m, double f, double cu, double cv, 
 
 int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* I2, const int32_t* dims,
                               int32_t replace) {
+    svh::ActiveCaller active_;
     if (!m || !dims) return mfail(SVH_ERR_BAD_ARG, "null argument");
     const int32_t w = dims[0], h = dims[1], pitch = dims[2];
     if (w <= 0 || h <= 0 || pitch < w || I1 == 0) {
@@ -620,6 +632,7 @@ int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* 
 }
 
 int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double* Tr) {
+    svh::ActiveCaller active_;
     if (!m) return mfail(SVH_ERR_BAD_ARG, "null argument");
     const svh_matcher_params& p = m->p;
     // sanity checks: return silently, previous matches stay (matcher.cpp:216-259)

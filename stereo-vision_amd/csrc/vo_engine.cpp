@@ -255,6 +255,7 @@ void svh_vo_destroy(svh_vo* v) {
 }
 
 int32_t svh_vo_process(svh_vo* v, const uint8_t* I1, const uint8_t* I2, const int32_t* dims, int32_t replace) {
+    svh::ActiveCaller active_;
     if (!v || !dims) return svh::fail(SVH_ERR_BAD_ARG, "null argument");
     const svh_vo_params& P = v->p;
     int32_t rc = svh_matcher_push_back(v->matcher, I1, I2, dims, replace);
@@ -277,12 +278,14 @@ int32_t svh_vo_process(svh_vo* v, const uint8_t* I1, const uint8_t* I2, const in
 }
 
 int32_t svh_vo_process_matches(svh_vo* v, const svh_p_match* matches, int32_t n) {
+    svh::ActiveCaller active_;
     if (!v || (n > 0 && !matches) || n < 0) return svh::fail(SVH_ERR_BAD_ARG, "null argument");
     v->matched.assign(matches, matches + n);
     return update_motion(v);
 }
 
 int32_t svh_vo_estimate_motion(svh_vo* v, const svh_p_match* matches, int32_t n, double* tr_delta6) {
+    svh::ActiveCaller active_;
     if (!v || !tr_delta6 || (n > 0 && !matches) || n < 0) return svh::fail(SVH_ERR_BAD_ARG, "null argument");
     return estimate(v, matches, n, tr_delta6);
 }

@@ -20,11 +20,19 @@ struct VoResult {          // written by k_vo_refine into pinned host memory
     int32_t pad_;
 };
 
-// Wait for a stream of a Matcher / visual-odometry object.  One or two live objects: the driver's
-// spinning wait (lowest latency for the single-sequence case of stereomapper).  Three or more live objects
-// in the process (K independent sequences on one GPU): polling with short sleeps, so that K host threads do
-// not burn K cores spinning on a GPU they share (matcher_engine.cpp keeps the count).
+// Wait for a stream of a Matcher / visual-odometry object.  One or two threads inside the library's compute
+// entries at this moment: the driver's spinning wait (lowest latency for the single-sequence case of
+// stereomapper).  Three or more (K independent sequences driven concurrently on one GPU): polling with short
+// sleeps, so that K host threads do not burn K cores spinning on a GPU they share.  The count is of
+// concurrent callers (ActiveCaller below), not of objects that exist; SVH_MATCHER_WAIT=0/1 overrides.
 int wait_stream(void* stream);   // returns a hipError_t value
+// RAII marker of a thread inside a Matcher / visual-odometry compute entry (matcher_engine.cpp)
+struct ActiveCaller {
+    ActiveCaller();
+    ~ActiveCaller();
+    ActiveCaller(const ActiveCaller&) = delete;
+    ActiveCaller& operator=(const ActiveCaller&) = delete;
+};
 
 // pinned host -> device copy by a kernel (bytes is a multiple of 16)
 void vlaunch_upload(void* stream, const uint8_t* pinned, uint8_t* dev, size_t bytes);

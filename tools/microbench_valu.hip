@@ -19,12 +19,14 @@
 enum Op { FMA_F32, PK_FMA_F32, ADD_U32, LSHL_ADD_U32, MIN3_I32, MIN_U32, MED3_U32, SAD_U8, AND_B32, XOR_B32,
           CNDMASK, ADD3_U32, MAD_U32_U24, PK_ADD_U16, MIN_U32_DPP, MOV_DPP, BFE_U32, MUL_LO_U32, PERM_B32,
           CNDMASK_SGPR, CMP_CNDMASK, CMP_VCC, OR_B32, SUB_U32, LSHLREV_B32, LSHRREV_B32, MOV_B32, MAX_U32, MIN_I32, MUL_U32_U24,
-          ADD_F32, MUL_F32, CVT_F32_U32, BFI_B32, OR3_B32, AND_OR_B32, LSHL_OR_B32, ADD_LSHL_U32, BFE_I32, ALIGNBIT, NUM_OPS };
+          ADD_F32, MUL_F32, CVT_F32_U32, BFI_B32, OR3_B32, AND_OR_B32, LSHL_OR_B32, ADD_LSHL_U32, BFE_I32, ALIGNBIT,
+          SAD_HI_U8, SAD_U16, SAD_U32, MSAD_U8, QSAD_PK, MQSAD_PK, MQSAD_U32, SUB_SDWA, NUM_OPS };
 static const char* kNames[NUM_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_add_u32", "v_lshl_add_u32", "v_min3_i32",
     "v_min_u32", "v_med3_u32", "v_sad_u8", "v_and_b32", "v_xor_b32", "v_cndmask_b32", "v_add3_u32", "v_mad_u32_u24",
     "v_pk_add_u16", "v_min_u32_dpp", "v_mov_b32_dpp", "v_bfe_u32", "v_mul_lo_u32", "v_perm_b32",
     "v_cndmask(sgpr)", "v_cmp+v_cndmask", "v_cmp_lt_u32 vcc", "v_or_b32", "v_sub_u32", "v_lshlrev_b32", "v_lshrrev_b32", "v_mov_b32", "v_max_u32", "v_min_i32",
-    "v_mul_u32_u24", "v_add_f32", "v_mul_f32", "v_cvt_f32_u32", "v_bfi_b32", "v_or3_b32", "v_and_or_b32", "v_lshl_or_b32", "v_add_lshl_u32", "v_bfe_i32", "v_alignbit_b32"};
+    "v_mul_u32_u24", "v_add_f32", "v_mul_f32", "v_cvt_f32_u32", "v_bfi_b32", "v_or3_b32", "v_and_or_b32", "v_lshl_or_b32", "v_add_lshl_u32", "v_bfe_i32", "v_alignbit_b32",
+    "v_sad_hi_u8", "v_sad_u16", "v_sad_u32", "v_msad_u8", "v_qsad_pk_u16_u8", "v_mqsad_pk_u16_u8", "v_mqsad_u32_u8", "v_sub_u32_sdwa"};
 
 #define CH8(STMT) STMT(a0) STMT(a1) STMT(a2) STMT(a3) STMT(a4) STMT(a5) STMT(a6) STMT(a7)
 
@@ -35,6 +37,8 @@ __global__ __launch_bounds__(256) void k_probe(uint32_t* out, unsigned long long
     uint32_t b = seed ^ 0x12345678u, c = seed * 77u + 1u;
     // 64-bit pairs for the packed fp32 op
     double p0 = a0, p1 = a1, p2 = a2, p3 = a3, p4 = a4, p5 = a5, p6 = a6, p7 = a7, pb = b, pc = c;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 q0 = {a0, a1, a2, a3}, q1 = {a4, a5, a6, a7}, q2 = {a1, a3, a5, a7}, q3 = {a0, a2, a4, a6};   // 128-bit accumulators (v_mqsad_u32_u8)
     asm volatile("v_cmp_lt_u32 vcc, %0, %1" ::"v"(a0), "v"(b) : "vcc");
     const unsigned long long smask = __builtin_amdgcn_ballot_w64((threadIdx.x & 3) != 0) ^ (unsigned long long)seed;   // an SGPR pair
     unsigned long long t0 = __builtin_readcyclecounter();
@@ -81,6 +85,14 @@ __global__ __launch_bounds__(256) void k_probe(uint32_t* out, unsigned long long
 #define S_BFEI(x) asm volatile("v_bfe_i32 %0, %0, 3, 29" : "+v"(x));
 #define S_ALIGN(x) asm volatile("v_alignbit_b32 %0, %0, %1, 3" : "+v"(x) : "v"(b));
 #define S_PERM(x) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define S_SADHI(x) asm volatile("v_sad_hi_u8 %0, %0, %1, %0" : "+v"(x) : "v"(b));
+#define S_SAD16(x) asm volatile("v_sad_u16 %0, %0, %1, %0" : "+v"(x) : "v"(b));
+#define S_SAD32(x) asm volatile("v_sad_u32 %0, %0, %1, %0" : "+v"(x) : "v"(b));
+#define S_MSAD(x) asm volatile("v_msad_u8 %0, %0, %1, %0" : "+v"(x) : "v"(b));
+#define S_QSAD(x) asm volatile("v_qsad_pk_u16_u8 %0, %0, %1, %0" : "+v"(x) : "v"(b));
+#define S_MQSADPK(x) asm volatile("v_mqsad_pk_u16_u8 %0, %0, %1, %0" : "+v"(x) : "v"(b));
+#define S_MQSAD32(x, y) asm volatile("v_mqsad_u32_u8 %0, %1, %2, %0" : "+v"(x) : "v"(y), "v"(b));
+#define S_SUBSDWA(x) asm volatile("v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(x) : "v"(b));
             if (kOp == FMA_F32) { CH8(S_FMA) }
             else if (kOp == PK_FMA_F32) { S_PKFMA(p0) S_PKFMA(p1) S_PKFMA(p2) S_PKFMA(p3) S_PKFMA(p4) S_PKFMA(p5) S_PKFMA(p6) S_PKFMA(p7) }
             else if (kOp == ADD_U32) { CH8(S_ADD) }
@@ -121,11 +133,20 @@ __global__ __launch_bounds__(256) void k_probe(uint32_t* out, unsigned long long
             else if (kOp == ADD_LSHL_U32) { CH8(S_ADDLSHL) }
             else if (kOp == BFE_I32) { CH8(S_BFEI) }
             else if (kOp == ALIGNBIT) { CH8(S_ALIGN) }
+            else if (kOp == SAD_HI_U8) { CH8(S_SADHI) }
+            else if (kOp == SAD_U16) { CH8(S_SAD16) }
+            else if (kOp == SAD_U32) { CH8(S_SAD32) }
+            else if (kOp == MSAD_U8) { CH8(S_MSAD) }
+            else if (kOp == QSAD_PK) { S_QSAD(p0) S_QSAD(p1) S_QSAD(p2) S_QSAD(p3) S_QSAD(p4) S_QSAD(p5) S_QSAD(p6) S_QSAD(p7) }
+            else if (kOp == MQSAD_PK) { S_MQSADPK(p0) S_MQSADPK(p1) S_MQSADPK(p2) S_MQSADPK(p3) S_MQSADPK(p4) S_MQSADPK(p5) S_MQSADPK(p6) S_MQSADPK(p7) }
+            else if (kOp == MQSAD_U32) { S_MQSAD32(q0, p0) S_MQSAD32(q1, p1) S_MQSAD32(q2, p2) S_MQSAD32(q3, p3) S_MQSAD32(q0, p4) S_MQSAD32(q1, p5) S_MQSAD32(q2, p6) S_MQSAD32(q3, p7) }
+            else if (kOp == SUB_SDWA) { CH8(S_SUBSDWA) }
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
     uint32_t acc = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
     acc += (uint32_t)(p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7);
+    acc += q0.x + q1.y + q2.z + q3.w;
     out[blockIdx.x * 256 + threadIdx.x] = acc;
     if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -172,7 +193,7 @@ void sweep(int clk_khz) {
     for (int w : {1, 2, 4, 8}) run<kOp>(w, clk_khz);
 }
 
-int main() {
+int main(int argc, char** argv) {
     int clk_khz = 0;
     hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0);
     hipDeviceProp_t p;
@@ -180,6 +201,20 @@ int main() {
     printf("# %s, %d CUs, clock attribute %d MHz; cyc = launch time x clock / (wave-instructions per SIMD)\n", p.gcnArchName,
            p.multiProcessorCount, clk_khz / 1000);
     printf("# a dependent-free stream of one opcode; w/SIMD = resident waves per SIMD (grid = 256 x w blocks of 256)\n");
+    if (argc > 1 && !strcmp(argv[1], "sad")) {
+        // round 4: the SAD family (the quad forms slide a 4-byte window over 8 bytes: four SADs per instruction)
+        sweep<SAD_U8>(clk_khz);
+        sweep<SAD_HI_U8>(clk_khz);
+        sweep<SAD_U16>(clk_khz);
+        sweep<SAD_U32>(clk_khz);
+        sweep<MSAD_U8>(clk_khz);
+        sweep<QSAD_PK>(clk_khz);
+        sweep<MQSAD_PK>(clk_khz);
+        sweep<MQSAD_U32>(clk_khz);
+        sweep<SUB_SDWA>(clk_khz);
+        sweep<SUB_U32>(clk_khz);
+        return 0;
+    }
     sweep<FMA_F32>(clk_khz);
     sweep<PK_FMA_F32>(clk_khz);
     sweep<ADD_U32>(clk_khz);
