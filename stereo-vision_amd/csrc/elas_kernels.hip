@@ -75,6 +75,15 @@ __device__ __forceinline__ uint32_t sad16_acc(const uint4& a, const uint4& b, ui
     return s;
 }
 
+// (SAD << 16) accumulated on top of k: the chain that builds a  cost << 16 | rank  key in place (v_sad_hi_u8)
+__device__ __forceinline__ int sad_hi16(const uint4& a, const uint4& b, uint32_t k) {
+    k = __builtin_amdgcn_sad_hi_u8(a.x, b.x, k);
+    k = __builtin_amdgcn_sad_hi_u8(a.y, b.y, k);
+    k = __builtin_amdgcn_sad_hi_u8(a.z, b.z, k);
+    k = __builtin_amdgcn_sad_hi_u8(a.w, b.w, k);
+    return (int)k;
+}
+
 // best / second best update: best2 = median(best1, best2, key), best1 = min(best1, key)
 // (the strict-"<" chain of elas.cpp:419-427 on keys E<<16|d, two VALU ops)
 __device__ __forceinline__ void keep_two(uint32_t key, uint32_t& best1, uint32_t& best2) {
@@ -364,11 +373,13 @@ __device__ __forceinline__ int support_match_rows(const StripView& own, const St
         const int d = d0 + off;
         if (d <= dm) {
             const int uw = right ? u + d : u - d;
-            uint32_t e = sad16(r0, oth.at(0, uw - 2));
-            e = sad16_acc(r1, oth.at(0, uw + 2), e);
-            e = sad16_acc(r2, oth.at(1, uw - 2), e);
-            e = sad16_acc(r3, oth.at(1, uw + 2), e);
-            keep_two((e << 16) | (uint32_t)d, best1, best2);
+            // v_sad_hi_u8 accumulates (SAD << 16) on top of its third operand: a chain started on d IS the
+            // key  E << 16 | d  (E <= 64 * 255), no shift-or afterwards
+            uint32_t key = (uint32_t)sad_hi16(r0, oth.at(0, uw - 2), (uint32_t)d);
+            key = (uint32_t)sad_hi16(r1, oth.at(0, uw + 2), key);
+            key = (uint32_t)sad_hi16(r2, oth.at(1, uw - 2), key);
+            key = (uint32_t)sad_hi16(r3, oth.at(1, uw + 2), key);
+            keep_two(key, best1, best2);
         }
     }
     const uint32_t m1 = row_min_u32(best1);
@@ -1142,13 +1153,6 @@ __device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
 __device__ __forceinline__ uint32_t lds_read2(uint32_t addr) {
     return *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)addr;
 }
-__device__ __forceinline__ int sad_hi16(const uint4& a, const uint4& b, uint32_t k) {
-    k = __builtin_amdgcn_sad_hi_u8(a.x, b.x, k);
-    k = __builtin_amdgcn_sad_hi_u8(a.y, b.y, k);
-    k = __builtin_amdgcn_sad_hi_u8(a.z, b.z, k);
-    k = __builtin_amdgcn_sad_hi_u8(a.w, b.w, k);
-    return (int)k;
-}
 __device__ __forceinline__ int min3i(int a, int b, int c) {
     const int m = b < c ? b : c;
     return a < m ? a : m;
@@ -1412,8 +1416,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(kIters <= 5
     for (int k = 0; k < kIters; k++) {
         const int u = x0 + k * half;
         const float4 pl = pl_next;
-        if (k + 1 < kIters)
+        if (k + 1 < kIters) {
             pl_next = *reinterpret_cast<const float4*>(G.raster + (tk[k + 1] >= 0 ? (uint32_t)(tri0 + tk[k + 1]) : 0u));
+            asm volatile("" ::: "memory");   // the request goes out HERE (hipcc would sink it to its use, a pixel later)
+        }
         if (u < P.DW) {
             int res = -10;
             const uint4 own = lds_read16(own_base + (uint32_t)(u < P.W ? u : 0) * 16u);
