@@ -1261,7 +1261,11 @@ static bool dt_big_lds_ok() {
 }
 static size_t dt_lds_bytes(const svh_elas_params& p, const Dims& d, bool big) {
     const size_t hist = 4 * (size_t)(2 * (dt_columns(p, d) + d.H) + 2);
-    return big ? std::max<size_t>(hist, 159 * 1024) : std::max<size_t>(hist, 63 * 1024);
+    // KITTI-size lattices: 54 KB (1 973 points per side in LDS; the crops have <= 1 761) instead of the 63 KB the
+    // kernel could take: a CU that hosts one triangulation then still fits TWO 52 KB blocks of k_match_list beside
+    // it instead of one (pipelined bench 33.2-33.4 -> 33.4-33.7 k pairs/s; 48 KB spills records to L2: 31.6-32.1 k)
+    static const size_t small_kb = getenv("SVH_DT_LDS_KB") ? (size_t)atoi(getenv("SVH_DT_LDS_KB")) : 54;
+    return big ? std::max<size_t>(hist, 159 * 1024) : std::max<size_t>(hist, std::min<size_t>(63, std::max<size_t>(small_kb, 8)) * 1024);
 }
 
 bool stage_device_ok(const svh_elas_params& p, const Dims& d) {
