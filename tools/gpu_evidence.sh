@@ -1,35 +1,39 @@
 #!/bin/bash
 # Round evidence on the GPU box for the CURRENT build -> gpurun_out/evidence/ (copy what is to be
-# judged into profiles/):
-#   bench lines (driver command; 2 ranks sharing the GPU over gloo; hd1080; sequence)
+# judged into profiles/ under the round's prefix):
+#   PMC passes first (SQ issue counters, FETCH_SIZE / WRITE_SIZE; counters only, separate runs): bench.py
+#   quotes them only when their build stamp is the loaded library's
+#   bench lines: the driver's command; batch vs stream on the sequence and 1920x1080 workloads; 2 ranks
+#   sharing the GPU over gloo; the RCCL branch with one rank; a soak run
 #   rocprofv3 --kernel-trace --stats summaries of the same commands and of the secondary legs
-#   PMC passes (SQ issue counters, FETCH_SIZE / WRITE_SIZE) -- counters only, separate runs
+ulimit -c 0
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/evidence
+ROUND=${ROUND:-r04}
 mkdir -p $O
-# PMC passes first: bench.py quotes the summaries (measured HBM traffic, VALU counts) only when their
-# build stamp is the loaded library's, so they must be in profiles/ before the bench lines are taken
-GRAFT_REPO_ROOT=$R bash $R/tools/gpu_pmc_all.sh > $O/pmc_summary.txt 2>&1
+GRAFT_REPO_ROOT=$R timeout 600 bash $R/tools/gpu_pmc_all.sh > $O/pmc_summary.txt 2>&1
 cp $R/gpurun_out/pmc_issue.json $R/gpurun_out/pmc_traffic.json $O/
-ROUND=${ROUND:-r03}
 cp $R/gpurun_out/pmc_issue.json $R/profiles/${ROUND}_pmc_issue.json
 cp $R/gpurun_out/pmc_traffic.json $R/profiles/${ROUND}_pmc_traffic.json
 cd $R
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err
-timeout 600 python bench.py --gpus 2 --steps 10 --warmup 2 --dist-backend gloo --no-extras --no-cpu-baseline > $O/bench_line_2ranks_gloo_1gpu.json 2> /dev/null
-# hd1080 = configs[3]: the batch of 64 pairs on this one GPU (the default); then the share of one GPU of
-# eight (8 pairs per step: latency-bound) on the host stage (automatic there) and on the device stage
-timeout 600 python bench.py --workload hd1080 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_hd1080.json 2> /dev/null
-timeout 600 python bench.py --workload hd1080 --batch 8 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_b8.json 2> /dev/null
-timeout 600 python bench.py --workload hd1080 --batch 8 --stage device --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_b8_device_stage.json 2> /dev/null
-timeout 600 python bench.py --workload hd1080 --batch 256 --group 16 --lanes 6 --steps 8 --warmup 2 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_x256.json 2> /dev/null
-timeout 600 python bench.py --workload hd1080 --stage host --batch 64 --group 4 --lanes 8 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_hd1080_x64_host_stage.json 2> /dev/null
-timeout 600 python bench.py --lanes 3 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_lanes3.json 2> /dev/null
-timeout 600 python bench.py --lanes 6 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_lanes6.json 2> /dev/null
-timeout 600 python bench.py --steps 8 --warmup 2 --no-extras --no-cpu-baseline --soak 60 > $O/bench_line_soak60.json 2> /dev/null
-timeout 600 python bench.py --force-dist --dist-backend nccl --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/bench_line_1rank_nccl.json 2> $O/bench_line_1rank_nccl.err
-timeout 600 python bench.py --workload sequence --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_line_sequence.json 2> /dev/null
+b() { name=$1; shift; timeout 600 python bench.py "$@" > $O/bench_line$name.json 2> $O/bench_line$name.err; }
+b "" --gpus 1 --steps 20 --warmup 5
+Q="--no-extras --no-cpu-baseline"
+b _kitti_stream $Q --steps 10 --warmup 3 --api stream
+b _keyed_matcher $Q --steps 10 --warmup 3
+b _sequence $Q --workload sequence --steps 30 --warmup 5
+b _sequence_batch_api $Q --workload sequence --steps 30 --warmup 5 --api batch
+b _hd1080 $Q --workload hd1080 --steps 20 --warmup 3
+b _hd1080_batch_api $Q --workload hd1080 --steps 20 --warmup 3 --api batch
+b _hd1080_b8 $Q --workload hd1080 --batch 8 --steps 400 --warmup 20
+b _hd1080_b8_batch_api_device_stage $Q --workload hd1080 --batch 8 --steps 100 --warmup 10 --api batch --stage device
+b _hd1080_x256 $Q --workload hd1080 --batch 256 --group 16 --lanes 6 --steps 8 --warmup 2
+b _2ranks_gloo_1gpu $Q --gpus 2 --steps 10 --warmup 2 --dist-backend gloo
+b _1rank_nccl $Q --force-dist --dist-backend nccl --steps 10 --warmup 3
+b _soak60 $Q --steps 8 --warmup 2 --soak 60
+SVH_MATCH_LIST=0 timeout 300 python bench.py $Q --steps 10 --warmup 3 > $O/bench_line_keyed_matcher.json 2> /dev/null
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 cd /tmp
 kt() {  # name cmd...
   local name=$1; shift
@@ -41,21 +45,17 @@ kt() {  # name cmd...
   [ -n "$DB" ] && python $R/tools/rocpd_summary.py $DB > $O/kernel_stats_$name.txt
 }
 kt kitti python $R/bench.py --no-extras --no-cpu-baseline --steps 12 --warmup 3
-kt hd1080 python $R/bench.py --workload hd1080 --no-extras --no-cpu-baseline --steps 8 --warmup 3
-kt hd1080_b8 python $R/bench.py --workload hd1080 --batch 8 --no-extras --no-cpu-baseline --steps 20 --warmup 5
-kt sequence python $R/bench.py --workload sequence --no-extras --no-cpu-baseline --steps 12 --warmup 3
+kt hd1080 python $R/bench.py --workload hd1080 --no-extras --no-cpu-baseline --steps 20 --warmup 3
+kt hd1080_b8 python $R/bench.py --workload hd1080 --batch 8 --no-extras --no-cpu-baseline --steps 200 --warmup 10
+kt sequence python $R/bench.py --workload sequence --no-extras --no-cpu-baseline --steps 20 --warmup 3
 kt matcher python $R/tools/gpu_legs.py matcher
 kt vo python $R/tools/gpu_legs.py vo
-kt map python $R/tools/gpu_legs.py map
-kt vo_replicas16 python $R/tools/gpu_legs.py replicas16
-ls -la $O | tail -20
 python - <<PY
-import json
-for f in ("bench_line","bench_line_2ranks_gloo_1gpu","bench_line_hd1080","bench_line_hd1080_b8","bench_line_hd1080_b8_device_stage","bench_line_hd1080_x256","bench_line_hd1080_x64_host_stage","bench_line_sequence","bench_line_lanes3","bench_line_lanes6","bench_line_soak60","bench_line_1rank_nccl"):
+import json, glob, os
+for f in sorted(glob.glob("$O/bench_line*.json")):
     try:
-        d=json.loads([l for l in open("$O/%s.json"%f) if l.startswith("{")][-1])
-        print(f, round(d["value"]), "n_gpus", d["n_gpus"], "cores", d["config"]["host_cores_used"], d["roofline"]["kernel"], round(d["roofline"]["frac"],3), d.get("outputs_match_golden"), d["config"].get("stage_groups_device_handed_back"))
-    except Exception as e: print(f, "ERR", e)
+        d=json.loads([l for l in open(f) if l.startswith("{")][-1]); r=d["roofline"]
+        print(os.path.basename(f), round(d["value"]), "n_gpus", d["n_gpus"], "api", d["config"].get("api"), "cores", d["config"]["host_cores_used"], r["kernel"], "frac", round(r["frac"],3), "bound", r["bound"], "iso_us", round(r["avg_launch_us"],1), "golden", d.get("outputs_match_golden"), "oracle", d.get("outputs_match_oracle"))
+    except Exception as e: print(os.path.basename(f), "ERR", e)
 PY
-GRAFT_REPO_ROOT=$R bash $R/tools/gpu_pmc_all.sh _hd1080 --workload hd1080 > $O/pmc_summary_hd1080.txt 2>&1
-cp $R/gpurun_out/pmc_issue_hd1080.json $R/gpurun_out/pmc_traffic_hd1080.json $O/
+cat $O/smoke.txt | tail -2
