@@ -247,7 +247,7 @@ struct Lane {
         const size_t gw_bytes = G2 * d.gw * d.gh * d.gwords * sizeof(uint32_t);
         HIP_TRY(hipMalloc(&seed, gw_bytes));
         HIP_TRY(hipMalloc(&mask, gw_bytes));
-        if (d.gwords == 8) HIP_TRY(hipMalloc(&lists, G2 * d.gw * d.gh * 32 * sizeof(uint16_t)));
+        if (d.gwords <= 8) HIP_TRY(hipMalloc(&lists, G2 * d.gw * d.gh * 32 * sizeof(uint16_t)));
         hp.resize(g);
         // fixed layout of the packed lists when the device builds them
         o_P = (sizeof(GroupHdr) + 63) & ~(size_t)63;

@@ -690,16 +690,16 @@ __global__ __launch_bounds__(256) void k_grid_dilate(GroupDev G, int slots, int 
     G.mask[i] = o;
 }
 
-// Candidate records for k_match_list (disp_max <= 255): one wave per cell turns the cell's 256-bit set into
+// Candidate records for k_match_list (disp_max <= 255): one wave per cell turns the cell's bit set (up to 256 bits) into
 // ML_CAP = 32 uint16: [0..27] the candidates, ascending, as 16 * d (the byte offset of the candidate in a
 // descriptor row), padded with the last one; [28..30] the last candidate; [31] their number.  Cells with more
 // than 28 candidates are decoded from the bit set by the matcher itself.
-__global__ __launch_bounds__(256) void k_grid_list(GroupDev G, int ncells) {
+__global__ __launch_bounds__(256) void k_grid_list(GroupDev G, int ncells, int gwords) {
     const int lane = threadIdx.x & 63;
     const int cell = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
     if (cell >= ncells) return;
-    const uint32_t* bits = G.mask + (size_t)cell * 8;
-    const uint32_t wq = lane < 8 ? bits[lane] : 0u;
+    const uint32_t* bits = G.mask + (size_t)cell * gwords;     // gwords <= 8 (disp_max <= 255)
+    const uint32_t wq = lane < gwords ? bits[lane] : 0u;
     uint16_t* rec = G.lists + (size_t)cell * 32;
     int n = 0, last = 0;
 #pragma unroll
@@ -1317,7 +1317,7 @@ __device__ __forceinline__ int ml_pixel_checked(const uint4& own, const PixelPla
     } else {
         // a cell of the wave holds more candidates than a record: every lane decodes its cell's bit set
 #pragma unroll 1
-        for (int w = 0; w < 8; w++) {
+        for (int w = 0; w < P.gwords; w++) {
             uint32_t b = bits[w];
             while (b) {
                 const int dc = w * 32 + __builtin_ctz(b);
@@ -2138,8 +2138,9 @@ void launch_prior(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
                d.gw, d.gh, d.gwords, p.grid_size, p.disp_max);
     LAUNCH("k_grid_dilate", k_grid_dilate, dim3((unsigned)((words + 255) / 256)), dim3(256), G,
            2 * g, d.gw, d.gh, d.gwords);
-    if (d.gwords == 8 && G.lists)
-        LAUNCH("k_grid_list", k_grid_list, dim3((unsigned)((2 * g * cells + 3) / 4)), dim3(256), G, 2 * g * cells);
+    if (d.gwords <= 8 && G.lists)
+        LAUNCH("k_grid_list", k_grid_list, dim3((unsigned)((2 * g * cells + 3) / 4)), dim3(256), G, 2 * g * cells,
+               d.gwords);
 }
 
 void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
@@ -2189,7 +2190,7 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     }
     // round 4: the list form of the keyed kernel (per-cell candidate records, v_sad_hi_u8 keys, LDS-DMA staging)
     static const bool list_off = getenv("SVH_MATCH_LIST") && atoi(getenv("SVH_MATCH_LIST")) == 0;
-    if (keyed_ok && !list_off && !p.subsampling && d.gwords == 8 && G.lists && G.prior_absmax < 28000 &&
+    if (keyed_ok && !list_off && !p.subsampling && d.gwords <= 8 && G.lists && G.prior_absmax < 28000 &&
         d.DW <= 8 * 256) {
         MatchList Q;
         Q.Wr = (d.W + 7) / 8 * 8;
