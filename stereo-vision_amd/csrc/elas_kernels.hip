@@ -75,6 +75,26 @@ __device__ __forceinline__ uint32_t sad16_acc(const uint4& a, const uint4& b, ui
     return s;
 }
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+// LDS accesses by absolute byte address: keeps the per-candidate arithmetic at one v_sub / v_add
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
+    const u32x4_t q = *(__attribute__((address_space(3))) const u32x4_t*)(uintptr_t)addr;
+    return make_uint4(q.x, q.y, q.z, q.w);
+}
+__device__ __forceinline__ uint2 lds_read8(uint32_t addr) {
+    const u32x2_t q = *(__attribute__((address_space(3))) const u32x2_t*)(uintptr_t)addr;
+    return make_uint2(q.x, q.y);
+}
+__device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
+    return *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)addr;
+}
+__device__ __forceinline__ uint32_t lds_read2(uint32_t addr) {
+    return *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)addr;
+}
 // (SAD << 16) accumulated on top of k: the chain that builds a  cost << 16 | rank  key in place (v_sad_hi_u8)
 __device__ __forceinline__ int sad_hi16(const uint4& a, const uint4& b, uint32_t k) {
     k = __builtin_amdgcn_sad_hi_u8(a.x, b.x, k);
@@ -369,24 +389,56 @@ __device__ __forceinline__ int support_match_rows(const StripView& own, const St
     const int so = (act ? u : 0) - oth.x0;   // slot of disparity 0 (the +-2 offsets are constants)
     const int off = right ? (gl - so - dmin) & 15 : (so - gl - dmin) & 15;
     uint32_t best1 = 0xFFFFFFFFu, best2 = 0xFFFFFFFFu;
-    for (int d0 = dmin; d0 <= top; d0 += 16) {
-        const int d = d0 + off;
-        if (d <= dm) {
-            const int uw = right ? u + d : u - d;
-            // v_sad_hi_u8 accumulates (SAD << 16) on top of its third operand: a chain started on d IS the
-            // key  E << 16 | d  (E <= 64 * 255), no shift-or afterwards
-            uint32_t key = (uint32_t)sad_hi16(r0, oth.at(0, uw - 2), (uint32_t)d);
-            key = (uint32_t)sad_hi16(r1, oth.at(0, uw + 2), key);
-            key = (uint32_t)sad_hi16(r2, oth.at(1, uw - 2), key);
-            key = (uint32_t)sad_hi16(r3, oth.at(1, uw + 2), key);
-            keep_two(key, best1, best2);
-        }
+    // Trip t evaluates d = dmin + 16 t + off.  The trips are taken in the order in which the LDS addresses RISE
+    // (forward search: slot u - d, so t descends; backward: slot u + d, t ascends): four consecutive trips then
+    // read at constant offsets k * 256 from two address registers (rows v-2 and v+2), and the trips in which every
+    // lane of the wave is inside its range run without the per-trip range test (round 4: 24 -> ~20 operations per
+    // trip).  Keys E << 16 | d make the minimum independent of the order.
+    const int T = (top - dmin) / 16 + 1;                                   // trips of the wave (uniform)
+    const int tl = act ? (dm - dmin - off >= 0 ? (dm - dmin - off) >> 4 : -1) : T - 1;   // last trip this lane is inside its range
+    // j = position in evaluation order: t = right ? j : T - 1 - j.  A lane is valid for j <= tl (right) / j >= T-1-tl
+    const int jl = right ? tl : T - 1 - tl;
+    // uniform split: right: j in [0, jmin] unmasked, then (jmin, T) masked; forward: j in [0, jmax) masked, then [jmax, T)
+    const uint32_t red = wave_min_u32(right ? (uint32_t)(jl + 1) : (uint32_t)(T - jl));   // both >= 0
+    const int jsplit = right ? (int)red - 1 : T - (int)red;             // right: jmin; forward: jmax
+    const uint32_t oth_addr = lds_addr_of(oth.base);
+    const int d_first = right ? dmin + off : dmin + 16 * (T - 1) + off;   // disparity of j = 0
+    const int uw_first = right ? (act ? u : oth.x0 + 2) + d_first : (act ? u - d_first : oth.x0 + 2);
+    uint32_t a0 = oth_addr + (uint32_t)(uw_first - 2 - oth.x0) * 16u;      // (row 0, uw - 2) of j = 0; + 256 per trip
+    const uint32_t row1 = (uint32_t)oth.w * 16u;
+    int d = d_first;
+    auto trip = [&](uint32_t addr0, uint32_t addr1, int dd) {
+        uint32_t key = (uint32_t)sad_hi16(r0, lds_read16(addr0), (uint32_t)dd);
+        key = (uint32_t)sad_hi16(r1, lds_read16(addr0 + 64u), key);
+        key = (uint32_t)sad_hi16(r2, lds_read16(addr1), key);
+        key = (uint32_t)sad_hi16(r3, lds_read16(addr1 + 64u), key);
+        keep_two(key, best1, best2);
+    };
+    const int dstep = right ? 16 : -16;
+    int j = 0;
+    if (!right) {   // masked head: trips some lanes are outside of
+        for (; j < jsplit; j++, a0 += 256u, d += dstep)
+            if (j >= jl) trip(a0, a0 + row1, d);
+    }
+    const int jend = right ? jsplit + 1 : T;
+    for (; j + 4 <= jend; j += 4, a0 += 1024u, d += 4 * dstep) {
+        const uint32_t a1 = a0 + row1;
+        trip(a0, a1, d);
+        trip(a0 + 256u, a1 + 256u, d + dstep);
+        trip(a0 + 512u, a1 + 512u, d + 2 * dstep);
+        trip(a0 + 768u, a1 + 768u, d + 3 * dstep);
+    }
+    for (; j < jend; j++, a0 += 256u, d += dstep) trip(a0, a0 + row1, d);
+    if (right) {    // masked tail
+        for (; j < T; j++, a0 += 256u, d += dstep)
+            if (j <= jl) trip(a0, a0 + row1, d);
     }
     const uint32_t m1 = row_min_u32(best1);
     const uint32_t m2 = row_min_u32(best1 == m1 ? best2 : best1);
     const float e1 = (float)(m1 >> 16), e2 = (float)(m2 >> 16);
     const bool good = m1 != 0xFFFFFFFFu && m2 != 0xFFFFFFFFu && e1 < __fmul_rn(P.support_threshold, e2);
-    return good ? (int)(m1 & 0xFFFFu) : -1;
+    // (rows that take no part -- no texture, range too short -- ran the unmasked trips on a dummy slot: no result)
+    return act && good ? (int)(m1 & 0xFFFFu) : -1;
 }
 
 template <int kSB, int kST>
@@ -1133,26 +1185,6 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P, 
 constexpr int ML_CAP = 32;     // uint16 per cell record: [0..27] candidates, [28..30] last candidate, [31] count
 constexpr int ML_FAST = 28;    // cells with more candidates are decoded from their bit set
 
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-// LDS accesses by absolute byte address: keeps the per-candidate arithmetic at one v_sub / v_add
-__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
-__device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
-    const u32x4_t q = *(__attribute__((address_space(3))) const u32x4_t*)(uintptr_t)addr;
-    return make_uint4(q.x, q.y, q.z, q.w);
-}
-__device__ __forceinline__ uint2 lds_read8(uint32_t addr) {
-    const u32x2_t q = *(__attribute__((address_space(3))) const u32x2_t*)(uintptr_t)addr;
-    return make_uint2(q.x, q.y);
-}
-__device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
-    return *(__attribute__((address_space(3))) const uint32_t*)(uintptr_t)addr;
-}
-__device__ __forceinline__ uint32_t lds_read2(uint32_t addr) {
-    return *(__attribute__((address_space(3))) const uint16_t*)(uintptr_t)addr;
-}
 __device__ __forceinline__ int min3i(int a, int b, int c) {
     const int m = b < c ? b : c;
     return a < m ? a : m;
