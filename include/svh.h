@@ -295,6 +295,17 @@ int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* 
 /* Matcher::matchFeatures(method, Tr_delta) -- matcher.cpp:209-293.  method 0 flow,
  * 1 stereo, 2 quad.  Tr_delta: 16 doubles row-major (4x4) or NULL.               */
 int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double* Tr_delta);
+/* One frame of K sequences: the two calls above for K Matchers in lockstep (same parameters and image size).
+ * The device work of all K objects is ONE launch per kernel (blockIdx.z = object), the per-object host steps
+ * (row packing, outlier votes, prior statistics) run on helper threads.  Results per object are exactly those of
+ * K separate calls; objects that cannot run in lockstep (different parameters, taps on) are run one by one.
+ * I1 / I2 / Tr_delta: K pointers each (I2, Tr_delta and their entries may be NULL as in the single calls).
+ * The reference has no batched form: this is the multi-sequence counterpart of demo.cpp's frame loop
+ * (viso_stereo.cpp:41-68 per object). */
+int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uint8_t* const* I1,
+                                    const uint8_t* const* I2, const int32_t* dims, int32_t replace);
+int32_t svh_matcher_match_features_batch(svh_matcher* const* ms, int32_t K, int32_t method,
+                                         const double* const* Tr_delta);
 /* Matcher::bucketFeatures -- matcher.cpp:297-343 (std::random_shuffle on the host) */
 int32_t svh_matcher_bucket_features(svh_matcher* m, int32_t max_features, float bucket_width,
                                     float bucket_height);
@@ -353,6 +364,13 @@ void    svh_vo_destroy(svh_vo* v);
  * returns 1 (true), 0 (false: motion estimate failed) or a negative SVH_ERR_* */
 int32_t svh_vo_process(svh_vo* v, const uint8_t* I1, const uint8_t* I2, const int32_t* dims,
                        int32_t replace);
+/* svh_vo_process for K objects in lockstep (one frame of K sequences): batched Matcher steps, the K motion
+ * estimates in two launches.  libc rand() is drawn in the order of K svh_vo_process calls, so with the same
+ * srand() the results are bit-identical to that loop.  ok[i] (optional) receives the per-object return value;
+ * the call returns the number of objects whose motion was updated, or a negative SVH_ERR_*.  Objects that are
+ * still bootstrapping (viso_stereo.cpp:47-53) or differ in parameters are processed one after the other. */
+int32_t svh_vo_process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const* I1, const uint8_t* const* I2,
+                             const int32_t* dims, int32_t replace, int32_t* ok);
 /* bool VisualOdometry::process(p_matched) -- viso.h:87-91: motion from given matches */
 int32_t svh_vo_process_matches(svh_vo* v, const svh_p_match* matches, int32_t n);
 /* vector<double> estimateMotion(p_matched) -- viso_stereo.cpp:72-228 (RANSAC + Gauss-Newton on

@@ -24,10 +24,15 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <deque>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include "batch_rec.h"
 #include "matcher_internal.h"
 #include "vo_internal.h"
 
@@ -61,6 +66,137 @@ int wait_stream(void* stream) {
         std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
 }
+
+// ---------------------------------------------------------------------------
+// batch recorder (batch_rec.h) and the host-side helpers of the batched entries
+// ---------------------------------------------------------------------------
+thread_local BatchRec* t_rec = nullptr;
+
+hipError_t BatchRec::flush(hipStream_t s) {
+    cursor = 0;
+    if (slots.empty()) return hipSuccess;
+    auto al = [](size_t n) { return (n + 255) & ~(size_t)255; };
+    size_t need = 0;
+    for (const Slot& sl : slots) need += al(sl.jobs.size());
+    if (used + need > cap) {
+        // the arena may still be read by launches in flight: wait, then grow
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return e;
+        release();
+        cap = std::max<size_t>(2 * (used + need), 256 * 1024);
+        e = hipHostMalloc((void**)&h_arena, cap);
+        if (e != hipSuccess) return e;
+        e = hipMalloc((void**)&d_arena, cap);
+        if (e != hipSuccess) return e;
+        used = 0;
+    }
+    size_t off = used;
+    std::vector<size_t> at;
+    for (const Slot& sl : slots) {
+        memcpy(h_arena + off, sl.jobs.data(), sl.jobs.size());
+        at.push_back(off);
+        off += al(sl.jobs.size());
+    }
+    hipError_t e = hipMemcpyAsync(d_arena + used, h_arena + used, need, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    for (size_t i = 0; i < slots.size(); i++) {
+        const Slot& sl = slots[i];
+        if (sl.njobs > 0) sl.fn(d_arena + at[i], sl.njobs, sl.gx, sl.gy, sl.lds, s);
+    }
+    used += need;
+    slots.clear();
+    return hipGetLastError();
+}
+
+void BatchRec::release() {
+    (void)hipHostFree(h_arena);
+    (void)hipFree(d_arena);
+    h_arena = d_arena = nullptr;
+    cap = 0;
+}
+
+// the calling thread's recorder (its arena lives as long as the thread)
+BatchRec& batch_recorder() {
+    static thread_local BatchRec rec;
+    return rec;
+}
+
+// Parked helper threads for the per-object HOST work of a batch call (outlier votes, prior statistics):
+// parallel_for(n, fn) runs fn(0..n-1) on the helpers and the caller, returns when all are done.
+namespace {
+class BatchPool {
+public:
+    void parallel_for(int n, const std::function<void(int)>& fn) {
+        if (n <= 1) {
+            for (int i = 0; i < n; i++) fn(i);
+            return;
+        }
+        std::lock_guard<std::mutex> one_call(call_mu_);   // batches of several caller threads take turns
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            const int want = std::min(n - 1, max_threads());
+            while ((int)threads_.size() < want) threads_.emplace_back(&BatchPool::run, this);
+            fn_ = &fn;
+            n_ = n;
+            next_ = 0;
+            done_ = 0;
+            gen_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return done_ == n_; });
+        fn_ = nullptr;
+    }
+    static BatchPool& get() {
+        static BatchPool* p = new BatchPool();   // leaked on purpose: its threads outlive static destruction
+        return *p;
+    }
+
+private:
+    static int max_threads() {
+        static const int n = std::max(1, std::min(15, (int)std::thread::hardware_concurrency() - 1));
+        return n;
+    }
+    void work() {
+        for (;;) {
+            int i;
+            const std::function<void(int)>* fn;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!fn_ || next_ >= n_) return;
+                i = next_++;
+                fn = fn_;
+            }
+            (*fn)(i);
+            bool last;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                last = ++done_ == n_;
+            }
+            if (last) cv_done_.notify_all();
+        }
+    }
+    void run() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::mutex mu_, call_mu_;
+    std::condition_variable cv_, cv_done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int n_ = 0, next_ = 0, done_ = 0;
+    uint64_t gen_ = 0;
+};
+thread_local bool t_in_batch = false;   // inside a batch call: the outlier vote does not fork (the pool is the parallelism)
+}  // namespace
 
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
@@ -137,6 +273,8 @@ struct svh_matcher {
     size_t owner_cap = 0;
     float* ranges_dev = nullptr;
     int32_t ranges_cap = 0;
+    float* h_ranges = nullptr;                  // pinned copy of `ranges` (batched calls upload it from a kernel)
+    size_t h_ranges_cap = 0;
     uint8_t* h_stage[2] = {nullptr, nullptr};   // pinned upload staging, one per camera
     size_t h_stage_cap[2] = {0, 0};
     svh_p_match* h_pm = nullptr;                // pinned download staging for match lists
@@ -226,9 +364,9 @@ static int ensure_scratch(svh_matcher* m, int32_t slot_need, int32_t pm_need, si
     return SVH_OK;
 }
 
-// M1..M5  Matcher::computeFeatures   matcher.cpp:780-878
-static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* src, int32_t pitch) {
-    const svh_matcher_params& p = m->p;
+// M1..M5  Matcher::computeFeatures   matcher.cpp:780-878, in two steps: the host packs the rows, then the
+// device work is enqueued (or, in a batched call, recorded)
+static int features_pack(svh_matcher* m, DevView& V, int cam, const uint8_t* src, int32_t pitch) {
     hipStream_t s = cam == 1 ? m->stream2 : m->stream;
     const size_t fn = (size_t)V.bpl * V.h;
     if (fn > m->h_stage_cap[cam]) {
@@ -240,9 +378,6 @@ static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* 
     // rows are packed at the aligned pitch in pinned memory, then one linear DMA;
     // the previous pushBack ended with a stream sync, so the staging buffer is free
     uint8_t* stage = m->h_stage[cam];
-    double tf[6] = {0, 0, 0, 0, 0, 0};
-    auto ftick = [&](int i) { if (g_mtiming) tf[i] = mnow_ms(); };
-    ftick(0);
     // one zero row past the image: getGain clamps its window to [0,H] INCLUSIVE like the
     // reference (matcher.cpp:362-371), whose read of row H is out of bounds; here it reads zeros
     V.host.assign(fn + V.bpl, 0);
@@ -252,11 +387,20 @@ static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* 
         memset(row + V.w, 0, V.bpl - V.w);
     }
     memcpy(V.host.data(), stage, fn);
+    return SVH_OK;
+}
+
+static int features_enqueue(svh_matcher* m, DevView& V, int cam, double* tf) {
+    const svh_matcher_params& p = m->p;
+    hipStream_t s = cam == 1 ? m->stream2 : m->stream;
+    const size_t fn = (size_t)V.bpl * V.h;
+    const uint8_t* stage = m->h_stage[cam];
+    auto ftick = [&](int i) { if (g_mtiming && tf) tf[i] = mnow_ms(); };
     ftick(1);
     if (fn % 16 == 0)
         mlaunch_upload(s, stage, V.I, fn);
     else
-        HIP_TRY(hipMemcpyAsync(V.I, stage, fn, hipMemcpyHostToDevice, s));
+        mlaunch_copy(s, V.I, stage, fn, hipMemcpyHostToDevice);   // (bpl is a multiple of 16: not taken)
     ftick(2);
     const uint8_t* Im = V.I;
     if (p.half_resolution) {
@@ -275,19 +419,29 @@ static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* 
         mlaunch_features(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, ns, p.nms_tau, m->margin, scale,
                          m->slots[cam], m->flags[cam], m->order[cam], V.tab[0], V.cnt + 0);
     else
-        HIP_TRY(hipMemsetAsync(V.cnt, 0, sizeof(int32_t), s));
+        mlaunch_fill(s, V.cnt, 0, sizeof(int32_t));
     mlaunch_features(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, p.nms_n, p.nms_tau, m->margin, scale,
                      m->slots[cam], m->flags[cam], m->order[cam], V.tab[1], V.cnt + 1);
     ftick(4);
     // feature counts come back through pinned memory after BOTH cameras are enqueued
     // (a copy into pageable memory would block here until this camera's kernels finish)
-    HIP_TRY(hipMemcpyAsync(m->h_n + 2 * cam, V.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    mlaunch_copy(s, m->h_n + 2 * cam, V.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
     ftick(5);
-    if (g_mtiming)
-        for (int i = 0; i < 5; i++) m->tfine[i] += tf[i + 1] - tf[i];
     V.nbins = 0;   // bin indices are (re)built by matchFeatures for the current bin grid
     V.valid = true;
     return SVH_OK;   // the caller synchronises once after both cameras
+}
+
+static int compute_features(svh_matcher* m, DevView& V, int cam, const uint8_t* src, int32_t pitch) {
+    double tf[6] = {0, 0, 0, 0, 0, 0};
+    if (g_mtiming) tf[0] = mnow_ms();
+    int rc = features_pack(m, V, cam, src, pitch);
+    if (rc) return rc;
+    rc = features_enqueue(m, V, cam, tf);
+    if (rc) return rc;
+    if (g_mtiming)
+        for (int i = 0; i < 5; i++) m->tfine[i] += tf[i + 1] - tf[i];
+    return SVH_OK;
 }
 
 // (re)build the bin indices of every view whose tables changed since the last call: one launch
@@ -339,7 +493,7 @@ static int remove_outliers(const svh_matcher_params& p, std::vector<svh_p_match>
     static const int par = getenv("SVH_DELAUNAY_PAR") ? atoi(getenv("SVH_DELAUNAY_PAR")) : 2;
     // (several callers at once = several sequences on this GPU: their host threads already fill the
     // cores, the helper pool would only be fought over)
-    const bool alone = g_active_callers.load(std::memory_order_relaxed) <= 2;
+    const bool alone = g_active_callers.load(std::memory_order_relaxed) <= 2 && !t_in_batch;
     const int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 16, (n >= 1500 && alone) ? par : 0);
     if (nt < 0) return mfail(SVH_ERR_UNSUPPORTED, "outlier triangulation failed");
     std::vector<int32_t> votes(n, 0);
@@ -439,11 +593,16 @@ static SobelView sobel_of(const DevView& V, bool half) {
     return s;
 }
 
-// one matching() pass on the device; result copied to `out`
-static int run_matching(svh_matcher* m, int dense, int32_t method, bool use_prior, const double* Tr,
-                        std::vector<svh_p_match>& out, bool refine, std::vector<svh_p_match>* raw_tap) {
+// one matching() pass on the device, in steps a batched call can interleave over its objects:
+// match_enqueue -> [refine_enqueue] -> download_enqueue -> (stream wait) -> match_collect
+struct MatchPass {
+    int32_t nq = 0;
+    const svh_p_match* result = nullptr;
+    const int32_t* result_count = nullptr;
+};
+
+static int match_enqueue(svh_matcher* m, int dense, int32_t method, bool use_prior, const double* Tr, MatchPass& mp) {
     const svh_matcher_params& p = m->p;
-    hipStream_t s = m->stream;
     MatchParams P;
     memset(&P, 0, sizeof(P));
     P.method = method;
@@ -461,7 +620,7 @@ static int run_matching(svh_matcher* m, int dense, int32_t method, bool use_prio
     const int32_t nq = q.n[dense];
     int rc = ensure_scratch(m, 0, std::max(nq, 1), method < 2 ? (size_t)P.width * P.height : 0);
     if (rc) return rc;
-    mlaunch_match(s, P, view_of(m->prev[0], dense), view_of(m->prev[1], dense), view_of(m->cur[0], dense),
+    mlaunch_match(m->stream, P, view_of(m->prev[0], dense), view_of(m->prev[1], dense), view_of(m->cur[0], dense),
                   view_of(m->cur[1], dense), nq, m->ranges_dev, use_prior ? 1 : 0, m->pm_slots, m->pm_flags,
                   m->pixel_owner, m->pm_out, m->pm_count);
     if (nq > m->h_pm_cap || !m->h_cnt) {
@@ -470,33 +629,53 @@ static int run_matching(svh_matcher* m, int dense, int32_t method, bool use_prio
         if (!m->h_cnt) HIP_TRY(hipHostMalloc((void**)&m->h_cnt, sizeof(int32_t)));
         m->h_pm_cap = std::max(nq, 1);
     }
-    const svh_p_match* result = m->pm_out;
-    const int32_t* result_count = m->pm_count;
+    mp.nq = nq;
+    mp.result = m->pm_out;
+    mp.result_count = m->pm_count;
+    return SVH_OK;
+}
+
+static void refine_enqueue(svh_matcher* m, int32_t method, MatchPass& mp) {
+    const svh_matcher_params& p = m->p;
+    const bool half = p.half_resolution != 0;
+    const int parabolic = p.refinement == 2;
+    mlaunch_refine(m->stream, m->pm_out, m->pm_count, mp.nq, method, m->margin, sobel_of(m->prev[0], half),
+                   sobel_of(m->prev[1], half), sobel_of(m->cur[0], half), sobel_of(m->cur[1], half), parabolic,
+                   m->pm_flags, m->pm_slots, m->pm_count + 1);
+    if (parabolic) {
+        mp.result = m->pm_slots;
+        mp.result_count = m->pm_count + 1;
+    }
+}
+
+static void download_enqueue(svh_matcher* m, const MatchPass& mp) {
+    mlaunch_copy(m->stream, m->h_cnt, mp.result_count, sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (mp.nq > 0)
+        mlaunch_copy(m->stream, m->h_pm, mp.result, (size_t)mp.nq * sizeof(svh_p_match), hipMemcpyDeviceToHost);
+}
+
+static void match_collect(svh_matcher* m, const MatchPass& mp, std::vector<svh_p_match>& dst) {
+    const int32_t count = std::max(0, std::min(*m->h_cnt, mp.nq));
+    dst.assign(m->h_pm, m->h_pm + count);
+}
+
+static int run_matching(svh_matcher* m, int dense, int32_t method, bool use_prior, const double* Tr,
+                        std::vector<svh_p_match>& out, bool refine, std::vector<svh_p_match>* raw_tap) {
+    MatchPass mp;
+    int rc = match_enqueue(m, dense, method, use_prior, Tr, mp);
+    if (rc) return rc;
     auto download = [&](std::vector<svh_p_match>& dst) -> int {
-        HIP_TRY(hipMemcpyAsync(m->h_cnt, result_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        if (nq > 0)
-            HIP_TRY(hipMemcpyAsync(m->h_pm, result, (size_t)nq * sizeof(svh_p_match), hipMemcpyDeviceToHost, s));
-        HIP_TRY((hipError_t)wait_stream(s));
+        download_enqueue(m, mp);
+        HIP_TRY((hipError_t)wait_stream(m->stream));
         HIP_TRY(hipGetLastError());
-        const int32_t count = std::min(*m->h_cnt, nq);
-        dst.assign(m->h_pm, m->h_pm + count);
+        match_collect(m, mp, dst);
         return SVH_OK;
     };
     if (refine && raw_tap && m->taps) {
         rc = download(*raw_tap);
         if (rc) return rc;
     }
-    if (refine) {
-        const bool half = p.half_resolution != 0;
-        const int parabolic = p.refinement == 2;
-        mlaunch_refine(s, m->pm_out, m->pm_count, nq, method, m->margin, sobel_of(m->prev[0], half),
-                       sobel_of(m->prev[1], half), sobel_of(m->cur[0], half), sobel_of(m->cur[1], half),
-                       parabolic, m->pm_flags, m->pm_slots, m->pm_count + 1);
-        if (parabolic) {
-            result = m->pm_slots;
-            result_count = m->pm_count + 1;
-        }
-    }
+    if (refine) refine_enqueue(m, method, mp);
     rc = download(out);
     if (rc) return rc;
     if (!refine && raw_tap && m->taps) *raw_tap = out;
@@ -564,6 +743,7 @@ void svh_matcher_destroy(svh_matcher* m) {
         (void)hipFree(m->pixel_owner); (void)hipFree(m->ranges_dev); (void)hipHostFree(m->h_stage[0]);
         (void)hipHostFree(m->h_stage[1]); (void)hipHostFree(m->h_pm); (void)hipHostFree(m->h_cnt);
         (void)hipHostFree(m->h_n);
+        (void)hipHostFree(m->h_ranges);
         (void)hipStreamDestroy(m->stream);
         if (m->stream2) (void)hipStreamDestroy(m->stream2);
     }
@@ -575,9 +755,8 @@ void svh_matcher_set_intrinsics(svh_matcher* m, double f, double cu, double cv, 
     m->p.f = f; m->p.cu = cu; m->p.cv = cv; m->p.base = base;
 }
 
-int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* I2, const int32_t* dims,
-                              int32_t replace) {
-    svh::ActiveCaller active_;
+// pushBack up to the device work: argument checks, ring-buffer rotation, buffers.  `src` = the two rows of images
+static int32_t push_prepare(svh_matcher* m, const uint8_t* I1, const uint8_t* I2, const int32_t* dims, int32_t replace) {
     if (!m || !dims) return mfail(SVH_ERR_BAD_ARG, "null argument");
     const int32_t w = dims[0], h = dims[1], pitch = dims[2];
     if (w <= 0 || h <= 0 || pitch < w || I1 == 0) {
@@ -604,25 +783,42 @@ int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* 
     m->dims_c[0] = w;
     m->dims_c[1] = h;
     m->dims_c[2] = w + 16 - w % 16;   // +16 even when w % 16 == 0 (matcher.cpp:173)
-    const uint8_t* src[2] = {I1, I2};
     if (!m->h_n) HIP_TRY(hipHostMalloc((void**)&m->h_n, 4 * sizeof(int32_t)));
-    const double t0 = g_mtiming ? mnow_ms() : 0;
+    const uint8_t* src[2] = {I1, I2};
     for (int k = 0; k < 2; k++) {
         if (!src[k]) continue;
         int rc = ensure_view(m, m->cur[k], w, h, m->dims_c[2]);
         if (rc) return rc;
-        rc = compute_features(m, m->cur[k], k, src[k], pitch);
+    }
+    return SVH_OK;
+}
+
+static void push_finish(svh_matcher* m, const uint8_t* I1, const uint8_t* I2) {
+    const uint8_t* src[2] = {I1, I2};
+    for (int k = 0; k < 2; k++)
+        if (src[k]) {
+            m->cur[k].n[0] = m->h_n[2 * k];
+            m->cur[k].n[1] = m->h_n[2 * k + 1];
+        }
+}
+
+int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* I2, const int32_t* dims,
+                              int32_t replace) {
+    svh::ActiveCaller active_;
+    int32_t rc = push_prepare(m, I1, I2, dims, replace);
+    if (rc) return rc;
+    const uint8_t* src[2] = {I1, I2};
+    const double t0 = g_mtiming ? mnow_ms() : 0;
+    for (int k = 0; k < 2; k++) {
+        if (!src[k]) continue;
+        rc = compute_features(m, m->cur[k], k, src[k], dims[2]);
         if (rc) return rc;
     }
     const double t1 = g_mtiming ? mnow_ms() : 0;
     HIP_TRY((hipError_t)wait_stream(m->stream));
     HIP_TRY((hipError_t)wait_stream(m->stream2));
     HIP_TRY(hipGetLastError());
-    for (int k = 0; k < 2; k++)
-        if (src[k]) {
-            m->cur[k].n[0] = m->h_n[2 * k];
-            m->cur[k].n[1] = m->h_n[2 * k + 1];
-        }
+    push_finish(m, I1, I2);
     if (g_mtiming) {
         m->tacc[T_PACK] += t1 - t0;
         m->tacc[T_PUSH_GPU] += mnow_ms() - t1;
@@ -631,38 +827,122 @@ int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* 
     return SVH_OK;
 }
 
-int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double* Tr) {
+// K Matchers in lockstep (one frame of K sequences): the host packs the K x 2 images on the helper threads,
+// the device work of all K is recorded and issued as ONE launch per kernel (batch_rec.h) on ms[0]'s stream.
+// Results are those of K svh_matcher_push_back calls.  Objects must share parameters and image size;
+// otherwise (or with taps on) the call runs them one after the other.
+int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uint8_t* const* I1,
+                                    const uint8_t* const* I2, const int32_t* dims, int32_t replace) {
     svh::ActiveCaller active_;
-    if (!m) return mfail(SVH_ERR_BAD_ARG, "null argument");
+    if (!ms || K < 0 || !I1 || !dims) return mfail(SVH_ERR_BAD_ARG, "null argument");
+    if (K == 0) return SVH_OK;
+    bool lockstep = K > 1;
+    for (int i = 0; i < K && lockstep; i++) {
+        if (!ms[i]) return mfail(SVH_ERR_BAD_ARG, "null matcher in the batch");
+        for (int j = 0; j < i; j++)
+            if (ms[j] == ms[i]) return mfail(SVH_ERR_BAD_ARG, "the same matcher twice in one batch");
+        lockstep = memcmp(&ms[i]->p, &ms[0]->p, sizeof(ms[0]->p)) == 0 && !ms[i]->taps &&
+                   ms[i]->device == ms[0]->device && (!I2 || !I2[i]) == (!I2 || !I2[0]) && I1[i];
+    }
+    auto serial = [&]() -> int32_t {
+        for (int i = 0; i < K; i++) {
+            const int32_t rc = svh_matcher_push_back(ms[i], I1[i], I2 ? I2[i] : nullptr, dims, replace);
+            if (rc) return rc;
+        }
+        return SVH_OK;
+    };
+    if (!lockstep) return serial();
+    for (int i = 0; i < K; i++) {
+        const int32_t rc = push_prepare(ms[i], I1[i], I2 ? I2[i] : nullptr, dims, replace);
+        if (rc) return rc;
+    }
+    const int ncam = (I2 && I2[0]) ? 2 : 1;
+    std::vector<int> rcs((size_t)K * ncam, 0);
+    t_in_batch = true;
+    BatchPool::get().parallel_for(K * ncam, [&](int j) {
+        (void)hipSetDevice(ms[0]->device);
+        svh_matcher* m = ms[j / ncam];
+        const int cam = j % ncam;
+        rcs[j] = features_pack(m, m->cur[cam], cam, cam ? I2[j / ncam] : I1[j / ncam], dims[2]);
+    });
+    t_in_batch = false;
+    for (int rc : rcs)
+        if (rc) return rc;
+    BatchRec& rec = batch_recorder();
+    rec.reset();
+    t_rec = &rec;
+    int rc = SVH_OK;
+    for (int i = 0; i < K && !rc; i++) {
+        rec.begin_object();
+        for (int cam = 0; cam < ncam && !rc; cam++) rc = features_enqueue(ms[i], ms[i]->cur[cam], cam, nullptr);
+    }
+    t_rec = nullptr;
+    if (rc) return rc;
+    hipStream_t s = ms[0]->stream;
+    if (rec.broken) {
+        // (not reachable with equal parameters and sizes; kept so that a future launcher change cannot corrupt a batch)
+        rec.reset();
+        for (int i = 0; i < K; i++) {
+            for (int cam = 0; cam < ncam; cam++) {
+                rc = features_enqueue(ms[i], ms[i]->cur[cam], cam, nullptr);
+                if (rc) return rc;
+            }
+            HIP_TRY((hipError_t)wait_stream(ms[i]->stream));
+            HIP_TRY((hipError_t)wait_stream(ms[i]->stream2));
+            push_finish(ms[i], I1[i], I2 ? I2[i] : nullptr);
+        }
+        return SVH_OK;
+    }
+    HIP_TRY(rec.flush(s));
+    HIP_TRY((hipError_t)wait_stream(s));
+    HIP_TRY(hipGetLastError());
+    rec.synced();
+    for (int i = 0; i < K; i++) push_finish(ms[i], I1[i], I2 ? I2[i] : nullptr);
+    return SVH_OK;
+}
+
+// matchFeatures' sanity checks (matcher.cpp:216-259): false = return silently, previous matches stay
+static bool match_inputs_present(const svh_matcher* m, int32_t method) {
     const svh_matcher_params& p = m->p;
-    // sanity checks: return silently, previous matches stay (matcher.cpp:216-259)
     auto missing = [&](const DevView& V, int dense) { return !V.valid || V.n[dense] == 0; };
     const bool need_1p = method == 0 || method >= 2, need_2p = method >= 2;
     const bool need_2c = method >= 1;
     for (int dense = 1; dense >= (p.multi_stage ? 0 : 1); dense--) {
-        if (need_1p && missing(m->prev[0], dense)) return SVH_OK;
-        if (need_2p && missing(m->prev[1], dense)) return SVH_OK;
-        if (missing(m->cur[0], dense)) return SVH_OK;
-        if (need_2c && missing(m->cur[1], dense)) return SVH_OK;
+        if (need_1p && missing(m->prev[0], dense)) return false;
+        if (need_2p && missing(m->prev[1], dense)) return false;
+        if (missing(m->cur[0], dense)) return false;
+        if (need_2c && missing(m->cur[1], dense)) return false;
     }
-    if (method > 2) method = 2;
-    HIP_TRY(hipSetDevice(m->device));
+    return true;
+}
+
+// result vectors cleared, bin indices of changed tables rebuilt, prior-range buffer sized
+static int32_t match_prepare(svh_matcher* m, int32_t ub, int32_t vb) {
     for (int s = 0; s < SVH_M_STAGE_COUNT; s++) m->stage[s].clear();
     m->m1.clear();
     m->m2.clear();
-    const int32_t ub = (int32_t)ceilf((float)m->dims_c[0] / (float)p.match_binsize);
-    const int32_t vb = (int32_t)ceilf((float)m->dims_c[1] / (float)p.match_binsize);
     DevView* views[4] = {&m->prev[0], &m->prev[1], &m->cur[0], &m->cur[1]};
-    {
-        int rc = ensure_bins(m, views, 4, ub, vb);
-        if (rc) return rc;
-    }
+    const int rc = ensure_bins(m, views, 4, ub, vb);
+    if (rc) return rc;
     if (ub * vb > m->ranges_cap) {
         (void)hipFree(m->ranges_dev);
         HIP_TRY(dalloc(&m->ranges_dev, (size_t)16 * ub * vb));
         m->ranges_cap = ub * vb;
     }
-    int rc;
+    return SVH_OK;
+}
+
+int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double* Tr) {
+    svh::ActiveCaller active_;
+    if (!m) return mfail(SVH_ERR_BAD_ARG, "null argument");
+    const svh_matcher_params& p = m->p;
+    if (!match_inputs_present(m, method)) return SVH_OK;
+    if (method > 2) method = 2;
+    HIP_TRY(hipSetDevice(m->device));
+    const int32_t ub = (int32_t)ceilf((float)m->dims_c[0] / (float)p.match_binsize);
+    const int32_t vb = (int32_t)ceilf((float)m->dims_c[1] / (float)p.match_binsize);
+    int rc = match_prepare(m, ub, vb);
+    if (rc) return rc;
     double tm[6] = {0, 0, 0, 0, 0, 0};
     auto tick = [&](int i) { if (g_mtiming) tm[i] = mnow_ms(); };
     tick(0);
@@ -695,6 +975,137 @@ int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double*
     }
     if (m->taps) m->stage[SVH_M_DENSE] = m->m2;
     return SVH_OK;
+}
+
+// matchFeatures for K Matchers in lockstep: every device step is one launch over the objects that pass the
+// sanity checks, the host steps between them (outlier votes, prior statistics) run on the helper threads.
+// Tr = K pointers (or null), one Tr_delta per object.  Results are those of K svh_matcher_match_features calls.
+int32_t svh_matcher_match_features_batch(svh_matcher* const* ms, int32_t K, int32_t method,
+                                         const double* const* Tr) {
+    svh::ActiveCaller active_;
+    if (!ms || K < 0) return mfail(SVH_ERR_BAD_ARG, "null argument");
+    if (K == 0) return SVH_OK;
+    bool lockstep = K > 1;
+    for (int i = 0; i < K && lockstep; i++) {
+        if (!ms[i]) return mfail(SVH_ERR_BAD_ARG, "null matcher in the batch");
+        for (int j = 0; j < i; j++)
+            if (ms[j] == ms[i]) return mfail(SVH_ERR_BAD_ARG, "the same matcher twice in one batch");
+        lockstep = memcmp(&ms[i]->p, &ms[0]->p, sizeof(ms[0]->p)) == 0 && !ms[i]->taps &&
+                   ms[i]->device == ms[0]->device && memcmp(ms[i]->dims_c, ms[0]->dims_c, sizeof(ms[0]->dims_c)) == 0;
+    }
+    auto serial = [&](const std::vector<svh_matcher*>& list, const std::vector<const double*>& trs) -> int32_t {
+        for (size_t i = 0; i < list.size(); i++) {
+            const int32_t rc = svh_matcher_match_features(list[i], method, trs[i]);
+            if (rc) return rc;
+        }
+        return SVH_OK;
+    };
+    std::vector<svh_matcher*> part;
+    std::vector<const double*> trs;
+    for (int i = 0; i < K; i++) {
+        if (!ms[i]) return mfail(SVH_ERR_BAD_ARG, "null matcher in the batch");
+        if (lockstep && !match_inputs_present(ms[i], method)) continue;
+        part.push_back(ms[i]);
+        trs.push_back(Tr ? Tr[i] : nullptr);
+    }
+    if (!lockstep || part.size() < 2) return serial(part, trs);
+    if (method > 2) method = 2;
+    const int n = (int)part.size();
+    const svh_matcher_params& p = part[0]->p;
+    HIP_TRY(hipSetDevice(part[0]->device));
+    const int32_t ub = (int32_t)ceilf((float)part[0]->dims_c[0] / (float)p.match_binsize);
+    const int32_t vb = (int32_t)ceilf((float)part[0]->dims_c[1] / (float)p.match_binsize);
+    hipStream_t s = part[0]->stream;
+    BatchRec& rec = batch_recorder();
+    std::vector<MatchPass> mp(n);
+    std::vector<int> rcs(n, 0);
+    // record one device phase over all objects; on a sequence mismatch the objects run one by one instead
+    auto device_phase = [&](const std::function<int(int)>& body) -> int {
+        rec.reset();
+        t_rec = &rec;
+        int rc = SVH_OK;
+        for (int i = 0; i < n && !rc; i++) {
+            rec.begin_object();
+            rc = body(i);
+        }
+        t_rec = nullptr;
+        if (rc) return rc;
+        if (rec.broken) {
+            rec.reset();
+            for (int i = 0; i < n; i++) {
+                // (the recording pass marked the bin indices as built: build them for real)
+                for (int k = 0; k < 2; k++) part[i]->prev[k].nbins = part[i]->cur[k].nbins = 0;
+                rc = body(i);
+                if (rc) return rc;
+                HIP_TRY((hipError_t)wait_stream(part[i]->stream));
+            }
+            HIP_TRY(hipGetLastError());
+            return SVH_OK;
+        }
+        HIP_TRY(rec.flush(s));
+        HIP_TRY((hipError_t)wait_stream(s));
+        HIP_TRY(hipGetLastError());
+        rec.synced();
+        return SVH_OK;
+    };
+    auto host_phase = [&](const std::function<int(int)>& body) -> int {
+        t_in_batch = true;
+        BatchPool::get().parallel_for(n, [&](int i) {
+            t_in_batch = true;
+            rcs[i] = body(i);
+            t_in_batch = false;
+        });
+        t_in_batch = false;
+        for (int rc : rcs)
+            if (rc) return rc;
+        return SVH_OK;
+    };
+    int rc;
+    if (p.multi_stage) {
+        rc = device_phase([&](int i) {
+            int r = match_prepare(part[i], ub, vb);
+            if (!r) r = match_enqueue(part[i], 0, method, false, trs[i], mp[i]);
+            if (!r) download_enqueue(part[i], mp[i]);
+            return r;
+        });
+        if (rc) return rc;
+        const size_t nr = (size_t)16 * ub * vb;
+        for (int i = 0; i < n; i++) {
+            svh_matcher* m = part[i];
+            match_collect(m, mp[i], m->m1);
+            if (nr > m->h_ranges_cap) {
+                (void)hipHostFree(m->h_ranges);
+                m->h_ranges = nullptr;
+                HIP_TRY(hipHostMalloc((void**)&m->h_ranges, nr * sizeof(float)));
+                m->h_ranges_cap = nr;
+            }
+        }
+        rc = host_phase([&](int i) {
+            svh_matcher* m = part[i];
+            const int r = remove_outliers(m->p, m->m1, method);
+            if (r) return r;
+            prior_statistics(m, m->m1, method, ub, vb);
+            memcpy(m->h_ranges, m->ranges.data(), m->ranges.size() * sizeof(float));
+            return (int)SVH_OK;
+        });
+        if (rc) return rc;
+    }
+    rc = device_phase([&](int i) {
+        svh_matcher* m = part[i];
+        int r = SVH_OK;
+        if (p.multi_stage)
+            mlaunch_copy(m->stream, m->ranges_dev, m->h_ranges, m->ranges.size() * sizeof(float), hipMemcpyHostToDevice);
+        else
+            r = match_prepare(m, ub, vb);
+        if (!r) r = match_enqueue(m, 1, method, p.multi_stage != 0, trs[i], mp[i]);
+        if (r) return r;
+        if (p.refinement > 0) refine_enqueue(m, method, mp[i]);
+        download_enqueue(m, mp[i]);
+        return (int)SVH_OK;
+    });
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) match_collect(part[i], mp[i], part[i]->m2);
+    return host_phase([&](int i) { return remove_outliers(part[i]->p, part[i]->m2, method); });
 }
 
 // Matcher::bucketFeatures   matcher.cpp:297-343 (host; std::random_shuffle like the reference)

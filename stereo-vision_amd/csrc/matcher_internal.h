@@ -36,6 +36,10 @@ struct MatchParams {
 };
 
 void mlaunch_upload(void* stream, const uint8_t* pinned, uint8_t* dev, size_t bytes);
+// small transfers (a multiple of 4 bytes) between pinned host and device memory: hipMemcpyAsync / hipMemsetAsync,
+// or -- while a batch is being recorded (batch_rec.h) -- jobs of one copy / fill kernel per phase
+void mlaunch_copy(void* stream, void* dst, const void* src, size_t bytes, int kind);
+void mlaunch_fill(void* stream, void* dst, int byte_value, size_t bytes);
 void mlaunch_half(void* stream, const uint8_t* I, int bpl, uint8_t* out, int hw, int hh, int hbpl);
 // f1 == nullptr: Sobel only
 void mlaunch_filters(void* stream, const uint8_t* I, int w, int h, int bpl, uint8_t* du, uint8_t* dv,

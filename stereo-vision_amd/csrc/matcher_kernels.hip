@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 
+#include "batch_rec.h"
 #include "matcher_internal.h"
 
 namespace svh {
@@ -23,10 +24,10 @@ __device__ __forceinline__ int32_t sat_u8(int32_t x) { return x < 0 ? 0 : (x > 2
 // ---------------------------------------------------------------------------
 // M1  Matcher::createHalfResolutionImage   libviso2/src/matcher.cpp:760-776
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_half(const uint8_t* __restrict__ I, int bpl,
-                                              uint8_t* __restrict__ out, int hw, int hh, int hbpl) {
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
+__device__ __forceinline__ void d_half(const uint8_t* __restrict__ I, int bpl,
+                                              uint8_t* __restrict__ out, int hw, int hh, int hbpl, unsigned bx, unsigned by) {
+    const int x = bx * 64 + threadIdx.x;
+    const int y = by * 4 + threadIdx.y;
     if (x >= hw || y >= hh) return;
     const uint8_t* r0 = I + (size_t)(2 * y) * bpl + 2 * x;
     const uint8_t* r1 = r0 + bpl;
@@ -43,11 +44,11 @@ __global__ __launch_bounds__(256) void k_half(const uint8_t* __restrict__ I, int
 constexpr int FX = 64, FY = 16;
 
 template <bool kFeatures>
-__global__ __launch_bounds__(256) void k_filters(const uint8_t* __restrict__ I, int w, int h, int bpl,
+__device__ __forceinline__ void d_filters(const uint8_t* __restrict__ I, int w, int h, int bpl,
                                                  uint8_t* __restrict__ du, uint8_t* __restrict__ dv,
-                                                 int16_t* __restrict__ f1, int16_t* __restrict__ f2) {
+                                                 int16_t* __restrict__ f1, int16_t* __restrict__ f2, unsigned bx, unsigned by) {
     __shared__ uint8_t s[FY + 4][FX + 8];
-    const int x0 = blockIdx.x * FX, y0 = blockIdx.y * FY;
+    const int x0 = bx * FX, y0 = by * FY;
     const int tid = threadIdx.y * FX + threadIdx.x;
     for (int i = tid; i < (FY + 4) * (FX + 4); i += 256) {
         const int r = i / (FX + 4), c = i - r * (FX + 4);
@@ -137,11 +138,11 @@ __device__ __forceinline__ bool group_any(bool p) {
 }
 
 template <int kG>
-__global__ __launch_bounds__(256) void k_nms(const int16_t* __restrict__ f1,
+__device__ __forceinline__ void d_nms(const int16_t* __restrict__ f1,
                                              const int16_t* __restrict__ f2, int w, int h, int bpl,
                                              int n, int tau, int margin, int ni, int nj,
-                                             int4* __restrict__ slots, int32_t* __restrict__ flags) {
-    const int b = (int)(blockIdx.x * 256 + threadIdx.x) / kG;
+                                             int4* __restrict__ slots, int32_t* __restrict__ flags, unsigned bx) {
+    const int b = (int)(bx * 256 + threadIdx.x) / kG;
     const int lane = (int)threadIdx.x % kG;
     if (b >= ni * nj) return;   // whole groups leave together
     const int ib = b / nj, jb = b - ib * nj;
@@ -207,9 +208,9 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int value, int* total) 
 }
 
 // ordered compaction of the surviving slots: order[k] = slot of the k-th feature
-__global__ __launch_bounds__(1024) void k_compact_slots(const int32_t* __restrict__ flags, int nslots,
+__device__ __forceinline__ void d_compact_slots(const int32_t* __restrict__ flags, int nslots,
                                                         int32_t* __restrict__ order,
-                                                        int32_t* __restrict__ count) {
+                                                        int32_t* __restrict__ count, unsigned bx) {
     const int t = threadIdx.x;
     const int chunk = ((nslots + 1023) / 1024 + 3) & ~3;   // multiple of 4: 16-byte flag loads
     const int lo = min(t * chunk, nslots), hi = min(lo + chunk, nslots);
@@ -233,13 +234,13 @@ __global__ __launch_bounds__(1024) void k_compact_slots(const int32_t* __restric
 // M5  descriptor + record packing   matcher.cpp:534-579, 854-877
 // one thread per (feature, descriptor word): 16 (du,dv) pairs around (u, v-1),
 // rows -5,-3,-1,+1,+3,+5 relative to v
-__global__ __launch_bounds__(256) void k_feature_records(const int4* __restrict__ slots,
+__device__ __forceinline__ void d_feature_records(const int4* __restrict__ slots,
                                                          const int32_t* __restrict__ order,
                                                          const int32_t* __restrict__ count,
                                                          const uint8_t* __restrict__ du,
                                                          const uint8_t* __restrict__ dv, int bpl,
-                                                         int scale, int32_t* __restrict__ table) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
+                                                         int scale, int32_t* __restrict__ table, unsigned bx) {
+    const int g = bx * 256 + threadIdx.x;
     const int feat = g >> 3, q = g & 7;
     if (feat >= *count) return;
     const int4 m = slots[order[feat]];
@@ -261,13 +262,13 @@ __global__ __launch_bounds__(256) void k_feature_records(const int4* __restrict_
 // ---------------------------------------------------------------------------
 // LDS build: histogram, scan, scatter and the per-bin ascending sort all stay on chip;
 // used when 2*nb + 1 + n ints fit the LDS budget (launcher), else k_bin_index below.
-__global__ __launch_bounds__(1024) void k_bin_index_lds(BinJobs J, int ub, int vb, int binsize) {
+__device__ __forceinline__ void d_bin_index_lds(BinJobs J, int ub, int vb, int binsize, unsigned bx) {
     extern __shared__ int s_bin[];
-    // one workgroup per table (blockIdx.x): the four tables of a stereo frame build concurrently
-    const int32_t* __restrict__ table = J.table[blockIdx.x];
-    int32_t* __restrict__ off = J.off[blockIdx.x];
-    int32_t* __restrict__ ids = J.ids[blockIdx.x];
-    const int n = *J.count[blockIdx.x], nb = 4 * ub * vb, t = threadIdx.x;
+    // one workgroup per table (bx): the four tables of a stereo frame build concurrently
+    const int32_t* __restrict__ table = J.table[bx];
+    int32_t* __restrict__ off = J.off[bx];
+    int32_t* __restrict__ ids = J.ids[bx];
+    const int n = *J.count[bx], nb = 4 * ub * vb, t = threadIdx.x;
     int* s_off = s_bin;            // nb + 1
     int* s_cur = s_bin + nb + 1;   // nb
     int* s_ids = s_cur + nb;       // n
@@ -475,12 +476,12 @@ __device__ __forceinline__ svh_p_match mk(float u1p, float v1p, int i1p, float u
 // M8  Matcher::matching   matcher.cpp:1161-1379 -- one thread per query feature.
 // flags: 0 = no match, 1 = match.  For flow/stereo the "pixel not matched yet"
 // rule (first query in index order wins) is resolved by k_match_dedupe.
-__global__ __launch_bounds__(128) void k_match(MatchParams P, FeatView m1p, FeatView m2p, FeatView m1c,
+__device__ __forceinline__ void d_match(MatchParams P, FeatView m1p, FeatView m2p, FeatView m1c,
                                                FeatView m2c, const float* __restrict__ ranges,
                                                int use_prior, svh_p_match* __restrict__ out,
                                                int32_t* __restrict__ flags,
-                                               int32_t* __restrict__ pixel_owner) {
-    const int i = (int)(blockIdx.x * 128 + threadIdx.x) / kQ;
+                                               int32_t* __restrict__ pixel_owner, unsigned bx) {
+    const int i = (int)(bx * 128 + threadIdx.x) / kQ;
     const int lane = (int)threadIdx.x % kQ;
     const FeatView& q = P.method == 2 ? m1p : m1c;
     if (i >= *q.count) return;   // whole groups leave together
@@ -551,21 +552,21 @@ __global__ __launch_bounds__(128) void k_match(MatchParams P, FeatView m1p, Feat
 }
 
 // flow / stereo: keep a match only if its query is the first one on its pixel
-__global__ __launch_bounds__(256) void k_match_dedupe(const int32_t* __restrict__ n, int width,
+__device__ __forceinline__ void d_match_dedupe(const int32_t* __restrict__ n, int width,
                                                       const svh_p_match* __restrict__ m,
                                                       int32_t* __restrict__ flags,
-                                                      const int32_t* __restrict__ pixel_owner) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                      const int32_t* __restrict__ pixel_owner, unsigned bx) {
+    const int i = bx * 256 + threadIdx.x;
     if (i >= *n || !flags[i]) return;
     const int u = (int)m[i].u1c, v = (int)m[i].v1c;
     if (pixel_owner[(size_t)v * width + u] != i) flags[i] = 0;
 }
 
-__global__ __launch_bounds__(1024) void k_compact_matches(const svh_p_match* __restrict__ in,
+__device__ __forceinline__ void d_compact_matches(const svh_p_match* __restrict__ in,
                                                           const int32_t* __restrict__ flags,
                                                           const int32_t* __restrict__ nslots_ptr,
                                                           svh_p_match* __restrict__ out,
-                                                          int32_t* __restrict__ count) {
+                                                          int32_t* __restrict__ count, unsigned bx) {
     const int nslots = *nslots_ptr;
     const int t = threadIdx.x;
     const int chunk = (nslots + 1023) / 1024;
@@ -641,11 +642,11 @@ __device__ __forceinline__ void relocate_group(const SobelView& s1, const SobelV
     *v2 = (float)((double)*v2 + ((double)(float)(best / 5) - 2.0));
 }
 
-__global__ __launch_bounds__(256) void k_refine_group(svh_p_match* __restrict__ m,
+__device__ __forceinline__ void d_refine_group(svh_p_match* __restrict__ m,
                                                       const int32_t* __restrict__ count, int method, int margin,
                                                       SobelView s1p, SobelView s2p, SobelView s1c,
-                                                      SobelView s2c) {
-    const int i = (int)(blockIdx.x * 256 + threadIdx.x) >> 5, lane = threadIdx.x & 31;
+                                                      SobelView s2c, unsigned bx) {
+    const int i = (int)(bx * 256 + threadIdx.x) >> 5, lane = threadIdx.x & 31;
     if (i >= *count) return;   // whole groups leave together
     svh_p_match q = m[i];
     if (method == 0 || method == 2) relocate_group(s1c, s1p, margin, q.u1c, q.v1c, &q.u1p, &q.v1p, lane);
@@ -790,11 +791,11 @@ __device__ bool parabolic(const SobelView& s1, const SobelView& s2, int margin, 
 }
 
 template <bool kParabolic>
-__global__ __launch_bounds__(128) void k_refine(svh_p_match* __restrict__ m,
+__device__ __forceinline__ void d_refine(svh_p_match* __restrict__ m,
                                                 const int32_t* __restrict__ count, int method, int margin,
                                                 SobelView s1p, SobelView s2p, SobelView s1c,
-                                                SobelView s2c, int32_t* __restrict__ flags) {
-    const int i = blockIdx.x * 128 + threadIdx.x;
+                                                SobelView s2c, int32_t* __restrict__ flags, unsigned bx) {
+    const int i = bx * 128 + threadIdx.x;
     if (i >= *count) return;
     svh_p_match q = m[i];
     bool ok = true;
@@ -811,40 +812,207 @@ __global__ __launch_bounds__(128) void k_refine(svh_p_match* __restrict__ m,
     if (ok) m[i] = q;
 }
 
-}  // namespace
+
+// ---------------------------------------------------------------------------
+// Kernels: every body above is a __device__ function of (arguments, block index); each gets a plain
+// __global__ form (one object: arguments by value) and a BATCHED form (K objects in lockstep, batch_rec.h:
+// arguments of job blockIdx.z read from a job table in device memory, grid = the largest job's).
+// ---------------------------------------------------------------------------
+struct HalfJob { const uint8_t* I; int bpl; uint8_t* out; int hw, hh, hbpl; };
+__global__ __launch_bounds__(256) void k_half(HalfJob a) { d_half(a.I, a.bpl, a.out, a.hw, a.hh, a.hbpl, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_half_b(const HalfJob* J) {
+    const HalfJob a = J[blockIdx.z];
+    d_half(a.I, a.bpl, a.out, a.hw, a.hh, a.hbpl, blockIdx.x, blockIdx.y);
+}
+
+struct FiltersJob { const uint8_t* I; int w, h, bpl; uint8_t *du, *dv; int16_t *f1, *f2; };
+template <bool kFeatures>
+__global__ __launch_bounds__(256) void k_filters(FiltersJob a) {
+    d_filters<kFeatures>(a.I, a.w, a.h, a.bpl, a.du, a.dv, a.f1, a.f2, blockIdx.x, blockIdx.y);
+}
+template <bool kFeatures>
+__global__ __launch_bounds__(256) void k_filters_b(const FiltersJob* J) {
+    const FiltersJob a = J[blockIdx.z];
+    d_filters<kFeatures>(a.I, a.w, a.h, a.bpl, a.du, a.dv, a.f1, a.f2, blockIdx.x, blockIdx.y);
+}
+
+struct NmsJob { const int16_t *f1, *f2; int w, h, bpl, n, tau, margin, ni, nj; int4* slots; int32_t* flags; };
+template <int kG>
+__global__ __launch_bounds__(256) void k_nms(NmsJob a) {
+    d_nms<kG>(a.f1, a.f2, a.w, a.h, a.bpl, a.n, a.tau, a.margin, a.ni, a.nj, a.slots, a.flags, blockIdx.x);
+}
+template <int kG>
+__global__ __launch_bounds__(256) void k_nms_b(const NmsJob* J) {
+    const NmsJob a = J[blockIdx.z];
+    d_nms<kG>(a.f1, a.f2, a.w, a.h, a.bpl, a.n, a.tau, a.margin, a.ni, a.nj, a.slots, a.flags, blockIdx.x);
+}
+
+struct CompactSlotsJob { const int32_t* flags; int nslots; int32_t *order, *count; };
+__global__ __launch_bounds__(1024) void k_compact_slots(CompactSlotsJob a) { d_compact_slots(a.flags, a.nslots, a.order, a.count, 0u); }
+__global__ __launch_bounds__(1024) void k_compact_slots_b(const CompactSlotsJob* J) {
+    const CompactSlotsJob a = J[blockIdx.z];
+    d_compact_slots(a.flags, a.nslots, a.order, a.count, 0u);
+}
+
+struct FeatureRecordsJob { const int4* slots; const int32_t *order, *count; const uint8_t *du, *dv; int bpl, scale; int32_t* table; };
+__global__ __launch_bounds__(256) void k_feature_records(FeatureRecordsJob a) {
+    d_feature_records(a.slots, a.order, a.count, a.du, a.dv, a.bpl, a.scale, a.table, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_feature_records_b(const FeatureRecordsJob* J) {
+    const FeatureRecordsJob a = J[blockIdx.z];
+    d_feature_records(a.slots, a.order, a.count, a.du, a.dv, a.bpl, a.scale, a.table, blockIdx.x);
+}
+
+struct BinIndexJob { BinJobs J; int njobs, ub, vb, binsize; };
+__global__ __launch_bounds__(1024) void k_bin_index_lds(BinJobs J, int ub, int vb, int binsize) { d_bin_index_lds(J, ub, vb, binsize, blockIdx.x); }
+__global__ __launch_bounds__(1024) void k_bin_index_lds_b(const BinIndexJob* J) {
+    const BinIndexJob& a = J[blockIdx.z];
+    if ((int)blockIdx.x >= a.njobs) return;
+    d_bin_index_lds(a.J, a.ub, a.vb, a.binsize, blockIdx.x);
+}
+
+struct MatchJob {
+    MatchParams P;
+    FeatView m1p, m2p, m1c, m2c;
+    const float* ranges;
+    int use_prior;
+    svh_p_match* out;
+    int32_t *flags, *pixel_owner;
+};
+__global__ __launch_bounds__(128) void k_match(MatchJob a) {
+    d_match(a.P, a.m1p, a.m2p, a.m1c, a.m2c, a.ranges, a.use_prior, a.out, a.flags, a.pixel_owner, blockIdx.x);
+}
+__global__ __launch_bounds__(128) void k_match_b(const MatchJob* J) {
+    const MatchJob& a = J[blockIdx.z];
+    d_match(a.P, a.m1p, a.m2p, a.m1c, a.m2c, a.ranges, a.use_prior, a.out, a.flags, a.pixel_owner, blockIdx.x);
+}
+
+struct DedupeJob { const int32_t* n; int width; const svh_p_match* m; int32_t* flags; const int32_t* pixel_owner; };
+__global__ __launch_bounds__(256) void k_match_dedupe(DedupeJob a) { d_match_dedupe(a.n, a.width, a.m, a.flags, a.pixel_owner, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_match_dedupe_b(const DedupeJob* J) {
+    const DedupeJob a = J[blockIdx.z];
+    d_match_dedupe(a.n, a.width, a.m, a.flags, a.pixel_owner, blockIdx.x);
+}
+
+struct CompactMatchesJob { const svh_p_match* in; const int32_t *flags, *nslots; svh_p_match* out; int32_t* count; };
+__global__ __launch_bounds__(1024) void k_compact_matches(CompactMatchesJob a) { d_compact_matches(a.in, a.flags, a.nslots, a.out, a.count, 0u); }
+__global__ __launch_bounds__(1024) void k_compact_matches_b(const CompactMatchesJob* J) {
+    const CompactMatchesJob a = J[blockIdx.z];
+    d_compact_matches(a.in, a.flags, a.nslots, a.out, a.count, 0u);
+}
+
+struct RefineJob { svh_p_match* m; const int32_t* count; int method, margin; SobelView s1p, s2p, s1c, s2c; int32_t* flags; };
+__global__ __launch_bounds__(256) void k_refine_group(RefineJob a) {
+    d_refine_group(a.m, a.count, a.method, a.margin, a.s1p, a.s2p, a.s1c, a.s2c, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_refine_group_b(const RefineJob* J) {
+    const RefineJob& a = J[blockIdx.z];
+    d_refine_group(a.m, a.count, a.method, a.margin, a.s1p, a.s2p, a.s1c, a.s2c, blockIdx.x);
+}
+__global__ __launch_bounds__(128) void k_refine_parabolic(RefineJob a) {
+    d_refine<true>(a.m, a.count, a.method, a.margin, a.s1p, a.s2p, a.s1c, a.s2c, a.flags, blockIdx.x);
+}
+__global__ __launch_bounds__(128) void k_refine_parabolic_b(const RefineJob* J) {
+    const RefineJob& a = J[blockIdx.z];
+    d_refine<true>(a.m, a.count, a.method, a.margin, a.s1p, a.s2p, a.s1c, a.s2c, a.flags, blockIdx.x);
+}
 
 // ---------------------------------------------------------------------------
 // Image upload: the rows were packed into PINNED host memory; the device reads
 // them over PCIe with 16-byte loads and writes its HBM copy.  One kernel launch
 // instead of a hipMemcpyAsync (whose submission alone costs ~90 us per image).
+// The batched entries move every small transfer of a phase this way (feature counts and match lists to
+// pinned host memory, search ranges to the device): words of 4 bytes, any direction the device can address.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_upload(const uint4* __restrict__ host, uint4* __restrict__ dev,
-                                                size_t n16) {
+struct UploadJob { const uint4* host; uint4* dev; size_t n16; };
+__global__ __launch_bounds__(256) void k_upload(UploadJob a) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n16) dev[i] = host[i];
+    if (i < a.n16) a.dev[i] = a.host[i];
+}
+__global__ __launch_bounds__(256) void k_upload_b(const UploadJob* J) {
+    const UploadJob a = J[blockIdx.z];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < a.n16) a.dev[i] = a.host[i];
+}
+struct Copy4Job { uint32_t* dst; const uint32_t* src; size_t n4; };
+__global__ __launch_bounds__(256) void k_copy4_b(const Copy4Job* J) {
+    const Copy4Job a = J[blockIdx.z];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) a.dst[i] = a.src[i];
+}
+struct Fill4Job { uint32_t* dst; uint32_t value; size_t n4; };
+__global__ __launch_bounds__(256) void k_fill4_b(const Fill4Job* J) {
+    const Fill4Job a = J[blockIdx.z];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) a.dst[i] = a.value;
 }
 
+// batched launch entries (BatchLaunchFn): jobs = device copy of the table, grid (gx, gy, njobs)
+#define SVH_BATCH_FN(name, kernel, Job, threads)                                                                   \
+    void name(const void* jobs, int njobs, unsigned gx, unsigned gy, size_t lds, hipStream_t s) {                  \
+        hipLaunchKernelGGL(kernel, dim3(gx, gy, (unsigned)njobs), threads, lds, s, reinterpret_cast<const Job*>(jobs)); \
+    }
+SVH_BATCH_FN(b_half, k_half_b, HalfJob, dim3(64, 4))
+SVH_BATCH_FN(b_filters0, k_filters_b<false>, FiltersJob, dim3(FX, 4))
+SVH_BATCH_FN(b_filters1, k_filters_b<true>, FiltersJob, dim3(FX, 4))
+SVH_BATCH_FN(b_nms16, k_nms_b<16>, NmsJob, dim3(256))
+SVH_BATCH_FN(b_nms64, k_nms_b<64>, NmsJob, dim3(256))
+SVH_BATCH_FN(b_compact_slots, k_compact_slots_b, CompactSlotsJob, dim3(1024))
+SVH_BATCH_FN(b_feature_records, k_feature_records_b, FeatureRecordsJob, dim3(256))
+SVH_BATCH_FN(b_bin_index, k_bin_index_lds_b, BinIndexJob, dim3(1024))
+SVH_BATCH_FN(b_match, k_match_b, MatchJob, dim3(128))
+SVH_BATCH_FN(b_dedupe, k_match_dedupe_b, DedupeJob, dim3(256))
+SVH_BATCH_FN(b_compact_matches, k_compact_matches_b, CompactMatchesJob, dim3(1024))
+SVH_BATCH_FN(b_refine_group, k_refine_group_b, RefineJob, dim3(256))
+SVH_BATCH_FN(b_refine_parabolic, k_refine_parabolic_b, RefineJob, dim3(128))
+SVH_BATCH_FN(b_upload, k_upload_b, UploadJob, dim3(256))
+SVH_BATCH_FN(b_copy4, k_copy4_b, Copy4Job, dim3(256))
+SVH_BATCH_FN(b_fill4, k_fill4_b, Fill4Job, dim3(256))
+
+}  // namespace
+
 // ---------------------------------------------------------------------------
-// launchers
+// launchers: launch now, or -- while the calling thread records a batch (batch_rec.h) -- append a job
 // ---------------------------------------------------------------------------
 void mlaunch_upload(void* stream, const uint8_t* pinned, uint8_t* dev, size_t bytes) {
     const size_t n16 = bytes / 16;   // bpl is a multiple of 16
-    hipLaunchKernelGGL(k_upload, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const uint4*>(pinned), reinterpret_cast<uint4*>(dev), n16);
+    const UploadJob a = {reinterpret_cast<const uint4*>(pinned), reinterpret_cast<uint4*>(dev), n16};
+    const unsigned gx = (unsigned)((n16 + 255) / 256);
+    if (t_rec) return t_rec->add(b_upload, a, gx);
+    hipLaunchKernelGGL(k_upload, dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
+}
+
+// small transfers between pinned host and device memory, either direction (bytes: a multiple of 4)
+void mlaunch_copy(void* stream, void* dst, const void* src, size_t bytes, int kind) {
+    if (t_rec) {
+        const Copy4Job a = {static_cast<uint32_t*>(dst), static_cast<const uint32_t*>(src), bytes / 4};
+        return t_rec->add(b_copy4, a, (unsigned)std::min<size_t>((bytes / 4 + 255) / 256, 64));
+    }
+    (void)hipMemcpyAsync(dst, src, bytes, (hipMemcpyKind)kind, (hipStream_t)stream);
+}
+void mlaunch_fill(void* stream, void* dst, int byte_value, size_t bytes) {
+    if (t_rec) {
+        const uint32_t b = (uint32_t)(byte_value & 0xFF);
+        const Fill4Job a = {static_cast<uint32_t*>(dst), b | b << 8 | b << 16 | b << 24, bytes / 4};
+        return t_rec->add(b_fill4, a, (unsigned)std::min<size_t>((bytes / 4 + 255) / 256, 256));
+    }
+    (void)hipMemsetAsync(dst, byte_value, bytes, (hipStream_t)stream);
 }
 
 void mlaunch_half(void* stream, const uint8_t* I, int bpl, uint8_t* out, int hw, int hh, int hbpl) {
-    hipLaunchKernelGGL(k_half, dim3((hw + 63) / 64, (hh + 3) / 4), dim3(64, 4), 0, (hipStream_t)stream, I, bpl,
-                       out, hw, hh, hbpl);
+    const HalfJob a = {I, bpl, out, hw, hh, hbpl};
+    const unsigned gx = (hw + 63) / 64, gy = (hh + 3) / 4;
+    if (t_rec) return t_rec->add(b_half, a, gx, gy);
+    hipLaunchKernelGGL(k_half, dim3(gx, gy), dim3(64, 4), 0, (hipStream_t)stream, a);
 }
 
 void mlaunch_filters(void* stream, const uint8_t* I, int w, int h, int bpl, uint8_t* du, uint8_t* dv,
                      int16_t* f1, int16_t* f2) {
-    dim3 grid((w + FX - 1) / FX, (h + FY - 1) / FY), block(FX, 4);
+    const FiltersJob a = {I, w, h, bpl, du, dv, f1, f2};
+    const dim3 grid((w + FX - 1) / FX, (h + FY - 1) / FY), block(FX, 4);
+    if (t_rec) return t_rec->add(f1 ? b_filters1 : b_filters0, a, grid.x, grid.y);
     if (f1)
-        hipLaunchKernelGGL(k_filters<true>, grid, block, 0, (hipStream_t)stream, I, w, h, bpl, du, dv, f1, f2);
+        hipLaunchKernelGGL(k_filters<true>, grid, block, 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(k_filters<false>, grid, block, 0, (hipStream_t)stream, I, w, h, bpl, du, dv, f1, f2);
+        hipLaunchKernelGGL(k_filters<false>, grid, block, 0, (hipStream_t)stream, a);
 }
 
 int mnms_blocks(int extent, int n, int margin) {
@@ -859,24 +1027,40 @@ void mlaunch_features(void* stream, const int16_t* f1, const int16_t* f2, const 
     hipStream_t s = (hipStream_t)stream;
     const int ni = mnms_blocks(w, n, margin), nj = mnms_blocks(h, n, margin);
     const int nb = ni * nj;
-    if (nb > 0) {
-        if ((n + 1) * (n + 1) <= 16)
-            hipLaunchKernelGGL(k_nms<16>, dim3((nb + 15) / 16), dim3(256), 0, s, f1, f2, w, h, bpl, n, tau,
-                               margin, ni, nj, slots, flags);
-        else
-            hipLaunchKernelGGL(k_nms<64>, dim3((nb + 3) / 4), dim3(256), 0, s, f1, f2, w, h, bpl, n, tau,
-                               margin, ni, nj, slots, flags);
+    const NmsJob an = {f1, f2, w, h, bpl, n, tau, margin, ni, nj, slots, flags};
+    const CompactSlotsJob ac = {flags, nb * 4, order, count};
+    const FeatureRecordsJob af = {slots, order, count, du, dv, bpl, scale, table};
+    const bool small = (n + 1) * (n + 1) <= 16;
+    if (t_rec) {
+        if (nb > 0) t_rec->add(small ? b_nms16 : b_nms64, an, small ? (nb + 15) / 16 : (nb + 3) / 4);
+        t_rec->add(b_compact_slots, ac, 1);
+        if (nb > 0) t_rec->add(b_feature_records, af, (nb * 4 * 8 + 255) / 256);
+        return;
     }
-    hipLaunchKernelGGL(k_compact_slots, dim3(1), dim3(1024), 0, s, flags, nb * 4, order, count);
-    if (nb > 0)
-        hipLaunchKernelGGL(k_feature_records, dim3((nb * 4 * 8 + 255) / 256), dim3(256), 0, s, slots, order,
-                           count, du, dv, bpl, scale, table);
+    if (nb > 0) {
+        if (small)
+            hipLaunchKernelGGL(k_nms<16>, dim3((nb + 15) / 16), dim3(256), 0, s, an);
+        else
+            hipLaunchKernelGGL(k_nms<64>, dim3((nb + 3) / 4), dim3(256), 0, s, an);
+    }
+    hipLaunchKernelGGL(k_compact_slots, dim3(1), dim3(1024), 0, s, ac);
+    if (nb > 0) hipLaunchKernelGGL(k_feature_records, dim3((nb * 4 * 8 + 255) / 256), dim3(256), 0, s, af);
 }
 
 void mlaunch_bin_index(void* stream, const BinJobs& J, int njobs, int n_host_max, int ub, int vb, int binsize,
                        int32_t* cursor) {
     const int nb = 4 * ub * vb;
     const size_t lds = ((size_t)2 * nb + 1 + (size_t)std::max(n_host_max, 0)) * sizeof(int32_t);
+    if (t_rec) {
+        // (the batched form has the LDS build only, with the 160 KB opt-in: ~38 k features per table)
+        BinIndexJob a;
+        a.J = J; a.njobs = njobs; a.ub = ub; a.vb = vb; a.binsize = binsize;
+        static bool attr_once = ((void)hipFuncSetAttribute((const void*)k_bin_index_lds_b,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024), true);
+        (void)attr_once;
+        if (lds > 156 * 1024) t_rec->broken = true;
+        return t_rec->add(b_bin_index, a, 8, 1, lds);
+    }
     if (lds <= 56 * 1024) {
         hipLaunchKernelGGL(k_bin_index_lds, dim3(njobs), dim3(1024), lds, (hipStream_t)stream, J, ub, vb, binsize);
     } else {
@@ -892,16 +1076,24 @@ void mlaunch_match(void* stream, const MatchParams& P, const FeatView& m1p, cons
                    svh_p_match* out, int32_t* out_count) {
     hipStream_t s = (hipStream_t)stream;
     const FeatView& q = P.method == 2 ? m1p : m1c;
-    if (P.method < 2)
-        (void)hipMemsetAsync(pixel_owner, 0x7F, (size_t)P.width * P.height * sizeof(int32_t), s);
-    if (nquery_cap > 0) {
-        hipLaunchKernelGGL(k_match, dim3((nquery_cap * kQ + 127) / 128), dim3(128), 0, s, P, m1p, m2p, m1c,
-                           m2c, ranges, use_prior, slots, flags, pixel_owner);
-        if (P.method < 2)
-            hipLaunchKernelGGL(k_match_dedupe, dim3((nquery_cap + 255) / 256), dim3(256), 0, s, q.count,
-                               P.width, slots, flags, pixel_owner);
+    if (P.method < 2) mlaunch_fill(stream, pixel_owner, 0x7F, (size_t)P.width * P.height * sizeof(int32_t));
+    MatchJob am;
+    am.P = P; am.m1p = m1p; am.m2p = m2p; am.m1c = m1c; am.m2c = m2c; am.ranges = ranges; am.use_prior = use_prior;
+    am.out = slots; am.flags = flags; am.pixel_owner = pixel_owner;
+    const DedupeJob ad = {q.count, P.width, slots, flags, pixel_owner};
+    const CompactMatchesJob ac = {slots, flags, q.count, out, out_count};
+    if (t_rec) {
+        if (nquery_cap > 0) {
+            t_rec->add(b_match, am, (nquery_cap * kQ + 127) / 128);
+            if (P.method < 2) t_rec->add(b_dedupe, ad, (nquery_cap + 255) / 256);
+        }
+        return t_rec->add(b_compact_matches, ac, 1);
     }
-    hipLaunchKernelGGL(k_compact_matches, dim3(1), dim3(1024), 0, s, slots, flags, q.count, out, out_count);
+    if (nquery_cap > 0) {
+        hipLaunchKernelGGL(k_match, dim3((nquery_cap * kQ + 127) / 128), dim3(128), 0, s, am);
+        if (P.method < 2) hipLaunchKernelGGL(k_match_dedupe, dim3((nquery_cap + 255) / 256), dim3(256), 0, s, ad);
+    }
+    hipLaunchKernelGGL(k_compact_matches, dim3(1), dim3(1024), 0, s, ac);
 }
 
 void mlaunch_refine(void* stream, svh_p_match* m, const int32_t* count, int cap, int method, int margin,
@@ -909,18 +1101,23 @@ void mlaunch_refine(void* stream, svh_p_match* m, const int32_t* count, int cap,
                     const SobelView& s2c, int parabolic, int32_t* flags, svh_p_match* compacted,
                     int32_t* compacted_count) {
     hipStream_t s = (hipStream_t)stream;
+    const RefineJob ar = {m, count, method, margin, s1p, s2p, s1c, s2c, flags};
     if (!parabolic) {
-        if (cap > 0)
-            hipLaunchKernelGGL(k_refine_group, dim3((unsigned)(((size_t)cap * 32 + 255) / 256)), dim3(256), 0, s, m,
-                               count, method, margin, s1p, s2p, s1c, s2c);
+        if (cap > 0) {
+            const unsigned gx = (unsigned)(((size_t)cap * 32 + 255) / 256);
+            if (t_rec) return t_rec->add(b_refine_group, ar, gx);
+            hipLaunchKernelGGL(k_refine_group, dim3(gx), dim3(256), 0, s, ar);
+        }
         return;
     }
-    if (cap > 0)
-        hipLaunchKernelGGL(k_refine<true>, dim3((cap + 127) / 128), dim3(128), 0, s, m, count, method, margin,
-                           s1p, s2p, s1c, s2c, flags);
     // matches whose fit failed are dropped, order preserved (matcher.cpp:1766-1816)
-    hipLaunchKernelGGL(k_compact_matches, dim3(1), dim3(1024), 0, s, m, flags, count, compacted,
-                       compacted_count);
+    const CompactMatchesJob ac = {m, flags, count, compacted, compacted_count};
+    if (t_rec) {
+        if (cap > 0) t_rec->add(b_refine_parabolic, ar, (cap + 127) / 128);
+        return t_rec->add(b_compact_matches, ac, 1);
+    }
+    if (cap > 0) hipLaunchKernelGGL(k_refine_parabolic, dim3((cap + 127) / 128), dim3(128), 0, s, ar);
+    hipLaunchKernelGGL(k_compact_matches, dim3(1), dim3(1024), 0, s, ac);
 }
 
 }  // namespace svh

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/svh.h"
+#include "batch_rec.h"
 #include "vo_internal.h"
 
 using namespace svh;
@@ -120,8 +121,11 @@ void vector_to_matrix(const double* tr, double* T) {
     T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
 }
 
-// estimateMotion: returns 1 + tr, 0 for the reference's empty vector, <0 on error
-int estimate(svh_vo* v, const svh_p_match* pm, int32_t N, double* tr6) {
+// estimateMotion in three steps (a batched call interleaves them over its objects):
+//   estimate_prepare: buffers, matches and the RANSAC samples into pinned memory (consumes libc rand())
+//   estimate_enqueue: upload + the two kernels;   estimate_collect: result after the stream wait
+// estimate_prepare returns 1 when there is device work, 0 for the reference's early return (N < 6), <0 on error
+int estimate_prepare(svh_vo* v, const svh_p_match* pm, int32_t N) {
     const svh_vo_params& P = v->p;
     if (N < 6) return 0;   // viso_stereo.cpp:91-94: returns before _inliers is cleared
     const int32_t iters = P.ransac_iters > 0 ? P.ransac_iters : 0;
@@ -131,7 +135,6 @@ int estimate(svh_vo* v, const svh_p_match* pm, int32_t N, double* tr6) {
     // getRandomSample(N, 3) for every iteration, viso.cpp:130-153: three libc rand() draws
     // without replacement (the draw indexes the list of the not yet chosen indices)
     const size_t m_bytes = ((size_t)N * sizeof(svh_p_match) + 15) & ~(size_t)15;
-    const size_t s_bytes = ((size_t)iters * 3 * sizeof(int32_t) + 15) & ~(size_t)15;
     memcpy(v->h_in, pm, (size_t)N * sizeof(svh_p_match));
     int32_t* samples = reinterpret_cast<int32_t*>(v->h_in + m_bytes);
     for (int32_t k = 0; k < iters; k++) {
@@ -154,6 +157,14 @@ int estimate(svh_vo* v, const svh_p_match* pm, int32_t N, double* tr6) {
             samples[3 * k + q] = idx;
         }
     }
+    return 1;
+}
+
+void estimate_enqueue(svh_vo* v, int32_t N) {
+    const svh_vo_params& P = v->p;
+    const int32_t iters = P.ransac_iters > 0 ? P.ransac_iters : 0;
+    const size_t m_bytes = ((size_t)N * sizeof(svh_p_match) + 15) & ~(size_t)15;
+    const size_t s_bytes = ((size_t)iters * 3 * sizeof(int32_t) + 15) & ~(size_t)15;
     hipStream_t s = v->stream;
     vlaunch_upload(s, v->h_in, v->d_in, m_bytes + s_bytes);
     VoCalib c;
@@ -163,13 +174,24 @@ int estimate(svh_vo* v, const svh_p_match* pm, int32_t N, double* tr6) {
     vlaunch_estimate(s, reinterpret_cast<const svh_p_match*>(v->d_in), N,
                      reinterpret_cast<const int32_t*>(v->d_in + m_bytes), iters, c, v->d_hyp_tr,
                      v->d_hyp_count, v->d_flags, v->d_J, v->d_res, v->h_out, v->h_inl);
-    VO_TRY((hipError_t)wait_stream(s));
-    VO_TRY(hipGetLastError());
+}
+
+int estimate_collect(svh_vo* v, double* tr6) {
     const VoResult& r = *v->h_out;
     v->inliers.assign(v->h_inl, v->h_inl + r.n_inliers);
     if (!r.success) return 0;
     for (int i = 0; i < 6; i++) tr6[i] = r.tr[i];
     return 1;
+}
+
+// estimateMotion: returns 1 + tr, 0 for the reference's empty vector, <0 on error
+int estimate(svh_vo* v, const svh_p_match* pm, int32_t N, double* tr6) {
+    const int rc = estimate_prepare(v, pm, N);
+    if (rc <= 0) return rc;
+    estimate_enqueue(v, N);
+    VO_TRY((hipError_t)wait_stream(v->stream));
+    VO_TRY(hipGetLastError());
+    return estimate_collect(v, tr6);
 }
 
 // bool VisualOdometry::updateMotion   viso.cpp:47-64
@@ -275,6 +297,93 @@ int32_t svh_vo_process(svh_vo* v, const uint8_t* I1, const uint8_t* I2, const in
                                 (float)P.bucket_height);
     fetch_matches(v);
     return update_motion(v);
+}
+
+// One frame of K sequences: K VisualOdometryStereo objects in lockstep.  The Matcher steps go through the batched
+// Matcher entries, the K motion estimates are two launches.  libc rand() is consumed in the order of K
+// svh_vo_process calls (object by object: bucketing, then the RANSAC samples), so with the same srand the results
+// are bit-identical to that loop.  ok[i] (optional) = what svh_vo_process would have returned for object i
+// (1 motion updated, 0 estimate failed); the call returns <0 on the first error, else the number of successes.
+// Objects that are still bootstrapping (no valid motion yet), or that differ in parameters, make the call run
+// them one after the other.
+int32_t svh_vo_process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const* I1, const uint8_t* const* I2,
+                             const int32_t* dims, int32_t replace, int32_t* ok) {
+    svh::ActiveCaller active_;
+    if (!vs || K < 0 || !I1 || !I2 || !dims) return svh::fail(SVH_ERR_BAD_ARG, "null argument");
+    bool lockstep = K > 1;
+    for (int i = 0; i < K; i++) {
+        if (!vs[i]) return svh::fail(SVH_ERR_BAD_ARG, "null object in the batch");
+        for (int j = 0; j < i; j++)
+            if (vs[j] == vs[i]) return svh::fail(SVH_ERR_BAD_ARG, "the same object twice in one batch");
+        lockstep = lockstep && vs[i]->Tr_valid && memcmp(&vs[i]->p, &vs[0]->p, sizeof(vs[0]->p)) == 0 &&
+                   vs[i]->device == vs[0]->device;
+    }
+    int32_t good = 0;
+    if (!lockstep) {
+        for (int i = 0; i < K; i++) {
+            const int32_t rc = svh_vo_process(vs[i], I1[i], I2[i], dims, replace);
+            if (rc < 0) return rc;
+            if (ok) ok[i] = rc;
+            good += rc > 0;
+        }
+        return good;
+    }
+    const svh_vo_params& P = vs[0]->p;
+    std::vector<svh_matcher*> ms(K);
+    std::vector<const double*> trs(K);
+    for (int i = 0; i < K; i++) {
+        ms[i] = vs[i]->matcher;
+        trs[i] = vs[i]->Tr;
+    }
+    int32_t rc = svh_matcher_push_back_batch(ms.data(), K, I1, I2, dims, replace);
+    if (rc < 0 && rc != SVH_ERR_BAD_ARG) return rc;
+    rc = svh_matcher_match_features_batch(ms.data(), K, 2, trs.data());
+    if (rc < 0) return rc;
+    std::vector<int> state(K, 0);
+    for (int i = 0; i < K; i++) {
+        svh_vo* v = vs[i];
+        svh_matcher_bucket_features(v->matcher, P.bucket_max_features, (float)P.bucket_width, (float)P.bucket_height);
+        fetch_matches(v);
+        state[i] = estimate_prepare(v, v->matched.data(), (int32_t)v->matched.size());
+        if (state[i] < 0) return state[i];
+    }
+    BatchRec& rec = batch_recorder();
+    rec.reset();
+    t_rec = &rec;
+    for (int i = 0; i < K; i++)
+        if (state[i] > 0) {
+            rec.begin_object();
+            estimate_enqueue(vs[i], (int32_t)vs[i]->matched.size());
+        }
+    t_rec = nullptr;
+    if (rec.broken) {
+        rec.reset();
+        for (int i = 0; i < K; i++)
+            if (state[i] > 0) {
+                estimate_enqueue(vs[i], (int32_t)vs[i]->matched.size());
+                VO_TRY((hipError_t)wait_stream(vs[i]->stream));
+            }
+    } else {
+        hipStream_t s = vs[0]->stream;
+        VO_TRY(rec.flush(s));
+        VO_TRY((hipError_t)wait_stream(s));
+        rec.synced();
+    }
+    VO_TRY(hipGetLastError());
+    for (int i = 0; i < K; i++) {
+        int32_t r = 0;
+        if (state[i] > 0) {
+            double tr[6];
+            r = estimate_collect(vs[i], tr);
+            if (r > 0) {
+                vector_to_matrix(tr, vs[i]->Tr);
+                vs[i]->Tr_valid = true;
+            }
+        }
+        if (ok) ok[i] = r;
+        good += r > 0;
+    }
+    return good;
 }
 
 int32_t svh_vo_process_matches(svh_vo* v, const svh_p_match* matches, int32_t n) {

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "../../include/svh.h"
+#include "batch_rec.h"
 #include "vo_internal.h"
 
 namespace svh {
@@ -182,13 +183,14 @@ __device__ __forceinline__ int wave_gn_step(const double* J, const double* res, 
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void k_vo_ransac(const svh_p_match* __restrict__ pm, int N,
-                                                  const int32_t* __restrict__ samples, VoCalib c,
-                                                  double* __restrict__ hyp_tr,       // [iters][6]
-                                                  int32_t* __restrict__ hyp_count,   // [iters], -1 = failed
-                                                  uint8_t* __restrict__ hyp_flags) { // [iters][N]
+__device__ __forceinline__ void d_vo_ransac(const svh_p_match* __restrict__ pm, int N,
+                                            const int32_t* __restrict__ samples, VoCalib c,
+                                            double* __restrict__ hyp_tr,       // [iters][6]
+                                            int32_t* __restrict__ hyp_count,   // [iters], -1 = failed
+                                            uint8_t* __restrict__ hyp_flags,   // [iters][N]
+                                            int k) {
     __shared__ double s_tr[6], s_J[12 * 6], s_res[12];
-    const int k = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     if (lane < 6) s_tr[lane] = 0.0;
     const int pt = lane / 6, col = lane - 6 * pt;      // lanes 0..17: (sampled match, parameter)
     svh_p_match m = pm[0];
@@ -299,13 +301,13 @@ __device__ __forceinline__ int vo_refine_loop(double* J, double* res, const svh_
 
 // One workgroup of 256.  The Jacobian / residual rows of the inliers live in LDS when they fit
 // (lds_rows >= 4 * inliers; the launcher sizes the dynamic LDS from N), else in global scratch.
-__global__ __launch_bounds__(256) void k_vo_refine(const svh_p_match* __restrict__ pm, int N, int iters,
-                                                   VoCalib c, const double* __restrict__ hyp_tr,
-                                                   const int32_t* __restrict__ hyp_count,
-                                                   const uint8_t* __restrict__ hyp_flags,
-                                                   double* __restrict__ Jg, double* __restrict__ resg,
-                                                   int lds_rows, VoResult* __restrict__ out,
-                                                   int32_t* __restrict__ out_inliers) {
+__device__ __forceinline__ void d_vo_refine(const svh_p_match* __restrict__ pm, int N, int iters,
+                                            VoCalib c, const double* __restrict__ hyp_tr,
+                                            const int32_t* __restrict__ hyp_count,
+                                            const uint8_t* __restrict__ hyp_flags,
+                                            double* __restrict__ Jg, double* __restrict__ resg,
+                                            int lds_rows, VoResult* __restrict__ out,
+                                            int32_t* __restrict__ out_inliers) {
     extern __shared__ double s_rows[];   // [lds_rows][6] J then [lds_rows] residuals
     __shared__ double s_tr[6];
     __shared__ int s_best, s_status, s_scan[256];
@@ -361,34 +363,78 @@ __global__ __launch_bounds__(256) void k_vo_refine(const svh_p_match* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_vo_upload(const uint4* __restrict__ host, uint4* __restrict__ dev,
-                                                   size_t n16) {
+// plain and batched forms (batch_rec.h: job blockIdx.z of a table in device memory)
+struct VoRansacJob { const svh_p_match* pm; int N; const int32_t* samples; VoCalib c; double* hyp_tr; int32_t* hyp_count; uint8_t* hyp_flags; int iters; };
+__global__ __launch_bounds__(64) void k_vo_ransac(VoRansacJob a) {
+    d_vo_ransac(a.pm, a.N, a.samples, a.c, a.hyp_tr, a.hyp_count, a.hyp_flags, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(64) void k_vo_ransac_b(const VoRansacJob* J) {
+    const VoRansacJob& a = J[blockIdx.z];
+    if ((int)blockIdx.x >= a.iters) return;
+    d_vo_ransac(a.pm, a.N, a.samples, a.c, a.hyp_tr, a.hyp_count, a.hyp_flags, (int)blockIdx.x);
+}
+struct VoRefineJob {
+    const svh_p_match* pm; int N, iters; VoCalib c; const double* hyp_tr; const int32_t* hyp_count; const uint8_t* hyp_flags;
+    double *Jg, *resg; int lds_rows; VoResult* out; int32_t* out_inliers;
+};
+__global__ __launch_bounds__(256) void k_vo_refine(VoRefineJob a) {
+    d_vo_refine(a.pm, a.N, a.iters, a.c, a.hyp_tr, a.hyp_count, a.hyp_flags, a.Jg, a.resg, a.lds_rows, a.out, a.out_inliers);
+}
+__global__ __launch_bounds__(256) void k_vo_refine_b(const VoRefineJob* J) {
+    const VoRefineJob& a = J[blockIdx.z];
+    d_vo_refine(a.pm, a.N, a.iters, a.c, a.hyp_tr, a.hyp_count, a.hyp_flags, a.Jg, a.resg, a.lds_rows, a.out, a.out_inliers);
+}
+struct VoUploadJob { const uint4* host; uint4* dev; size_t n16; };
+__global__ __launch_bounds__(256) void k_vo_upload(VoUploadJob a) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n16) dev[i] = host[i];
+    if (i < a.n16) a.dev[i] = a.host[i];
+}
+__global__ __launch_bounds__(256) void k_vo_upload_b(const VoUploadJob* J) {
+    const VoUploadJob a = J[blockIdx.z];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < a.n16) a.dev[i] = a.host[i];
+}
+static void b_vo_ransac(const void* jobs, int njobs, unsigned gx, unsigned gy, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL(k_vo_ransac_b, dim3(gx, gy, (unsigned)njobs), dim3(64), lds, s, reinterpret_cast<const VoRansacJob*>(jobs));
+}
+static void b_vo_refine(const void* jobs, int njobs, unsigned gx, unsigned gy, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL(k_vo_refine_b, dim3(gx, gy, (unsigned)njobs), dim3(256), lds, s, reinterpret_cast<const VoRefineJob*>(jobs));
+}
+static void b_vo_upload(const void* jobs, int njobs, unsigned gx, unsigned gy, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL(k_vo_upload_b, dim3(gx, gy, (unsigned)njobs), dim3(256), lds, s, reinterpret_cast<const VoUploadJob*>(jobs));
 }
 
 void vlaunch_upload(void* stream, const uint8_t* pinned, uint8_t* dev, size_t bytes) {
     const size_t n16 = bytes / 16;
-    hipLaunchKernelGGL(k_vo_upload, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const uint4*>(pinned), reinterpret_cast<uint4*>(dev), n16);
+    const VoUploadJob a = {reinterpret_cast<const uint4*>(pinned), reinterpret_cast<uint4*>(dev), n16};
+    const unsigned gx = (unsigned)((n16 + 255) / 256);
+    if (t_rec) return t_rec->add(b_vo_upload, a, gx);
+    hipLaunchKernelGGL(k_vo_upload, dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
 }
 
 void vlaunch_estimate(void* stream, const svh_p_match* pm, int N, const int32_t* samples, int iters,
                       const VoCalib& c, double* hyp_tr, int32_t* hyp_count, uint8_t* hyp_flags, double* Jg,
                       double* resg, VoResult* out, int32_t* out_inliers) {
     hipStream_t s = (hipStream_t)stream;
-    if (iters > 0)
-        hipLaunchKernelGGL(k_vo_ransac, dim3(iters), dim3(64), 0, s, pm, N, samples, c, hyp_tr, hyp_count,
-                           hyp_flags);
     // dynamic LDS for the refinement rows: 4 rows per match, 7 doubles per row, up to 144 KB
     static bool attr_once = ((void)hipFuncSetAttribute((const void*)k_vo_refine,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       144 * 1024),
+                             (void)hipFuncSetAttribute((const void*)k_vo_refine_b,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        144 * 1024), true);
     (void)attr_once;
     int lds_rows = 4 * N;
     if ((size_t)lds_rows * 7 * sizeof(double) > 144 * 1024) lds_rows = 0;
-    hipLaunchKernelGGL(k_vo_refine, dim3(1), dim3(256), (size_t)lds_rows * 7 * sizeof(double), s, pm, N, iters,
-                       c, hyp_tr, hyp_count, hyp_flags, Jg, resg, lds_rows, out, out_inliers);
+    const VoRansacJob ar = {pm, N, samples, c, hyp_tr, hyp_count, hyp_flags, iters};
+    const VoRefineJob af = {pm, N, iters, c, hyp_tr, hyp_count, hyp_flags, Jg, resg, lds_rows, out, out_inliers};
+    const size_t lds = (size_t)lds_rows * 7 * sizeof(double);
+    if (t_rec) {
+        if (iters > 0) t_rec->add(b_vo_ransac, ar, (unsigned)iters);
+        return t_rec->add(b_vo_refine, af, 1, 1, lds);
+    }
+    if (iters > 0) hipLaunchKernelGGL(k_vo_ransac, dim3(iters), dim3(64), 0, s, ar);
+    hipLaunchKernelGGL(k_vo_refine, dim3(1), dim3(256), lds, s, af);
 }
 
 }  // namespace svh

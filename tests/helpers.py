@@ -725,6 +725,55 @@ class ProductVo(VoBase):
         import svhip as S
         VoBase.__init__(self, S.lib(), "svh_", params)
 
+def _ptr_array(arrs):
+    return (C.c_void_p * len(arrs))(*[None if a is None else a.ctypes.data for a in arrs])
+
+
+def product_vo_process_batch(vos, I1s, I2s, replace=False):
+    """svh_vo_process_batch: one frame for K ProductVo objects; returns (n_ok, per-object return values)"""
+    import svhip as S
+    lib = S.lib()
+    lib.svh_vo_process_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p]
+    K = len(vos)
+    I1s = [np.ascontiguousarray(a, np.uint8) for a in I1s]
+    I2s = [np.ascontiguousarray(a, np.uint8) for a in I2s]
+    dims = (C.c_int32 * 3)(I1s[0].shape[1], I1s[0].shape[0], I1s[0].shape[1])
+    hs = (C.c_void_p * K)(*[v.h for v in vos])
+    ok = np.full(K, -99, np.int32)
+    rc = lib.svh_vo_process_batch(hs, K, _ptr_array(I1s), _ptr_array(I2s), dims, int(replace), _p(ok))
+    if rc < 0:
+        raise S.SvhError(rc, S.last_error())
+    return rc, ok
+
+
+def product_matcher_batch(ms, I1s, I2s, method, Trs=None, replace=False, push=True):
+    """svh_matcher_push_back_batch (+ svh_matcher_match_features_batch when method is not None)"""
+    import svhip as S
+    lib = S.lib()
+    lib.svh_matcher_push_back_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.svh_matcher_match_features_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    K = len(ms)
+    hs = (C.c_void_p * K)(*[m.h for m in ms])
+    if push:
+        I1s = [np.ascontiguousarray(a, np.uint8) for a in I1s]
+        I2s = None if I2s is None else [None if a is None else np.ascontiguousarray(a, np.uint8) for a in I2s]
+        dims = (C.c_int32 * 3)(I1s[0].shape[1], I1s[0].shape[0], I1s[0].shape[1])
+        rc = lib.svh_matcher_push_back_batch(hs, K, _ptr_array(I1s), None if I2s is None else _ptr_array(I2s),
+                                             dims, int(replace))
+        if rc < 0:
+            raise S.SvhError(rc, S.last_error())
+    if method is not None:
+        trs = None
+        if Trs is not None:
+            keep = [None if t is None else np.ascontiguousarray(t, np.float64) for t in Trs]
+            trs = _ptr_array(keep)
+        rc = lib.svh_matcher_match_features_batch(hs, K, method, trs)
+        if rc < 0:
+            raise S.SvhError(rc, S.last_error())
+    return 0
+
+
 def synth_vo_matches(n, seed=0, motion=(0.004, -0.01, 0.002, 0.03, -0.01, -0.8), outliers=0.25,
                      noise=0.3, calib=(645.24, 635.96, 194.13, 0.5707), size=(1344, 391)):
     """quad matches of random 3-D points seen before / after a known rigid motion (the model of

@@ -1,0 +1,216 @@
+"""GPU tests of the lockstep entries (svh_matcher_push_back_batch, svh_matcher_match_features_batch,
+svh_vo_process_batch): K objects driven as one launch per kernel must give, object by object, exactly what
+K separate calls give -- feature tables, match indices and coordinates, motion, inliers: bit-exact.  The
+unbatched calls are themselves pinned to the reference by test_matcher_gpu.py / test_vo_gpu.py; one case
+here also checks a batched object against the golden reference output directly."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+LIBC = C.CDLL(None)
+
+
+def quad():
+    return [H.read_pgm(os.path.join(H.GOLDEN, "viso_%s.pgm" % k)) for k in ("I1p", "I2p", "I1c", "I2c")]
+
+
+def variant(im, k):
+    """object k's sequence: the quad shifted by 3k columns (stereo geometry kept), every other one mirrored
+    top-down, so that the K objects carry different feature counts"""
+    out = [np.roll(a, 3 * k, axis=1) for a in im]
+    if k % 2:
+        out = [np.ascontiguousarray(a[::-1]) for a in out]
+    return out
+
+
+def plain_matcher(prm):
+    m = H.ProductMatcher(prm)
+    m.lib.svh_matcher_set_taps(C.c_void_p(m.h), 0)   # taps keep every stage and force the one-by-one path
+    return m
+
+
+def same_matcher_state(a, b, what):
+    for tb in range(8):
+        x, y = a.features(tb), b.features(tb)
+        assert x.shape == y.shape and (x == y).all(), (what, "table", tb)
+    x, y = a.matches(), b.matches()
+    assert len(x) == len(y), (what, len(x), len(y))
+    assert (x == y).all(), what
+
+
+@pytest.mark.parametrize("kw,method,with_tr", [
+    ({}, 2, False), ({}, 2, True), ({"half_resolution": 0}, 2, False), ({"multi_stage": 0}, 2, False),
+    ({"refinement": 2}, 2, True), ({"refinement": 0}, 0, False), ({}, 1, False),
+    ({"nms_n": 5, "nms_tau": 30, "match_binsize": 40}, 2, False), ({"refinement": 2, "half_resolution": 0}, 1, False),
+])
+def test_matcher_batch_equals_separate_calls(kw, method, with_tr):
+    K = 5
+    prm = H.matcher_defaults(**kw)
+    prm.f, prm.cu, prm.cv, prm.base = 645.24, 635.96, 194.13, 0.5707
+    im = quad()
+    seqs = [variant(im, k) for k in range(K)]
+    tr = None
+    if with_tr:
+        T = np.eye(4)
+        T[2, 3] = -0.8
+        T[0, 3] = 0.02
+        tr = [T + 0.001 * k * np.eye(4)[[1, 0, 2, 3]] for k in range(K)]
+    one = [plain_matcher(prm) for _ in range(K)]
+    for k, m in enumerate(one):
+        m.push_back(seqs[k][0], seqs[k][1])
+        m.push_back(seqs[k][2], seqs[k][3])
+        m.match(method, None if tr is None else tr[k])
+    bat = [plain_matcher(prm) for _ in range(K)]
+    H.product_matcher_batch(bat, [s[0] for s in seqs], [s[1] for s in seqs], None)
+    H.product_matcher_batch(bat, [s[2] for s in seqs], [s[3] for s in seqs], method, tr)
+    for k in range(K):
+        assert len(one[k].matches()) > 50
+        same_matcher_state(one[k], bat[k], ("object", k))
+    # a second frame through the ring buffer, replace = 1 on top, then once more
+    for rep in (True, False):
+        for k, m in enumerate(one):
+            m.push_back(seqs[k][0], seqs[k][1], replace=rep)
+            m.match(method, None if tr is None else tr[k])
+        H.product_matcher_batch(bat, [s[0] for s in seqs], [s[1] for s in seqs], method, tr, replace=rep)
+        for k in range(K):
+            same_matcher_state(one[k], bat[k], ("object", k, "replace", rep))
+
+
+def test_matcher_batch_object_equals_golden_reference_output():
+    z = np.load(os.path.join(H.GOLDEN, "viso_quad_default.npz"))
+    prm = H.MatcherParams.from_buffer_copy(z["params"].tobytes())
+    im = quad()
+    K = 3
+    seqs = [variant(im, k) for k in range(K)]
+    seqs[1] = im                                   # object 1 carries the golden quad itself
+    bat = [plain_matcher(prm) for _ in range(K)]
+    H.product_matcher_batch(bat, [s[0] for s in seqs], [s[1] for s in seqs], None)
+    H.product_matcher_batch(bat, [s[2] for s in seqs], [s[3] for s in seqs], int(z["method"]))
+    got, want = bat[1].matches(), z["dense"]
+    assert len(got) == len(want)
+    for f in ("i1p", "i2p", "i1c", "i2c"):
+        assert np.array_equal(got[f], want[f]), f
+    assert (got == want).all()
+    for tb in range(8):
+        assert np.array_equal(bat[1].features(tb), z["table_" + H.M_TABLES[tb]])
+
+
+def test_matcher_batch_with_objects_that_cannot_match_or_differ():
+    """an object without a previous frame returns silently (matcher.cpp:216-259) and keeps no matches while the
+    others run in lockstep; objects with other parameters send the whole call down the one-by-one path"""
+    prm = H.matcher_defaults()
+    im = quad()
+    K = 4
+    seqs = [variant(im, k) for k in range(K)]
+    bat = [plain_matcher(prm) for _ in range(K)]
+    H.product_matcher_batch(bat[:3], [s[0] for s in seqs[:3]], [s[1] for s in seqs[:3]], None)
+    H.product_matcher_batch(bat, [s[2] for s in seqs], [s[3] for s in seqs], 2)   # object 3: first frame
+    assert len(bat[3].matches()) == 0
+    for k in range(3):
+        m = plain_matcher(prm)
+        m.push_back(seqs[k][0], seqs[k][1])
+        m.push_back(seqs[k][2], seqs[k][3])
+        m.match(2)
+        same_matcher_state(m, bat[k], ("object", k))
+    # single-image flow (I2 = NULL) in lockstep
+    flow = [plain_matcher(prm) for _ in range(3)]
+    H.product_matcher_batch(flow, [s[0] for s in seqs[:3]], None, None)
+    H.product_matcher_batch(flow, [s[2] for s in seqs[:3]], None, 0)
+    for k in range(3):
+        m = plain_matcher(prm)
+        m.push_back(seqs[k][0])
+        m.push_back(seqs[k][2])
+        m.match(0)
+        same_matcher_state(m, flow[k], ("flow", k))
+    # mixed parameters
+    mixed = [plain_matcher(prm), plain_matcher(H.matcher_defaults(nms_n=4)), plain_matcher(prm)]
+    H.product_matcher_batch(mixed, [s[0] for s in seqs[:3]], [s[1] for s in seqs[:3]], None)
+    H.product_matcher_batch(mixed, [s[2] for s in seqs[:3]], [s[3] for s in seqs[:3]], 2)
+    m = plain_matcher(H.matcher_defaults(nms_n=4))
+    m.push_back(seqs[1][0], seqs[1][1])
+    m.push_back(seqs[1][2], seqs[1][3])
+    m.match(2)
+    same_matcher_state(m, mixed[1], "mixed")
+    # argument errors
+    import svhip as S
+    with pytest.raises(S.SvhError):
+        H.product_matcher_batch([bat[0], bat[0]], [seqs[0][0]] * 2, [seqs[0][1]] * 2, None)
+
+
+def run_vo(vos, seqs, frames, batched):
+    LIBC.srand(7)
+    log = []
+    for i in range(frames):
+        a = [s[0] if i % 2 == 0 else s[2] for s in seqs]
+        b = [s[1] if i % 2 == 0 else s[3] for s in seqs]
+        if batched:
+            _, ok = H.product_vo_process_batch(vos, a, b)
+            ok = list(ok)
+        else:
+            ok = [vo.process(a[k], b[k]) for k, vo in enumerate(vos)]
+        log.append((ok, [vo.motion().copy() for vo in vos], [vo.inliers().copy() for vo in vos],
+                    [vo.matches().copy() for vo in vos]))
+    return log
+
+
+@pytest.mark.parametrize("kw", [{}, {"ransac_iters": 64, "reweighting": 0}])
+def test_vo_batch_equals_loop_of_process_calls(kw):
+    """same srand, same draw order: the lockstep call reproduces the loop bit for bit (bootstrap frames
+    included, which the batch entry runs one by one)"""
+    K, frames = 6, 7
+    prm = H.vo_defaults(**kw)
+    im = quad()
+    seqs = [variant(im, k) for k in range(K)]
+    loop = run_vo([H.ProductVo(prm) for _ in range(K)], seqs, frames, False)
+    bat = run_vo([H.ProductVo(prm) for _ in range(K)], seqs, frames, True)
+    assert sum(sum(o == 1 for o in f[0]) for f in loop) >= K * (frames - 2)
+    for i in range(frames):
+        assert loop[i][0] == bat[i][0], ("return values", i)
+        for k in range(K):
+            assert np.array_equal(loop[i][1][k], bat[i][1][k]), ("motion", i, k)
+            assert np.array_equal(loop[i][2][k], bat[i][2][k]), ("inliers", i, k)
+            assert (loop[i][3][k] == bat[i][3][k]).all() and len(loop[i][3][k]) == len(bat[i][3][k]), ("matches", i, k)
+
+
+def test_two_threads_each_driving_a_batch():
+    """two host threads, each with its own K objects (own recorder, shared helper pool): match indices equal
+    the single-threaded run"""
+    prm = H.matcher_defaults()
+    im = quad()
+    K = 4
+    seqs = [variant(im, k) for k in range(2 * K)]
+    want = []
+    for k in range(2 * K):
+        m = plain_matcher(prm)
+        m.push_back(seqs[k][0], seqs[k][1])
+        m.push_back(seqs[k][2], seqs[k][3])
+        m.match(2)
+        want.append(m.matches())
+    groups = [[plain_matcher(prm) for _ in range(K)] for _ in range(2)]
+    errs = []
+
+    def work(g):
+        try:
+            sq = seqs[g * K:(g + 1) * K]
+            for _ in range(3):
+                H.product_matcher_batch(groups[g], [s[0] for s in sq], [s[1] for s in sq], None)
+                H.product_matcher_batch(groups[g], [s[2] for s in sq], [s[3] for s in sq], 2)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(g,)) for g in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for g in range(2):
+        for k in range(K):
+            got = groups[g][k].matches()
+            assert len(got) == len(want[g * K + k]) and (got == want[g * K + k]).all(), (g, k)

@@ -7,7 +7,8 @@
 //   make -C stereo-vision_amd sanitize_viso    builds it with -fsanitize=thread and with
 //                                              -fsanitize=address,undefined and runs both, K = 16 sequences
 // What is checked: data races and memory errors of K VisualOdometryStereo objects driven from K threads at
-// once (SURVEY 8(e) "replicas only"), plus one thread that creates and destroys Matchers meanwhile.
+// once (SURVEY 8(e) "replicas only"), one thread that creates and destroys Matchers meanwhile, and two threads
+// that each drive K/2 objects in lockstep through svh_vo_process_batch (recorder, helper pool, phase barriers).
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
@@ -63,7 +64,10 @@ int fail(int code, const std::string& msg) { t_err = msg; return code; }
 
 // ---------------------------------------------------------------- stub launchers
 static uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+// (the stub launchers run at once even while a batch is being recorded: the recorder stays empty, its flush is a no-op)
 void mlaunch_upload(void*, const uint8_t* pinned, uint8_t* dev, size_t bytes) { memcpy(dev, pinned, bytes); }
+void mlaunch_copy(void*, void* dst, const void* src, size_t bytes, int) { memcpy(dst, src, bytes); }
+void mlaunch_fill(void*, void* dst, int v, size_t bytes) { memset(dst, v, bytes); }
 void mlaunch_half(void*, const uint8_t*, int, uint8_t*, int, int, int) {}
 void mlaunch_filters(void*, const uint8_t*, int, int, int, uint8_t*, uint8_t*, int16_t*, int16_t*) {}
 int mnms_blocks(int extent, int n, int margin) { const int e = extent - 2 * margin; return e <= 0 ? 0 : (e + n) / (n + 1); }
@@ -166,8 +170,36 @@ int main(int argc, char** argv) {
             svh_matcher_destroy(m);
         }
     });
+    // two more threads, each driving K/2 objects in lockstep (svh_vo_process_batch: recorder, helper pool, phases)
+    auto lockstep = [&](int id) {
+        const int n = K / 2 > 1 ? K / 2 : 2;
+        svh_vo_params p;
+        svh_vo_params_default(&p);
+        p.f = 645.2; p.cu = 320.0; p.cv = 100.0; p.base = 0.57;
+        std::vector<svh_vo*> vs(n);
+        for (int i = 0; i < n; i++) vs[i] = svh_vo_create(&p);
+        std::vector<std::vector<uint8_t>> I1(n, std::vector<uint8_t>((size_t)W * H)), I2 = I1;
+        std::vector<const uint8_t*> p1(n), p2(n);
+        std::vector<int32_t> ok(n);
+        const int32_t dims[3] = {W, H, W};
+        for (int f = 0; f < frames; f++) {
+            for (int i = 0; i < n; i++) {
+                for (size_t j = 0; j < I1[i].size(); j++) {
+                    I1[i][j] = (uint8_t)(svh::mix((uint32_t)(j + 977 * f + 31 * i + 7777 * id)) >> 24);
+                    I2[i][j] = (uint8_t)(svh::mix((uint32_t)(j + 977 * f + 31 * i + 7777 * id + 5)) >> 24);
+                }
+                p1[i] = I1[i].data();
+                p2[i] = I2[i].data();
+            }
+            if (svh_vo_process_batch(vs.data(), n, p1.data(), p2.data(), dims, 0, ok.data()) < 0) bad++;
+            for (int i = 0; i < n; i++) matches += svh_vo_num_matches(vs[i]);
+        }
+        for (svh_vo* v : vs) svh_vo_destroy(v);
+    };
+    th.emplace_back(lockstep, 1);
+    th.emplace_back(lockstep, 2);
     for (std::thread& t : th) t.join();
-    printf("sanitize_viso: %d sequences x %d frames + 1 Matcher thread, %ld matches seen, %d failures\n", K, frames,
-           matches.load(), bad.load());
+    printf("sanitize_viso: %d sequences x %d frames + 1 Matcher thread + 2 lockstep threads, %ld matches seen, %d failures\n",
+           K, frames, matches.load(), bad.load());
     return bad.load() ? 1 : 0;
 }
