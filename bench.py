@@ -277,6 +277,61 @@ def vo_replicas_bench(ks=(1, 4, 16), frames=40):
                         "alternating, one host thread per object", "runs": out}
 
 
+def vo_lockstep_bench(shapes=((1, 4), (1, 16), (1, 32), (2, 8), (2, 16), (4, 8)), frames=40, private_rand=True):
+    """the same sequences driven in LOCKSTEP: svh_vo_process_batch, one launch per kernel over the K objects of a
+    call (blockIdx.z = object), host steps (row packing, outlier votes, prior statistics) on the library's
+    helper threads.  shapes = (host threads, objects per call): with two or more calling threads one group's
+    host steps overlap the other's device steps.  private_rand: every object draws from its own generator
+    (glibc's srand(0) sequence) instead of the process-wide rand(), whose lock the calling threads contend for
+    and whose draw order forces the bucketing of a call's objects to run one after the other.  Aggregate stereo frames/s; per object the results equal
+    svh_vo_process calls (tests/test_batch_gpu.py)."""
+    import resource
+    import threading
+    import helpers as Hh
+    im = [Hh.read_pgm(os.path.join(Hh.GOLDEN, "viso_%s.pgm" % k)) for k in ("I1p", "I2p", "I1c", "I2c")]
+    prm = Hh.vo_defaults()
+    out = []
+    for T, K in shapes:
+        groups = []
+        for g in range(T):
+            vos = [Hh.ProductVo(prm, private_rand=0 if private_rand else None) for _ in range(K)]
+            # object k sees the quad shifted by 3k columns: different sequences
+            seq = [[np.roll(a, 3 * (g * K + k), axis=1) for a in im] for k in range(K)]
+            even = ([s[0] for s in seq], [s[1] for s in seq])
+            odd = ([s[2] for s in seq], [s[3] for s in seq])
+            for i in range(4):              # allocations, bootstrap (run one by one inside the entry), warm-up
+                Hh.product_vo_process_batch(vos, *(even if i % 2 == 0 else odd))
+            groups.append((vos, even, odd))
+        good = [0] * T
+        go = threading.Barrier(T + 1)
+
+        def worker(g):
+            vos, even, odd = groups[g]
+            go.wait()
+            for i in range(frames):
+                n, _ = Hh.product_vo_process_batch(vos, *(even if i % 2 == 0 else odd))
+                good[g] += n
+        th = [threading.Thread(target=worker, args=(g,)) for g in range(T)]
+        for t in th:
+            t.start()
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
+        go.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        cpu = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
+        out.append({"calling_threads": T, "objects_per_call": K, "frames_per_s": T * K * frames / dt,
+                    "call_ms": 1e3 * dt / frames, "frames_ok": int(sum(good)), "frames": T * K * frames,
+                    "host_cores_used": round(cpu / dt, 2)})
+        del groups
+    return {"workload": "VisualOdometryStereo objects in lockstep (svh_vo_process_batch), libviso2/img quad "
+                        "1344x391 alternating, shifted 3k columns for object k",
+            "random_numbers": "private per-object streams with glibc's srand(0) sequence (svh_vo_set_private_rand)"
+                              if private_rand else "libc rand(), drawn in object order", "runs": out}
+
+
 def vo_replicas_processes(procs=4, per_proc=4, frames=60):
     """the same K = procs x per_proc sequences as `procs` PROCESSES with `per_proc` objects each (every
     process has its own HIP runtime: what serialises K objects of one process is the runtime's launch
@@ -1054,6 +1109,7 @@ def main():
             out["map_fusion"] = map_bench()
             out["visual_odometry"]["replicas"] = vo_replicas_bench()
             out["visual_odometry"]["replicas"]["as_processes"] = vo_replicas_processes()
+            out["visual_odometry"]["lockstep"] = vo_lockstep_bench()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(I1, I2, params, what, budget_s=args.cpu_budget,
                                                workers=int(avail) if args.workload == "kitti" else 0)

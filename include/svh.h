@@ -364,6 +364,16 @@ void    svh_vo_destroy(svh_vo* v);
  * returns 1 (true), 0 (false: motion estimate failed) or a negative SVH_ERR_* */
 int32_t svh_vo_process(svh_vo* v, const uint8_t* I1, const uint8_t* I2, const int32_t* dims,
                        int32_t replace);
+/* The random numbers of bucketFeatures (matcher.cpp:297-343) and getRandomSample (viso.cpp:130-153).  Default
+ * (enable = 0): libc rand(), the process-wide stream the reference draws from after its srand(0) (viso.cpp:36).
+ * enable = 1: the object draws from a PRIVATE generator that reproduces glibc's srand(seed) / rand() sequence,
+ * i.e. it sees exactly the numbers a reference object sees when it has the process to itself (seed 0 = the
+ * reference's constructor), independent of other objects and threads, and without glibc's rand() lock, for which
+ * K threads otherwise contend.  With private streams svh_vo_process_batch also runs the bucketing of its objects
+ * in parallel. */
+void svh_vo_set_private_rand(svh_vo* v, int32_t enable, uint32_t seed);
+/* the first n numbers of that generator for `seed` (== srand(seed); rand() x n with glibc): lets tests pin it */
+void svh_rand_sequence(uint32_t seed, int32_t* out, int32_t n);
 /* svh_vo_process for K objects in lockstep (one frame of K sequences): batched Matcher steps, the K motion
  * estimates in two launches.  libc rand() is drawn in the order of K svh_vo_process calls, so with the same
  * srand() the results are bit-identical to that loop.  ok[i] (optional) receives the per-object return value;

@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <functional>
 #include <vector>
 
 namespace svh {
@@ -71,6 +72,8 @@ struct BatchRec {
 extern thread_local BatchRec* t_rec;
 // the calling thread's recorder (its arena is kept for the thread's lifetime)
 BatchRec& batch_recorder();
+// fn(0..n-1) on the library's parked helper threads and the caller; returns when all are done
+void batch_parallel_for(int n, const std::function<void(int)>& fn);
 
 }  // namespace svh
 #endif

@@ -226,11 +226,14 @@ struct DevView {
     int32_t *off[2] = {nullptr, nullptr}, *ids[2] = {nullptr, nullptr};
     int32_t nbins = 0;
     int32_t off_cap = 0;      // bins the off[] arrays were allocated for
-    std::vector<uint8_t> host;              // full image on the host (getGain)
+    uint8_t* stage = nullptr;               // pinned: the packed image (upload source, and getGain's host copy),
+                                            // h rows of bpl bytes + one zero row
 
     void release() {
         (void)hipFree(I); (void)hipFree(Ih); (void)hipFree(du); (void)hipFree(dv); (void)hipFree(du_full);
         (void)hipFree(dv_full); (void)hipFree(f1); (void)hipFree(f2); (void)hipFree(cnt);
+        (void)hipHostFree(stage);
+        stage = nullptr;
         for (int k = 0; k < 2; k++) {
             (void)hipFree(tab[k]); (void)hipFree(off[k]); (void)hipFree(ids[k]);
             tab[k] = off[k] = ids[k] = nullptr;
@@ -275,8 +278,6 @@ struct svh_matcher {
     int32_t ranges_cap = 0;
     float* h_ranges = nullptr;                  // pinned copy of `ranges` (batched calls upload it from a kernel)
     size_t h_ranges_cap = 0;
-    uint8_t* h_stage[2] = {nullptr, nullptr};   // pinned upload staging, one per camera
-    size_t h_stage_cap[2] = {0, 0};
     svh_p_match* h_pm = nullptr;                // pinned download staging for match lists
     int32_t* h_cnt = nullptr;                   // pinned: match count
     int32_t* h_n = nullptr;                     // pinned: feature counts [camera][sparse, dense]
@@ -297,6 +298,20 @@ static double mnow_ms() {
 }
 static const bool g_mtiming = getenv("SVH_MATCHER_TIMING") != nullptr;
 enum { T_PACK = 0, T_PUSH_GPU, T_SPARSE, T_OUT1, T_PRIOR, T_DENSE, T_OUT2 };
+// SVH_MATCHER_TIMING=1: wall-clock of the phases of the lockstep entries, printed at exit
+struct BatchTiming {
+    double t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t calls[2] = {0, 0};
+    ~BatchTiming() {
+        if (!calls[0] || !calls[1]) return;
+        const double a = 1.0 / (double)calls[0], b = 1.0 / (double)calls[1];
+        fprintf(stderr, "[svh lockstep timing] pushBack: prepare %.3f, pack %.3f, record %.3f, flush %.3f, gpu wait %.3f ms | "
+                        "matchFeatures: sparse record+flush %.3f, wait %.3f, votes+prior %.3f, dense record+flush %.3f, "
+                        "wait %.3f, votes %.3f ms\n",
+                t[0] * a, t[1] * a, t[2] * a, t[3] * a, t[4] * a, t[5] * b, t[6] * b, t[7] * b, t[8] * b, t[9] * b, t[10] * b);
+    }
+};
+static BatchTiming g_btime;
 
 namespace svh {
 
@@ -324,6 +339,10 @@ static int ensure_view(svh_matcher* m, DevView& V, int32_t w, int32_t h, int32_t
         HIP_TRY(dalloc(&V.du_full, fn));
         HIP_TRY(dalloc(&V.dv_full, fn));
     }
+    // one zero row past the image: getGain clamps its window to [0,H] INCLUSIVE like the reference
+    // (matcher.cpp:362-371), whose read of row H is out of bounds; here it reads zeros
+    HIP_TRY(hipHostMalloc((void**)&V.stage, fn + bpl));
+    memset(V.stage + fn, 0, bpl);
     HIP_TRY(dalloc(&V.cnt, 2));
     HIP_TRY(hipMemsetAsync(V.cnt, 0, 2 * sizeof(int32_t), m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));   // (re)allocation path only; the cameras use two streams
@@ -367,37 +386,27 @@ static int ensure_scratch(svh_matcher* m, int32_t slot_need, int32_t pm_need, si
 // M1..M5  Matcher::computeFeatures   matcher.cpp:780-878, in two steps: the host packs the rows, then the
 // device work is enqueued (or, in a batched call, recorded)
 static int features_pack(svh_matcher* m, DevView& V, int cam, const uint8_t* src, int32_t pitch) {
-    hipStream_t s = cam == 1 ? m->stream2 : m->stream;
-    const size_t fn = (size_t)V.bpl * V.h;
-    if (fn > m->h_stage_cap[cam]) {
-        HIP_TRY(hipStreamSynchronize(s));
-        (void)hipHostFree(m->h_stage[cam]);
-        HIP_TRY(hipHostMalloc((void**)&m->h_stage[cam], fn));
-        m->h_stage_cap[cam] = fn;
-    }
-    // rows are packed at the aligned pitch in pinned memory, then one linear DMA;
-    // the previous pushBack ended with a stream sync, so the staging buffer is free
-    uint8_t* stage = m->h_stage[cam];
-    // one zero row past the image: getGain clamps its window to [0,H] INCLUSIVE like the
-    // reference (matcher.cpp:362-371), whose read of row H is out of bounds; here it reads zeros
-    V.host.assign(fn + V.bpl, 0);
+    (void)m; (void)cam;
+    // rows are packed at the aligned pitch into the view's pinned buffer (the ring buffer double-buffers it:
+    // the previous frame's copy stays valid for getGain), then one linear DMA
     for (int32_t v = 0; v < V.h; v++) {
-        uint8_t* row = stage + (size_t)v * V.bpl;
+        uint8_t* row = V.stage + (size_t)v * V.bpl;
         memcpy(row, src + (size_t)v * pitch, V.w);
         memset(row + V.w, 0, V.bpl - V.w);
     }
-    memcpy(V.host.data(), stage, fn);
     return SVH_OK;
 }
 
-static int features_enqueue(svh_matcher* m, DevView& V, int cam, double* tf) {
+static int features_enqueue(svh_matcher* m, DevView& V, int cam, double* tf, bool uploaded = false) {
     const svh_matcher_params& p = m->p;
     hipStream_t s = cam == 1 ? m->stream2 : m->stream;
     const size_t fn = (size_t)V.bpl * V.h;
-    const uint8_t* stage = m->h_stage[cam];
+    const uint8_t* stage = V.stage;
     auto ftick = [&](int i) { if (g_mtiming && tf) tf[i] = mnow_ms(); };
     ftick(1);
-    if (fn % 16 == 0)
+    if (uploaded)
+        ;   // (a lockstep call: issued by the thread that packed the image)
+    else if (fn % 16 == 0)
         mlaunch_upload(s, stage, V.I, fn);
     else
         mlaunch_copy(s, V.I, stage, fn, hipMemcpyHostToDevice);   // (bpl is a multiple of 16: not taken)
@@ -682,6 +691,50 @@ static int run_matching(svh_matcher* m, int dense, int32_t method, bool use_prio
     return SVH_OK;
 }
 
+// Matcher::bucketFeatures   matcher.cpp:297-343; draws from `rs` (libc rand() or the caller's private stream)
+int32_t bucket_features(svh_matcher* m, int32_t max_features, float bw, float bh, RandStream& rs) {
+    if (!m) return 0;
+    float u_max = 0, v_max = 0;
+    for (const svh_p_match& q : m->m2) {
+        if (q.u1c > u_max) u_max = q.u1c;
+        if (q.v1c > v_max) v_max = q.v1c;
+    }
+    const int32_t cols = (int32_t)floorf(u_max / bw) + 1, rows = (int32_t)floorf(v_max / bh) + 1;
+    // counting sort into the buckets (stable: the order inside a bucket is the order of the match list)
+    const size_t nb = (size_t)cols * rows, n = m->m2.size();
+    std::vector<int32_t> start(nb + 1, 0), cell(n);
+    for (size_t i = 0; i < n; i++) {
+        const svh_p_match& q = m->m2[i];
+        cell[i] = (int32_t)floorf(q.v1c / bh) * cols + (int32_t)floorf(q.u1c / bw);
+        start[cell[i] + 1]++;
+    }
+    for (size_t b = 0; b < nb; b++) start[b + 1] += start[b];
+    std::vector<int32_t> order(n), fill(start.begin(), start.end() - 1);
+    for (size_t i = 0; i < n; i++) order[fill[cell[i]]++] = (int32_t)i;
+    std::vector<svh_p_match> kept;
+    for (size_t b = 0; b < nb; b++) {
+        int32_t* o = order.data() + start[b];
+        const size_t len = (size_t)(start[b + 1] - start[b]);
+        // same shuffle as std::random_shuffle(first,last) of libstdc++: rand() % (i+1)
+        for (size_t i = 1; i < len; i++) std::swap(o[i], o[(size_t)rs.next() % (i + 1)]);
+        for (size_t i = 0; i < len && (int32_t)i < max_features; i++) kept.push_back(m->m2[o[i]]);
+    }
+    m->m2.swap(kept);
+    return (int32_t)m->m2.size();
+}
+
+void batch_parallel_for(int n, const std::function<void(int)>& fn) {
+    const bool was = t_in_batch;
+    t_in_batch = true;
+    BatchPool::get().parallel_for(n, [&](int i) {
+        const bool w = t_in_batch;
+        t_in_batch = true;
+        fn(i);
+        t_in_batch = w;
+    });
+    t_in_batch = was;
+}
+
 }  // namespace svh
 
 extern "C" {
@@ -740,8 +793,8 @@ void svh_matcher_destroy(svh_matcher* m) {
         (void)hipFree(m->cursor);
         (void)hipFree(m->pm_slots);
         (void)hipFree(m->pm_out); (void)hipFree(m->pm_flags); (void)hipFree(m->pm_count);
-        (void)hipFree(m->pixel_owner); (void)hipFree(m->ranges_dev); (void)hipHostFree(m->h_stage[0]);
-        (void)hipHostFree(m->h_stage[1]); (void)hipHostFree(m->h_pm); (void)hipHostFree(m->h_cnt);
+        (void)hipFree(m->pixel_owner); (void)hipFree(m->ranges_dev);
+        (void)hipHostFree(m->h_pm); (void)hipHostFree(m->h_cnt);
         (void)hipHostFree(m->h_n);
         (void)hipHostFree(m->h_ranges);
         (void)hipStreamDestroy(m->stream);
@@ -852,10 +905,14 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
         return SVH_OK;
     };
     if (!lockstep) return serial();
+    double tb[6] = {0, 0, 0, 0, 0, 0};
+    auto btick = [&](int i) { if (g_mtiming) tb[i] = mnow_ms(); };
+    btick(0);
     for (int i = 0; i < K; i++) {
         const int32_t rc = push_prepare(ms[i], I1[i], I2 ? I2[i] : nullptr, dims, replace);
         if (rc) return rc;
     }
+    btick(1);
     const int ncam = (I2 && I2[0]) ? 2 : 1;
     std::vector<int> rcs((size_t)K * ncam, 0);
     t_in_batch = true;
@@ -863,25 +920,31 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
         (void)hipSetDevice(ms[0]->device);
         svh_matcher* m = ms[j / ncam];
         const int cam = j % ncam;
-        rcs[j] = features_pack(m, m->cur[cam], cam, cam ? I2[j / ncam] : I1[j / ncam], dims[2]);
+        DevView& V = m->cur[cam];
+        rcs[j] = features_pack(m, V, cam, cam ? I2[j / ncam] : I1[j / ncam], dims[2]);
+        // the image goes to the device while the other threads still pack theirs (all on the call's stream)
+        if (!rcs[j]) mlaunch_upload(ms[0]->stream, V.stage, V.I, (size_t)V.bpl * V.h);
     });
     t_in_batch = false;
     for (int rc : rcs)
         if (rc) return rc;
+    btick(2);
     BatchRec& rec = batch_recorder();
     rec.reset();
     t_rec = &rec;
     int rc = SVH_OK;
     for (int i = 0; i < K && !rc; i++) {
         rec.begin_object();
-        for (int cam = 0; cam < ncam && !rc; cam++) rc = features_enqueue(ms[i], ms[i]->cur[cam], cam, nullptr);
+        for (int cam = 0; cam < ncam && !rc; cam++) rc = features_enqueue(ms[i], ms[i]->cur[cam], cam, nullptr, true);
     }
     t_rec = nullptr;
     if (rc) return rc;
+    btick(3);
     hipStream_t s = ms[0]->stream;
     if (rec.broken) {
         // (not reachable with equal parameters and sizes; kept so that a future launcher change cannot corrupt a batch)
         rec.reset();
+        HIP_TRY((hipError_t)wait_stream(s));   // (the uploads issued above)
         for (int i = 0; i < K; i++) {
             for (int cam = 0; cam < ncam; cam++) {
                 rc = features_enqueue(ms[i], ms[i]->cur[cam], cam, nullptr);
@@ -894,10 +957,16 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
         return SVH_OK;
     }
     HIP_TRY(rec.flush(s));
+    btick(4);
     HIP_TRY((hipError_t)wait_stream(s));
     HIP_TRY(hipGetLastError());
     rec.synced();
     for (int i = 0; i < K; i++) push_finish(ms[i], I1[i], I2 ? I2[i] : nullptr);
+    btick(5);
+    if (g_mtiming) {
+        for (int i = 0; i < 5; i++) g_btime.t[i] += tb[i + 1] - tb[i];
+        g_btime.calls[0]++;
+    }
     return SVH_OK;
 }
 
@@ -1019,6 +1088,9 @@ int32_t svh_matcher_match_features_batch(svh_matcher* const* ms, int32_t K, int3
     BatchRec& rec = batch_recorder();
     std::vector<MatchPass> mp(n);
     std::vector<int> rcs(n, 0);
+    double t_wait = 0, tm[5] = {0, 0, 0, 0, 0};
+    auto mtick = [&](int i) { if (g_mtiming) tm[i] = mnow_ms(); };
+    mtick(0); mtick(1); mtick(2);
     // record one device phase over all objects; on a sequence mismatch the objects run one by one instead
     auto device_phase = [&](const std::function<int(int)>& body) -> int {
         rec.reset();
@@ -1043,9 +1115,11 @@ int32_t svh_matcher_match_features_batch(svh_matcher* const* ms, int32_t K, int3
             return SVH_OK;
         }
         HIP_TRY(rec.flush(s));
+        const double tw = g_mtiming ? mnow_ms() : 0;
         HIP_TRY((hipError_t)wait_stream(s));
         HIP_TRY(hipGetLastError());
         rec.synced();
+        if (g_mtiming) t_wait += mnow_ms() - tw;
         return SVH_OK;
     };
     auto host_phase = [&](const std::function<int(int)>& body) -> int {
@@ -1069,6 +1143,12 @@ int32_t svh_matcher_match_features_batch(svh_matcher* const* ms, int32_t K, int3
             return r;
         });
         if (rc) return rc;
+        mtick(1);
+        if (g_mtiming) {
+            g_btime.t[5] += tm[1] - tm[0] - t_wait;
+            g_btime.t[6] += t_wait;
+            t_wait = 0;
+        }
         const size_t nr = (size_t)16 * ub * vb;
         for (int i = 0; i < n; i++) {
             svh_matcher* m = part[i];
@@ -1089,6 +1169,8 @@ int32_t svh_matcher_match_features_batch(svh_matcher* const* ms, int32_t K, int3
             return (int)SVH_OK;
         });
         if (rc) return rc;
+        mtick(2);
+        if (g_mtiming) g_btime.t[7] += tm[2] - tm[1];
     }
     rc = device_phase([&](int i) {
         svh_matcher* m = part[i];
@@ -1105,28 +1187,22 @@ int32_t svh_matcher_match_features_batch(svh_matcher* const* ms, int32_t K, int3
     });
     if (rc) return rc;
     for (int i = 0; i < n; i++) match_collect(part[i], mp[i], part[i]->m2);
-    return host_phase([&](int i) { return remove_outliers(part[i]->p, part[i]->m2, method); });
+    mtick(3);
+    rc = host_phase([&](int i) { return remove_outliers(part[i]->p, part[i]->m2, method); });
+    mtick(4);
+    if (g_mtiming) {
+        g_btime.t[8] += tm[3] - tm[2] - t_wait;
+        g_btime.t[9] += t_wait;
+        g_btime.t[10] += tm[4] - tm[3];
+        g_btime.calls[1]++;
+    }
+    return rc;
 }
 
 // Matcher::bucketFeatures   matcher.cpp:297-343 (host; std::random_shuffle like the reference)
 int32_t svh_matcher_bucket_features(svh_matcher* m, int32_t max_features, float bw, float bh) {
-    if (!m) return 0;
-    float u_max = 0, v_max = 0;
-    for (const svh_p_match& q : m->m2) {
-        if (q.u1c > u_max) u_max = q.u1c;
-        if (q.v1c > v_max) v_max = q.v1c;
-    }
-    const int32_t cols = (int32_t)floorf(u_max / bw) + 1, rows = (int32_t)floorf(v_max / bh) + 1;
-    std::vector<std::vector<svh_p_match>> buckets((size_t)cols * rows);
-    for (const svh_p_match& q : m->m2)
-        buckets[(size_t)((int32_t)floorf(q.v1c / bh)) * cols + (int32_t)floorf(q.u1c / bw)].push_back(q);
-    m->m2.clear();
-    for (auto& b : buckets) {
-        // same shuffle as std::random_shuffle(first,last) of libstdc++: rand() % (i+1)
-        for (size_t i = 1; i < b.size(); i++) std::swap(b[i], b[(size_t)rand() % (i + 1)]);
-        for (size_t i = 0; i < b.size() && (int32_t)i < max_features; i++) m->m2.push_back(b[i]);
-    }
-    return (int32_t)m->m2.size();
+    RandStream libc;   // not private: libc rand()
+    return bucket_features(m, max_features, bw, bh, libc);
 }
 
 int32_t svh_matcher_get_matches(svh_matcher* m, svh_p_match* out, int32_t cap) {
@@ -1141,7 +1217,7 @@ float svh_matcher_get_gain(svh_matcher* m, const int32_t* inliers, int32_t n) {
     auto meanf = [](const DevView& V, int32_t u0, int32_t u1, int32_t v0, int32_t v1) {
         float s = 0;
         for (int32_t v = v0; v <= v1; v++)
-            for (int32_t u = u0; u <= u1; u++) s += (float)V.host[(size_t)v * V.bpl + u];
+            for (int32_t u = u0; u <= u1; u++) s += (float)V.stage[(size_t)v * V.bpl + u];
         return s /= (float)((u1 - u0 + 1) * (v1 - v0 + 1));
     };
     auto cl = [](int32_t x, int32_t hi) { return std::min(std::max(x, 0), hi); };

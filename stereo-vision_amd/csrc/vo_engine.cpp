@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -34,6 +35,7 @@ struct svh_vo {
     svh_matcher* matcher = nullptr;
     double Tr[16];
     bool Tr_valid = false;
+    RandStream rng;   // libc rand() unless svh_vo_set_private_rand switched the object to its own stream
     std::vector<int32_t> inliers;
     std::vector<svh_p_match> matched;
     int device = 0;
@@ -140,7 +142,7 @@ int estimate_prepare(svh_vo* v, const svh_p_match* pm, int32_t N) {
     for (int32_t k = 0; k < iters; k++) {
         int32_t chosen[3];
         for (int q = 0; q < 3; q++) {
-            int32_t j = rand() % (N - q);
+            int32_t j = v->rng.next() % (N - q);
             // j-th smallest index not chosen yet
             int32_t idx = j;
             bool moved = true;
@@ -285,16 +287,14 @@ int32_t svh_vo_process(svh_vo* v, const uint8_t* I1, const uint8_t* I2, const in
     if (!v->Tr_valid) {   // bootstrap (viso_stereo.cpp:47-53)
         rc = svh_matcher_match_features(v->matcher, 2, nullptr);
         if (rc < 0) return rc;
-        svh_matcher_bucket_features(v->matcher, P.bucket_max_features, (float)P.bucket_width,
-                                    (float)P.bucket_height);
+        bucket_features(v->matcher, P.bucket_max_features, (float)P.bucket_width, (float)P.bucket_height, v->rng);
         fetch_matches(v);
         rc = update_motion(v);
         if (rc < 0) return rc;
     }
     rc = svh_matcher_match_features(v->matcher, 2, v->Tr_valid ? v->Tr : nullptr);
     if (rc < 0) return rc;
-    svh_matcher_bucket_features(v->matcher, P.bucket_max_features, (float)P.bucket_width,
-                                (float)P.bucket_height);
+    bucket_features(v->matcher, P.bucket_max_features, (float)P.bucket_width, (float)P.bucket_height, v->rng);
     fetch_matches(v);
     return update_motion(v);
 }
@@ -328,6 +328,20 @@ int32_t svh_vo_process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const*
         }
         return good;
     }
+    static const bool timing = getenv("SVH_MATCHER_TIMING") != nullptr;
+    struct Acc {
+        double t[5] = {0, 0, 0, 0, 0};
+        int64_t calls = 0;
+        ~Acc() {
+            if (calls)
+                fprintf(stderr, "[svh lockstep timing] vo: pushBack %.3f, matchFeatures %.3f, bucketing+samples %.3f, "
+                                "estimate %.3f ms per call\n", t[0] / calls, t[1] / calls, t[2] / calls, t[3] / calls);
+        }
+    };
+    static Acc acc;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tt[5] = {0, 0, 0, 0, 0};
+    if (timing) tt[0] = now();
     const svh_vo_params& P = vs[0]->p;
     std::vector<svh_matcher*> ms(K);
     std::vector<const double*> trs(K);
@@ -337,16 +351,31 @@ int32_t svh_vo_process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const*
     }
     int32_t rc = svh_matcher_push_back_batch(ms.data(), K, I1, I2, dims, replace);
     if (rc < 0 && rc != SVH_ERR_BAD_ARG) return rc;
+    if (timing) tt[1] = now();
     rc = svh_matcher_match_features_batch(ms.data(), K, 2, trs.data());
     if (rc < 0) return rc;
+    if (timing) tt[2] = now();
     std::vector<int> state(K, 0);
-    for (int i = 0; i < K; i++) {
+    auto select = [&](int i) {
         svh_vo* v = vs[i];
-        svh_matcher_bucket_features(v->matcher, P.bucket_max_features, (float)P.bucket_width, (float)P.bucket_height);
+        bucket_features(v->matcher, P.bucket_max_features, (float)P.bucket_width, (float)P.bucket_height, v->rng);
         fetch_matches(v);
         state[i] = estimate_prepare(v, v->matched.data(), (int32_t)v->matched.size());
-        if (state[i] < 0) return state[i];
+    };
+    bool all_private = true;
+    for (int i = 0; i < K; i++) all_private = all_private && vs[i]->rng.is_private;
+    if (all_private) {
+        // every object draws from its own stream: no order to keep between them
+        batch_parallel_for(K, [&](int i) {
+            (void)hipSetDevice(vs[i]->device);
+            select(i);
+        });
+    } else {
+        for (int i = 0; i < K; i++) select(i);   // the process-wide rand(): in the order of K svh_vo_process calls
     }
+    for (int i = 0; i < K; i++)
+        if (state[i] < 0) return state[i];
+    if (timing) tt[3] = now();
     BatchRec& rec = batch_recorder();
     rec.reset();
     t_rec = &rec;
@@ -383,6 +412,11 @@ int32_t svh_vo_process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const*
         if (ok) ok[i] = r;
         good += r > 0;
     }
+    if (timing) {
+        tt[4] = now();
+        for (int i = 0; i < 4; i++) acc.t[i] += tt[i + 1] - tt[i];
+        acc.calls++;
+    }
     return good;
 }
 
@@ -397,6 +431,20 @@ int32_t svh_vo_estimate_motion(svh_vo* v, const svh_p_match* matches, int32_t n,
     svh::ActiveCaller active_;
     if (!v || !tr_delta6 || (n > 0 && !matches) || n < 0) return svh::fail(SVH_ERR_BAD_ARG, "null argument");
     return estimate(v, matches, n, tr_delta6);
+}
+
+void svh_vo_set_private_rand(svh_vo* v, int32_t enable, uint32_t seed) {
+    if (!v) return;
+    if (enable)
+        v->rng.seed(seed);
+    else
+        v->rng.is_private = false;
+}
+
+void svh_rand_sequence(uint32_t seed, int32_t* out, int32_t n) {
+    RandStream rs;
+    rs.seed(seed);
+    for (int32_t i = 0; i < n && out; i++) out[i] = rs.next();
 }
 
 void svh_vo_get_motion(svh_vo* v, double* Tr16) {

@@ -721,9 +721,12 @@ class OracleVo(VoBase):
 
 
 class ProductVo(VoBase):
-    def __init__(self, params):
+    def __init__(self, params, private_rand=None):
         import svhip as S
         VoBase.__init__(self, S.lib(), "svh_", params)
+        if private_rand is not None:   # own generator with glibc's srand(seed) sequence instead of libc rand()
+            self.lib.svh_vo_set_private_rand.argtypes = [C.c_void_p, C.c_int32, C.c_uint32]
+            self.lib.svh_vo_set_private_rand(self.h, 1, private_rand)
 
 def _ptr_array(arrs):
     return (C.c_void_p * len(arrs))(*[None if a is None else a.ctypes.data for a in arrs])

@@ -214,3 +214,36 @@ def test_two_threads_each_driving_a_batch():
         for k in range(K):
             got = groups[g][k].matches()
             assert len(got) == len(want[g * K + k]) and (got == want[g * K + k]).all(), (g, k)
+
+
+def test_private_rand_objects_in_a_batch_equal_objects_alone_in_a_process():
+    """with private streams (svh_vo_set_private_rand, seed 0 = the reference constructor's srand(0)) every object
+    of a lockstep call reproduces the run of ONE object that has libc rand() to itself -- which is the reference's
+    situation (one VisualOdometryStereo per process) -- although K objects run interleaved here"""
+    K, frames = 5, 6
+    prm = H.vo_defaults()
+    im = quad()
+    seqs = [variant(im, k) for k in range(K)]
+    alone = []
+    for k in range(K):
+        vo = H.ProductVo(prm)              # its constructor calls srand(0); nobody else draws meanwhile
+        log = []
+        for i in range(frames):
+            s = seqs[k]
+            ok = vo.process(s[0] if i % 2 == 0 else s[2], s[1] if i % 2 == 0 else s[3])
+            log.append((ok, vo.motion().copy(), vo.inliers().copy(), vo.matches().copy()))
+        alone.append(log)
+        del vo
+    vos = [H.ProductVo(prm, private_rand=0) for _ in range(K)]
+    LIBC.srand(99)                          # the process-wide stream is not what they draw from
+    for i in range(frames):
+        a = [s[0] if i % 2 == 0 else s[2] for s in seqs]
+        b = [s[1] if i % 2 == 0 else s[3] for s in seqs]
+        _, ok = H.product_vo_process_batch(vos, a, b)
+        for k in range(K):
+            w = alone[k][i]
+            assert int(ok[k]) == w[0], (i, k)
+            assert np.array_equal(vos[k].motion(), w[1]), ("motion", i, k)
+            assert np.array_equal(vos[k].inliers(), w[2]), ("inliers", i, k)
+            got = vos[k].matches()
+            assert len(got) == len(w[3]) and (got == w[3]).all(), ("matches", i, k)

@@ -259,3 +259,21 @@ def test_python_binding_validates_output_arrays():
             e.process(I, I, bad, np.zeros((40, 64), np.float32))
         with pytest.raises(ValueError):
             e.process(I, I, np.zeros((40, 64), np.float32), bad)
+
+
+def test_private_rand_stream_is_glibc_rand():
+    """svh_vo_set_private_rand's generator against this machine's libc: srand(seed); rand() x 200000"""
+    import ctypes as C
+    import numpy as np
+    import svhip as S
+    lib = S.lib()
+    lib.svh_rand_sequence.argtypes = [C.c_uint32, C.c_void_p, C.c_int32]
+    libc = C.CDLL(None)
+    libc.rand.restype = C.c_int
+    n = 200000
+    for seed in (0, 1, 7, 20260929, 0x7FFFFFFF, 0xDEADBEEF):
+        got = np.zeros(n, np.int32)
+        lib.svh_rand_sequence(seed, got.ctypes.data, n)
+        libc.srand(C.c_uint(seed))
+        want = np.fromiter((libc.rand() for _ in range(n)), np.int32, n)
+        assert np.array_equal(got, want), seed

@@ -1,6 +1,6 @@
 """The secondary legs of bench.py on their own (Matcher, visual odometry, map fusion), so that a
 rocprofv3 kernel trace of this script shows their kernels only:
-    rocprofv3 --kernel-trace --stats -- python tools/gpu_legs.py [matcher|vo|map|replicas[K]]"""
+    rocprofv3 --kernel-trace --stats -- python tools/gpu_legs.py [matcher|vo|map|replicas[K]|lockstep[TxK]]"""
 import json
 import os
 import sys
@@ -23,4 +23,8 @@ if which in ("map", "all"):
 if which.startswith("replicas"):   # replicas, replicas16, ...
     ks = (int(which[8:]),) if which[8:] else (1, 4, 16)
     out["vo_replicas"] = bench.vo_replicas_bench(ks=ks, frames=60)
+if which.startswith("lockstep"):   # lockstep, lockstep16, ...
+    shapes = (tuple(int(x) for x in which[8:].split("x")),) if which[8:] else None   # lockstep2x8 = 2 threads x 8
+    out["vo_lockstep"] = bench.vo_lockstep_bench(frames=60, private_rand=os.environ.get("LOCKSTEP_LIBC_RAND") is None,
+                                                 **({"shapes": shapes} if shapes else {}))
 print(json.dumps(out))

@@ -1,0 +1,6 @@
+import json,sys
+for line in sys.stdin:
+    line=line.strip()
+    if line.startswith("{"):
+        for r in json.loads(line)["vo_lockstep"]["runs"]: print(r)
+    elif "lockstep timing" in line: print(line)
