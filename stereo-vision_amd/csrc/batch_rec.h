@@ -32,6 +32,13 @@ struct BatchRec {
     std::vector<Slot> slots;
     int cursor = 0;           // call position of the object being recorded
     bool broken = false;      // an object issued a different call sequence than the first one
+    // side streams (+ one event each) for work a lockstep call issues outside the recorded sequence: the image
+    // uploads, several in flight at once
+    static constexpr int kSide = 3;
+    hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
+    hipEvent_t side_done[kSide] = {nullptr, nullptr, nullptr};
+    hipError_t ensure_side();                 // creates them on first use (current device)
+    hipError_t join_side(hipStream_t s);      // s waits for everything issued on the side streams so far
     uint8_t* h_arena = nullptr;   // pinned staging of the job tables
     uint8_t* d_arena = nullptr;
     size_t cap = 0, used = 0;     // `used` advances per flush, reset by synced()
@@ -65,7 +72,11 @@ struct BatchRec {
     // job tables -> device (one copy), one launch per slot, slots cleared.  hipSuccess or the first error
     hipError_t flush(hipStream_t s);
     void synced() { used = 0; }   // the stream was waited for: the arena may be reused from its start
-    void release();
+    void release();   // frees the arena and the side streams
+    ~BatchRec() { release(); }
+    BatchRec() = default;
+    BatchRec(const BatchRec&) = delete;
+    BatchRec& operator=(const BatchRec&) = delete;
 };
 
 // non-null: the launchers record into it (set and cleared by the batch entries on their own thread)

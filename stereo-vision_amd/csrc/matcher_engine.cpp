@@ -82,7 +82,9 @@ hipError_t BatchRec::flush(hipStream_t s) {
         // the arena may still be read by launches in flight: wait, then grow
         hipError_t e = hipStreamSynchronize(s);
         if (e != hipSuccess) return e;
-        release();
+        if (h_arena) (void)hipHostFree(h_arena);
+        if (d_arena) (void)hipFree(d_arena);
+        h_arena = d_arena = nullptr;
         cap = std::max<size_t>(2 * (used + need), 256 * 1024);
         e = hipHostMalloc((void**)&h_arena, cap);
         if (e != hipSuccess) return e;
@@ -108,11 +110,39 @@ hipError_t BatchRec::flush(hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t BatchRec::ensure_side() {
+    for (int i = 0; i < kSide; i++) {
+        if (side[i]) continue;
+        hipError_t e = hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        e = hipEventCreateWithFlags(&side_done[i], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t BatchRec::join_side(hipStream_t s) {
+    for (int i = 0; i < kSide; i++) {
+        if (!side[i]) continue;
+        hipError_t e = hipEventRecord(side_done[i], side[i]);
+        if (e != hipSuccess) return e;
+        e = hipStreamWaitEvent(s, side_done[i], 0);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 void BatchRec::release() {
-    (void)hipHostFree(h_arena);
-    (void)hipFree(d_arena);
+    if (h_arena) (void)hipHostFree(h_arena);
+    if (d_arena) (void)hipFree(d_arena);
     h_arena = d_arena = nullptr;
     cap = 0;
+    for (int i = 0; i < kSide; i++) {
+        if (side[i]) (void)hipStreamDestroy(side[i]);
+        if (side_done[i]) (void)hipEventDestroy(side_done[i]);
+        side[i] = nullptr;
+        side_done[i] = nullptr;
+    }
 }
 
 // the calling thread's recorder (its arena lives as long as the thread)
@@ -915,6 +945,8 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
     btick(1);
     const int ncam = (I2 && I2[0]) ? 2 : 1;
     std::vector<int> rcs((size_t)K * ncam, 0);
+    BatchRec& up = batch_recorder();
+    HIP_TRY(up.ensure_side());
     t_in_batch = true;
     BatchPool::get().parallel_for(K * ncam, [&](int j) {
         (void)hipSetDevice(ms[0]->device);
@@ -922,9 +954,14 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
         const int cam = j % ncam;
         DevView& V = m->cur[cam];
         rcs[j] = features_pack(m, V, cam, cam ? I2[j / ncam] : I1[j / ncam], dims[2]);
-        // the image goes to the device while the other threads still pack theirs (all on the call's stream)
-        if (!rcs[j]) mlaunch_upload(ms[0]->stream, V.stage, V.I, (size_t)V.bpl * V.h);
+        // the image goes to the device while the other threads still pack theirs; the uploads rotate over the
+        // call's stream and the side streams (several copy kernels in flight fill the PCIe link better)
+        if (!rcs[j]) {
+            const int q = j % (BatchRec::kSide + 1);
+            mlaunch_upload(q == 0 ? ms[0]->stream : up.side[q - 1], V.stage, V.I, (size_t)V.bpl * V.h);
+        }
     });
+    HIP_TRY(up.join_side(ms[0]->stream));
     t_in_batch = false;
     for (int rc : rcs)
         if (rc) return rc;

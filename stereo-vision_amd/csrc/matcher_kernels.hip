@@ -37,67 +37,110 @@ __device__ __forceinline__ void d_half(const uint8_t* __restrict__ I, int bpl,
 // ---------------------------------------------------------------------------
 // M2  filter::sobel5x5   libviso2/src/filter.cpp:474 (+306-361, 154-222, 93-152)
 // M3  filter::blob5x5 / checkerboard5x5   filter.cpp:507-532, 492-497
-// One 64x16 tile per block; the 8-bit tile with a 2-pixel halo is staged in LDS
-// and all four 5x5 responses are taken from it.  Defined on rows 2..h-3, cols
-// 2..w-3 (0 elsewhere), which covers everything the matcher ever reads.
+// Separable form on packed 16-bit pairs (v_pk_* arithmetic; every intermediate fits 16 bits, so the
+// integers are those of the 25-tap sums): a thread owns 4 adjacent pixels and walks FR rows down the
+// image with the last five rows of its 8 input columns (x-2 .. x+5) in registers; per row it takes the
+// five vertical sums of each column, then the horizontal combinations for its 4 pixels, and stores one
+// 32-bit word per 8-bit plane (two for the 16-bit planes).  No LDS: the three aligned words a thread
+// reads per row are its neighbours' words too (L1/L2 hits).
+//   du = h[1 2 0 -2 -1] of v[1 4 6 4 1]      dv = h[1 4 6 4 1] of v[1 2 0 -2 -1]       (>>7, +128, clamp)
+//   f1 = -box5x5 + 2 box3x3 + 7 centre       f2 = h[1 1 0 -1 -1] of v[1 1 0 -1 -1]
+// Defined on rows 2..h-3, cols 2..w-3 (0 elsewhere), which covers everything the matcher ever reads.
 // ---------------------------------------------------------------------------
-constexpr int FX = 64, FY = 16;
+constexpr int FX = 64, FR = 8;   // a block of 64x4 threads covers 256 columns x 32 rows
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ s16x2 pk_bytes01(uint32_t w) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c010c00u)); }
+__device__ __forceinline__ s16x2 pk_bytes23(uint32_t w) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c030c02u)); }
+// (a.hi, b.lo): the pair one column to the right of a, given the next pair b
+__device__ __forceinline__ s16x2 pk_mid(s16x2 a, s16x2 b) {
+    return __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbyte(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 2u));
+}
+// four values in two pairs -> their low bytes in one word
+__device__ __forceinline__ uint32_t pk_to_bytes(s16x2 lo, s16x2 hi) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
+}
+__device__ __forceinline__ s16x2 pk_sobel_out(s16x2 v) {   // sat_u8((v >> 7) + 128)
+    const s16x2 lo = {0, 0}, hi = {255, 255}, off = {128, 128};
+    return __builtin_elementwise_min(__builtin_elementwise_max((v >> 7) + off, lo), hi);
+}
 
 template <bool kFeatures>
 __device__ __forceinline__ void d_filters(const uint8_t* __restrict__ I, int w, int h, int bpl,
                                                  uint8_t* __restrict__ du, uint8_t* __restrict__ dv,
                                                  int16_t* __restrict__ f1, int16_t* __restrict__ f2, unsigned bx, unsigned by) {
-    __shared__ uint8_t s[FY + 4][FX + 8];
-    const int x0 = bx * FX, y0 = by * FY;
-    const int tid = threadIdx.y * FX + threadIdx.x;
-    for (int i = tid; i < (FY + 4) * (FX + 4); i += 256) {
-        const int r = i / (FX + 4), c = i - r * (FX + 4);
-        const int y = y0 - 2 + r, x = x0 - 2 + c;
-        s[r][c] = (x >= 0 && x < w && y >= 0 && y < h) ? I[(size_t)y * bpl + x] : 0;
-    }
-    __syncthreads();
-    const int x = x0 + threadIdx.x;
-    if (x >= w) return;
+    const int x = 4 * (int)(bx * FX + threadIdx.x);
+    if (x >= bpl) return;
+    const int y0 = (int)(by * 4 + threadIdx.y) * FR;
+    if (y0 >= h) return;
+    // byte mask of the columns 2..w-3 among this thread's four
+    uint32_t xmask = 0;
 #pragma unroll
-    for (int k = 0; k < FY / 4; k++) {
-        const int ty = threadIdx.y + 4 * k, y = y0 + ty;
+    for (int i = 0; i < 4; i++)
+        if (x + i >= 2 && x + i < w - 2) xmask |= 0xFFu << (8 * i);
+    const bool left = x >= 4, right = x + 4 < bpl;
+    s16x2 win[5][4];
+#pragma unroll
+    for (int j = 0; j < FR + 4; j++) {
+        // input row y0 - 2 + j (clamped: rows outside the image only feed outputs that are zeroed)
+        const int yi = min(max(y0 - 2 + j, 0), h - 1);
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(I + (size_t)yi * bpl + x);
+        const uint32_t w1 = row[0];
+        const uint32_t w0 = left ? row[-1] : 0u, w2 = right ? row[1] : 0u;
+        s16x2* r = win[j % 5];
+        r[0] = pk_bytes23(w0);   // columns x-2, x-1
+        r[1] = pk_bytes01(w1);   //         x,   x+1
+        r[2] = pk_bytes23(w1);   //         x+2, x+3
+        r[3] = pk_bytes01(w2);   //         x+4, x+5
+        if (j < 4) continue;
+        const int y = y0 + j - 4;
         if (y >= h) break;
-        int odu = 0, odv = 0, of1 = 0, of2 = 0;
-        if (x >= 2 && x < w - 2 && y >= 2 && y < h - 2) {
-            int p[5][5];
+        const s16x2 *p0 = win[(j + 1) % 5], *p1 = win[(j + 2) % 5], *p2 = win[(j + 3) % 5], *p3 = win[(j + 4) % 5], *p4 = win[j % 5];
+        s16x2 S[4], T[4], V5[4], V3[4], VK[4];
 #pragma unroll
-            for (int r = 0; r < 5; r++)
-#pragma unroll
-                for (int c = 0; c < 5; c++) p[r][c] = s[ty + r][threadIdx.x + c];
-            int S[5], T[5];
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                S[c] = p[0][c] + 4 * p[1][c] + 6 * p[2][c] + 4 * p[3][c] + p[4][c];  // vertical 1 4 6 4 1
-                T[c] = p[0][c] + 2 * p[1][c] - 2 * p[3][c] - p[4][c];                // vertical 1 2 0 -2 -1
-            }
-            odu = sat_u8(((S[0] + 2 * S[1] - 2 * S[3] - S[4]) >> 7) + 128);
-            odv = sat_u8(((T[0] + 4 * T[1] + 6 * T[2] + 4 * T[3] + T[4]) >> 7) + 128);
+        for (int c = 0; c < 4; c++) {
+            const s16x2 a = p0[c] + p4[c], b = p1[c] + p3[c], d04 = p0[c] - p4[c], d13 = p1[c] - p3[c];
+            const s16x2 four = {4, 4}, six = {6, 6}, two = {2, 2};
+            S[c] = a + four * b + six * p2[c];       // vertical 1 4 6 4 1
+            T[c] = d04 + two * d13;                  // vertical 1 2 0 -2 -1
             if (kFeatures) {
-                int s5 = 0, s3 = 0, ck = 0;
-#pragma unroll
-                for (int r = 0; r < 5; r++)
-#pragma unroll
-                    for (int c = 0; c < 5; c++) {
-                        s5 += p[r][c];
-                        if (r >= 1 && r <= 3 && c >= 1 && c <= 3) s3 += p[r][c];
-                        const int sr = r < 2 ? 1 : (r > 2 ? -1 : 0), sc = c < 2 ? 1 : (c > 2 ? -1 : 0);
-                        ck += sr * sc * p[r][c];
-                    }
-                of1 = -s5 + 2 * s3 + 7 * p[2][2];
-                of2 = ck;
+                V5[c] = a + b + p2[c];               // vertical 1 1 1 1 1
+                V3[c] = b + p2[c];                   // vertical 0 1 1 1 0
+                VK[c] = d04 + d13;                   // vertical 1 1 0 -1 -1
             }
         }
+        const bool rowok = y >= 2 && y < h - 2;
+        const uint32_t keep = rowok ? xmask : 0u;
+        const s16x2 two = {2, 2}, four = {4, 4}, six = {6, 6};
+        // outputs (x, x+1) sit on column pairs 1; (x+2, x+3) on pair 2.  m01 = columns (x-1, x), m12 = (x+1, x+2), ...
+        const s16x2 Sm01 = pk_mid(S[0], S[1]), Sm12 = pk_mid(S[1], S[2]), Sm23 = pk_mid(S[2], S[3]);
+        const s16x2 du_a = (S[0] - S[2]) + two * (Sm01 - Sm12);   // S[c-2] + 2 S[c-1] - 2 S[c+1] - S[c+2]
+        const s16x2 du_b = (S[1] - S[3]) + two * (Sm12 - Sm23);
+        const s16x2 Tm01 = pk_mid(T[0], T[1]), Tm12 = pk_mid(T[1], T[2]), Tm23 = pk_mid(T[2], T[3]);
+        const s16x2 dv_a = (T[0] + T[2]) + four * (Tm01 + Tm12) + six * T[1];
+        const s16x2 dv_b = (T[1] + T[3]) + four * (Tm12 + Tm23) + six * T[2];
         const size_t o = (size_t)y * bpl + x;
-        du[o] = (uint8_t)odu;
-        dv[o] = (uint8_t)odv;
+        *reinterpret_cast<uint32_t*>(du + o) = pk_to_bytes(pk_sobel_out(du_a), pk_sobel_out(du_b)) & keep;
+        *reinterpret_cast<uint32_t*>(dv + o) = pk_to_bytes(pk_sobel_out(dv_a), pk_sobel_out(dv_b)) & keep;
         if (kFeatures) {
-            f1[o] = (int16_t)of1;
-            f2[o] = (int16_t)of2;
+            const s16x2 Am01 = pk_mid(V5[0], V5[1]), Am12 = pk_mid(V5[1], V5[2]), Am23 = pk_mid(V5[2], V5[3]);
+            const s16x2 Bm01 = pk_mid(V3[0], V3[1]), Bm12 = pk_mid(V3[1], V3[2]), Bm23 = pk_mid(V3[2], V3[3]);
+            const s16x2 Km01 = pk_mid(VK[0], VK[1]), Km12 = pk_mid(VK[1], VK[2]), Km23 = pk_mid(VK[2], VK[3]);
+            const s16x2 seven = {7, 7};
+            const s16x2 box5_a = V5[0] + Am01 + V5[1] + Am12 + V5[2], box5_b = V5[1] + Am12 + V5[2] + Am23 + V5[3];
+            const s16x2 box3_a = Bm01 + V3[1] + Bm12, box3_b = Bm12 + V3[2] + Bm23;
+            const s16x2 f1_a = two * box3_a - box5_a + seven * p2[1], f1_b = two * box3_b - box5_b + seven * p2[2];
+            const s16x2 f2_a = (VK[0] - VK[2]) + (Km01 - Km12), f2_b = (VK[1] - VK[3]) + (Km12 - Km23);
+            // 16-bit planes: mask = the byte mask widened to halves
+            const uint32_t k01 = ((keep & 0xFFu) ? 0xFFFFu : 0u) | ((keep & 0xFF00u) ? 0xFFFF0000u : 0u);
+            const uint32_t k23 = ((keep & 0xFF0000u) ? 0xFFFFu : 0u) | ((keep & 0xFF000000u) ? 0xFFFF0000u : 0u);
+            uint2 o1, o2;
+            o1.x = __builtin_bit_cast(uint32_t, f1_a) & k01;
+            o1.y = __builtin_bit_cast(uint32_t, f1_b) & k23;
+            o2.x = __builtin_bit_cast(uint32_t, f2_a) & k01;
+            o2.y = __builtin_bit_cast(uint32_t, f2_b) & k23;
+            *reinterpret_cast<uint2*>(f1 + o) = o1;
+            *reinterpret_cast<uint2*>(f2 + o) = o2;
         }
     }
 }
@@ -1007,7 +1050,7 @@ void mlaunch_half(void* stream, const uint8_t* I, int bpl, uint8_t* out, int hw,
 void mlaunch_filters(void* stream, const uint8_t* I, int w, int h, int bpl, uint8_t* du, uint8_t* dv,
                      int16_t* f1, int16_t* f2) {
     const FiltersJob a = {I, w, h, bpl, du, dv, f1, f2};
-    const dim3 grid((w + FX - 1) / FX, (h + FY - 1) / FY), block(FX, 4);
+    const dim3 grid((bpl / 4 + FX - 1) / FX, (h + 4 * FR - 1) / (4 * FR)), block(FX, 4);
     if (t_rec) return t_rec->add(f1 ? b_filters1 : b_filters0, a, grid.x, grid.y);
     if (f1)
         hipLaunchKernelGGL(k_filters<true>, grid, block, 0, (hipStream_t)stream, a);

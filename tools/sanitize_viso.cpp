@@ -49,6 +49,10 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, 
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = reinterpret_cast<hipStream_t>(new StubStream()); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { delete reinterpret_cast<StubStream*>(s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { if (s) reinterpret_cast<StubStream*>(s)->pending.store(0, std::memory_order_relaxed); return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(new int(0)); return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<int*>(e); return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { return hipSuccess; }
 hipError_t hipStreamQuery(hipStream_t s) {
     if (!s) return hipSuccess;
     StubStream* q = reinterpret_cast<StubStream*>(s);
