@@ -277,11 +277,13 @@ def vo_replicas_bench(ks=(1, 4, 16), frames=40):
                         "alternating, one host thread per object", "runs": out}
 
 
-def vo_lockstep_bench(shapes=((1, 4), (1, 16), (1, 32), (2, 8), (2, 16), (4, 8)), frames=40, private_rand=True):
+def vo_lockstep_bench(shapes=((1, 4), (1, 16), (1, 32), (2, 8), (2, 16), (4, 8)), frames=40, private_rand=True,
+                      pipelined=(False, True)):
     """the same sequences driven in LOCKSTEP: svh_vo_process_batch, one launch per kernel over the K objects of a
     call (blockIdx.z = object), host steps (row packing, outlier votes, prior statistics) on the library's
     helper threads.  shapes = (host threads, objects per call): with two or more calling threads one group's
-    host steps overlap the other's device steps.  private_rand: every object draws from its own generator
+    host steps overlap the other's device steps.  pipelined: svh_vo_prefetch_batch + svh_vo_process_next_batch, the
+    next frame's packing / upload / feature extraction overlap this frame's matching and motion estimate.  private_rand: every object draws from its own generator
     (glibc's srand(0) sequence) instead of the process-wide rand(), whose lock the calling threads contend for
     and whose draw order forces the bucketing of a call's objects to run one after the other.  Aggregate stereo frames/s; per object the results equal
     svh_vo_process calls (tests/test_batch_gpu.py)."""
@@ -291,7 +293,7 @@ def vo_lockstep_bench(shapes=((1, 4), (1, 16), (1, 32), (2, 8), (2, 16), (4, 8))
     im = [Hh.read_pgm(os.path.join(Hh.GOLDEN, "viso_%s.pgm" % k)) for k in ("I1p", "I2p", "I1c", "I2c")]
     prm = Hh.vo_defaults()
     out = []
-    for T, K in shapes:
+    for T, K, pipe in [(T, K, p) for p in pipelined for (T, K) in shapes]:
         groups = []
         for g in range(T):
             vos = [Hh.ProductVo(prm, private_rand=0 if private_rand else None) for _ in range(K)]
@@ -308,6 +310,14 @@ def vo_lockstep_bench(shapes=((1, 4), (1, 16), (1, 32), (2, 8), (2, 16), (4, 8))
         def worker(g):
             vos, even, odd = groups[g]
             go.wait()
+            if pipe:   # frame i + 1 is handed over while frame i is matched
+                shape = even[0][0].shape
+                Hh.product_vo_prefetch_batch(vos, *even)
+                for i in range(frames):
+                    nxt = (odd if i % 2 == 0 else even) if i + 1 < frames else (None, None)
+                    n, _ = Hh.product_vo_process_next_batch(vos, nxt[0], nxt[1], shape)
+                    good[g] += n
+                return
             for i in range(frames):
                 n, _ = Hh.product_vo_process_batch(vos, *(even if i % 2 == 0 else odd))
                 good[g] += n
@@ -322,7 +332,7 @@ def vo_lockstep_bench(shapes=((1, 4), (1, 16), (1, 32), (2, 8), (2, 16), (4, 8))
         dt = time.perf_counter() - t0
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
         cpu = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
-        out.append({"calling_threads": T, "objects_per_call": K, "frames_per_s": T * K * frames / dt,
+        out.append({"calling_threads": T, "objects_per_call": K, "pipelined": pipe, "frames_per_s": T * K * frames / dt,
                     "call_ms": 1e3 * dt / frames, "frames_ok": int(sum(good)), "frames": T * K * frames,
                     "host_cores_used": round(cpu / dt, 2)})
         del groups

@@ -306,6 +306,15 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
                                     const uint8_t* const* I2, const int32_t* dims, int32_t replace);
 int32_t svh_matcher_match_features_batch(svh_matcher* const* ms, int32_t K, int32_t method,
                                          const double* const* Tr_delta);
+/* The NEXT frame of the K Matchers handed over early: its rows are packed, uploaded and its features computed into
+ * a third set of per-frame buffers on the objects' second streams, and the call returns WITHOUT waiting -- that
+ * work then overlaps the matchFeatures (and, under the visual odometry, the motion estimate) of the frame before
+ * it.  The following svh_matcher_push_back / svh_matcher_push_back_batch of these objects is called with
+ * I1 = I2 = NULL and takes the prefetched frame (ring-buffer rotation and `replace` as usual); results are those
+ * of the plain calls.  One prefetched frame per object at a time.  (No counterpart in the reference, whose
+ * pushBack computes the features synchronously, matcher.cpp:102-205.) */
+int32_t svh_matcher_prefetch_batch(svh_matcher* const* ms, int32_t K, const uint8_t* const* I1,
+                                   const uint8_t* const* I2, const int32_t* dims);
 /* Matcher::bucketFeatures -- matcher.cpp:297-343 (std::random_shuffle on the host) */
 int32_t svh_matcher_bucket_features(svh_matcher* m, int32_t max_features, float bucket_width,
                                     float bucket_height);
@@ -381,6 +390,16 @@ void svh_rand_sequence(uint32_t seed, int32_t* out, int32_t n);
  * still bootstrapping (viso_stereo.cpp:47-53) or differ in parameters are processed one after the other. */
 int32_t svh_vo_process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const* I1, const uint8_t* const* I2,
                              const int32_t* dims, int32_t replace, int32_t* ok);
+/* The pipelined frame loop.  svh_vo_prefetch_batch hands over the FIRST frame (svh_matcher_prefetch_batch for the
+ * objects' Matchers; returns without waiting).  Then, per frame, svh_vo_process_next_batch processes the frame
+ * handed over before and hands over the next one (next_I1 / next_I2; NULL after the last frame) as soon as the ring
+ * buffers have rotated: the next frame's row packing, upload and feature extraction overlap this frame's matching
+ * and motion estimate.  Results and return values are those of svh_vo_process_batch with the images passed
+ * directly.  svh_vo_process / svh_vo_process_batch with I1 = I2 = NULL also take a frame handed over before. */
+int32_t svh_vo_prefetch_batch(svh_vo* const* vs, int32_t K, const uint8_t* const* I1, const uint8_t* const* I2,
+                              const int32_t* dims);
+int32_t svh_vo_process_next_batch(svh_vo* const* vs, int32_t K, const uint8_t* const* next_I1,
+                                  const uint8_t* const* next_I2, const int32_t* dims, int32_t replace, int32_t* ok);
 /* bool VisualOdometry::process(p_matched) -- viso.h:87-91: motion from given matches */
 int32_t svh_vo_process_matches(svh_vo* v, const svh_p_match* matches, int32_t n);
 /* vector<double> estimateMotion(p_matched) -- viso_stereo.cpp:72-228 (RANSAC + Gauss-Newton on

@@ -37,6 +37,11 @@ struct BatchRec {
     static constexpr int kSide = 3;
     hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
     hipEvent_t side_done[kSide] = {nullptr, nullptr, nullptr};
+    // a recorder whose launches outlive the call that flushed them (prefetch): flush() leaves an event, reuse()
+    // waits for it before the arena is written again
+    bool track = false, flush_pending = false;
+    hipEvent_t flushed = nullptr;
+    hipError_t reuse();
     hipError_t ensure_side();                 // creates them on first use (current device)
     hipError_t join_side(hipStream_t s);      // s waits for everything issued on the side streams so far
     uint8_t* h_arena = nullptr;   // pinned staging of the job tables
@@ -83,6 +88,7 @@ struct BatchRec {
 extern thread_local BatchRec* t_rec;
 // the calling thread's recorder (its arena is kept for the thread's lifetime)
 BatchRec& batch_recorder();
+BatchRec& prefetch_recorder();
 // fn(0..n-1) on the library's parked helper threads and the caller; returns when all are done
 void batch_parallel_for(int n, const std::function<void(int)>& fn);
 

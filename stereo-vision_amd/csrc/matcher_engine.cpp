@@ -26,6 +26,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <future>
 #include <mutex>
 #include <deque>
 #include <string>
@@ -107,6 +108,15 @@ hipError_t BatchRec::flush(hipStream_t s) {
     }
     used += need;
     slots.clear();
+    if (track) {
+        if (!flushed) {
+            e = hipEventCreateWithFlags(&flushed, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        e = hipEventRecord(flushed, s);
+        if (e != hipSuccess) return e;
+        flush_pending = true;
+    }
     return hipGetLastError();
 }
 
@@ -143,12 +153,32 @@ void BatchRec::release() {
         side[i] = nullptr;
         side_done[i] = nullptr;
     }
+    if (flushed) (void)hipEventDestroy(flushed);
+    flushed = nullptr;
+    flush_pending = false;
 }
 
 // the calling thread's recorder (its arena lives as long as the thread)
 BatchRec& batch_recorder() {
     static thread_local BatchRec rec;
     return rec;
+}
+// a second one for svh_matcher_prefetch_batch: its launches are still in flight when the thread records the next
+// phases of the frame before
+BatchRec& prefetch_recorder() {
+    static thread_local BatchRec rec;
+    rec.track = true;
+    return rec;
+}
+
+hipError_t BatchRec::reuse() {
+    if (flushed && flush_pending) {
+        const hipError_t e = hipEventSynchronize(flushed);
+        if (e != hipSuccess) return e;
+        flush_pending = false;
+    }
+    used = 0;
+    return hipSuccess;
 }
 
 // Parked helper threads for the per-object HOST work of a batch call (outlier votes, prior statistics):
@@ -225,6 +255,47 @@ private:
     int n_ = 0, next_ = 0, done_ = 0;
     uint64_t gen_ = 0;
 };
+// One parked thread that runs the host side of svh_matcher_prefetch_batch (row packing on the helper threads,
+// uploads, the recorded feature extraction) while the caller goes on with the frame before.
+class PrefetchWorker {
+public:
+    std::shared_future<int32_t> post(std::function<int32_t()> fn) {
+        std::packaged_task<int32_t()> task(std::move(fn));
+        std::shared_future<int32_t> f = task.get_future().share();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!started_) {
+                std::thread(&PrefetchWorker::run, this).detach();
+                started_ = true;
+            }
+            q_.push_back(std::move(task));
+        }
+        cv_.notify_one();
+        return f;
+    }
+    static PrefetchWorker& get() {
+        static PrefetchWorker* w = new PrefetchWorker();   // leaked on purpose, like the helper pool
+        return *w;
+    }
+
+private:
+    void run() {
+        for (;;) {
+            std::packaged_task<int32_t()> task;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return !q_.empty(); });
+                task = std::move(q_.front());
+                q_.pop_front();
+            }
+            task();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::packaged_task<int32_t()>> q_;
+    bool started_ = false;
+};
 thread_local bool t_in_batch = false;   // inside a batch call: the outlier vote does not fork (the pool is the parallelism)
 }  // namespace
 
@@ -290,6 +361,14 @@ struct svh_matcher {
     int device;
     hipStream_t stream;
     DevView prev[2], cur[2];
+    // a frame handed over early (svh_matcher_prefetch_batch): packed, uploaded and its features computed into a
+    // third view set while the frame before it is still being matched; the next pushBack without images takes it
+    DevView next[2];
+    int32_t dims_n[3] = {0, 0, 0};
+    bool has_next = false;
+    int next_cams = 0;
+    hipStream_t next_stream = nullptr;        // where the prefetch was issued (waited for when the frame is taken)
+    std::shared_future<int32_t> next_job;     // its host side, on the prefetch thread
     int32_t dims_p[3], dims_c[3];
     // scratch
     int4* slots[2] = {nullptr, nullptr};      // NMS scratch, one set per camera (the cameras'
@@ -387,7 +466,9 @@ static int ensure_view(svh_matcher* m, DevView& V, int32_t w, int32_t h, int32_t
     return SVH_OK;
 }
 
-static int ensure_scratch(svh_matcher* m, int32_t slot_need, int32_t pm_need, size_t owner_need) {
+// scratch of the feature extraction (may run on the prefetch thread) and of the matching (the caller's thread):
+// two functions, so that neither side reads the other's bookkeeping
+static int ensure_feature_scratch(svh_matcher* m, int32_t slot_need) {
     if (slot_need > m->slot_cap) {
         for (int c = 0; c < 2; c++) {
             (void)hipFree(m->slots[c]); (void)hipFree(m->flags[c]); (void)hipFree(m->order[c]);
@@ -397,6 +478,10 @@ static int ensure_scratch(svh_matcher* m, int32_t slot_need, int32_t pm_need, si
         }
         m->slot_cap = slot_need;
     }
+    return SVH_OK;
+}
+
+static int ensure_match_scratch(svh_matcher* m, int32_t pm_need, size_t owner_need) {
     if (pm_need > m->pm_cap) {
         (void)hipFree(m->pm_slots); (void)hipFree(m->pm_out); (void)hipFree(m->pm_flags);
         HIP_TRY(dalloc(&m->pm_slots, (size_t)pm_need));
@@ -427,9 +512,10 @@ static int features_pack(svh_matcher* m, DevView& V, int cam, const uint8_t* src
     return SVH_OK;
 }
 
-static int features_enqueue(svh_matcher* m, DevView& V, int cam, double* tf, bool uploaded = false) {
+static int features_enqueue(svh_matcher* m, DevView& V, int cam, double* tf, bool uploaded = false,
+                            int32_t* counts = nullptr, hipStream_t on = nullptr) {
     const svh_matcher_params& p = m->p;
-    hipStream_t s = cam == 1 ? m->stream2 : m->stream;
+    hipStream_t s = on ? on : (cam == 1 ? m->stream2 : m->stream);
     const size_t fn = (size_t)V.bpl * V.h;
     const uint8_t* stage = V.stage;
     auto ftick = [&](int i) { if (g_mtiming && tf) tf[i] = mnow_ms(); };
@@ -452,7 +538,7 @@ static int features_enqueue(svh_matcher* m, DevView& V, int cam, double* tf, boo
     const int32_t scale = p.half_resolution ? 2 : 1;
     int32_t ns = p.nms_n * 3;
     if (ns > 10) ns = std::max(p.nms_n, 10);
-    int rc = ensure_scratch(m, std::max(V.cap[0], V.cap[1]), 0, 0);
+    int rc = ensure_feature_scratch(m, std::max(V.cap[0], V.cap[1]));
     if (rc) return rc;
     if (p.multi_stage)
         mlaunch_features(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, ns, p.nms_tau, m->margin, scale,
@@ -464,7 +550,7 @@ static int features_enqueue(svh_matcher* m, DevView& V, int cam, double* tf, boo
     ftick(4);
     // feature counts come back through pinned memory after BOTH cameras are enqueued
     // (a copy into pageable memory would block here until this camera's kernels finish)
-    mlaunch_copy(s, m->h_n + 2 * cam, V.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
+    mlaunch_copy(s, (counts ? counts : m->h_n) + 2 * cam, V.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
     ftick(5);
     V.nbins = 0;   // bin indices are (re)built by matchFeatures for the current bin grid
     V.valid = true;
@@ -657,7 +743,7 @@ static int match_enqueue(svh_matcher* m, int dense, int32_t method, bool use_pri
     if (Tr) memcpy(P.tr, Tr, sizeof(P.tr));
     const DevView& q = method == 2 ? m->prev[0] : m->cur[0];
     const int32_t nq = q.n[dense];
-    int rc = ensure_scratch(m, 0, std::max(nq, 1), method < 2 ? (size_t)P.width * P.height : 0);
+    int rc = ensure_match_scratch(m, std::max(nq, 1), method < 2 ? (size_t)P.width * P.height : 0);
     if (rc) return rc;
     mlaunch_match(m->stream, P, view_of(m->prev[0], dense), view_of(m->prev[1], dense), view_of(m->cur[0], dense),
                   view_of(m->cur[1], dense), nq, m->ranges_dev, use_prior ? 1 : 0, m->pm_slots, m->pm_flags,
@@ -810,12 +896,15 @@ void svh_matcher_destroy(svh_matcher* m) {
                         "features enqueue %.3f, d2h enqueue %.3f ms\n",
                 m->tfine[0] * a, m->tfine[1] * a, m->tfine[2] * a, m->tfine[3] * a, m->tfine[4] * a);
     }
+    if (m->next_job.valid()) (void)m->next_job.get();   // a hand-over still running on the prefetch thread
     if (m->stream) {
         (void)hipSetDevice(m->device);
         (void)hipStreamSynchronize(m->stream);
+        if (m->stream2) (void)hipStreamSynchronize(m->stream2);
         for (int k = 0; k < 2; k++) {
             m->prev[k].release();
             m->cur[k].release();
+            m->next[k].release();
         }
         for (int c = 0; c < 2; c++) {
             (void)hipFree(m->slots[c]); (void)hipFree(m->flags[c]); (void)hipFree(m->order[c]);
@@ -839,8 +928,43 @@ void svh_matcher_set_intrinsics(svh_matcher* m, double f, double cu, double cv, 
 }
 
 // pushBack up to the device work: argument checks, ring-buffer rotation, buffers.  `src` = the two rows of images
+// takes the prefetched frame: waits for its device work, rotates it into `cur`
+static int32_t push_take_prefetched(svh_matcher* m, int32_t replace) {
+    if (m->next_job.valid()) {
+        const int32_t rc = m->next_job.get();
+        m->next_job = std::shared_future<int32_t>();
+        if (rc) {
+            m->has_next = false;
+            return mfail(rc, "the hand-over of the prefetched frame failed on the prefetch thread");
+        }
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY((hipError_t)wait_stream(m->next_stream));
+    HIP_TRY(hipGetLastError());
+    for (int k = 0; k < 2; k++) {
+        if (!replace) {
+            // ring buffer: current -> previous, prefetched -> current; the old previous buffers are recycled
+            std::swap(m->prev[k], m->cur[k]);
+            std::swap(m->cur[k], m->next[k]);
+        } else {
+            std::swap(m->cur[k], m->next[k]);
+        }
+        m->next[k].valid = false;
+        if (k >= m->next_cams) m->cur[k].valid = false;
+    }
+    if (!replace) memcpy(m->dims_p, m->dims_c, sizeof(m->dims_p));
+    memcpy(m->dims_c, m->dims_n, sizeof(m->dims_c));
+    for (int k = 0; k < m->next_cams; k++) {
+        m->cur[k].n[0] = m->h_n[4 + 2 * k];
+        m->cur[k].n[1] = m->h_n[4 + 2 * k + 1];
+    }
+    m->has_next = false;
+    return SVH_OK;
+}
+
 static int32_t push_prepare(svh_matcher* m, const uint8_t* I1, const uint8_t* I2, const int32_t* dims, int32_t replace) {
     if (!m || !dims) return mfail(SVH_ERR_BAD_ARG, "null argument");
+    if (m->has_next) return mfail(SVH_ERR_BAD_ARG, "a prefetched frame is pending: pass no images to take it");
     const int32_t w = dims[0], h = dims[1], pitch = dims[2];
     if (w <= 0 || h <= 0 || pitch < w || I1 == 0) {
         // matcher.cpp:110-114
@@ -866,7 +990,7 @@ static int32_t push_prepare(svh_matcher* m, const uint8_t* I1, const uint8_t* I2
     m->dims_c[0] = w;
     m->dims_c[1] = h;
     m->dims_c[2] = w + 16 - w % 16;   // +16 even when w % 16 == 0 (matcher.cpp:173)
-    if (!m->h_n) HIP_TRY(hipHostMalloc((void**)&m->h_n, 4 * sizeof(int32_t)));
+    if (!m->h_n) HIP_TRY(hipHostMalloc((void**)&m->h_n, 8 * sizeof(int32_t)));   // [4..7]: a prefetched frame's
     const uint8_t* src[2] = {I1, I2};
     for (int k = 0; k < 2; k++) {
         if (!src[k]) continue;
@@ -888,6 +1012,7 @@ static void push_finish(svh_matcher* m, const uint8_t* I1, const uint8_t* I2) {
 int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* I2, const int32_t* dims,
                               int32_t replace) {
     svh::ActiveCaller active_;
+    if (m && !I1 && !I2 && m->has_next) return push_take_prefetched(m, replace);
     int32_t rc = push_prepare(m, I1, I2, dims, replace);
     if (rc) return rc;
     const uint8_t* src[2] = {I1, I2};
@@ -910,6 +1035,119 @@ int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* 
     return SVH_OK;
 }
 
+}  // extern "C"
+
+namespace svh {
+// host side of svh_matcher_prefetch_batch (prefetch thread): buffers, packing + uploads, feature extraction issued
+static int32_t prefetch_body(const std::vector<svh_matcher*>& ms, const std::vector<const uint8_t*>& I1,
+                             const std::vector<const uint8_t*>& I2, int32_t w, int32_t h, int32_t pitch, int ncam,
+                             bool lockstep) {
+    const int K = (int)ms.size();
+    for (int i = 0; i < K; i++) {
+        svh_matcher* m = ms[i];
+        HIP_TRY(hipSetDevice(m->device));
+        if (!m->stream) HIP_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+        if (!m->stream2) HIP_TRY(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
+        if (!m->h_n) HIP_TRY(hipHostMalloc((void**)&m->h_n, 8 * sizeof(int32_t)));
+        m->dims_n[0] = w;
+        m->dims_n[1] = h;
+        m->dims_n[2] = w + 16 - w % 16;
+        for (int k = 0; k < ncam; k++) {
+            const int rc = ensure_view(m, m->next[k], w, h, m->dims_n[2]);
+            if (rc) return rc;
+        }
+    }
+    // one stream for the whole prefetch when the objects run in lockstep, else each object's second stream
+    BatchRec& pr = prefetch_recorder();
+    HIP_TRY(pr.reuse());
+    HIP_TRY(pr.ensure_side());
+    std::vector<int> rcs((size_t)K * ncam, 0);
+    batch_parallel_for(K * ncam, [&](int j) {
+        (void)hipSetDevice(ms[0]->device);
+        svh_matcher* m = ms[j / ncam];
+        const int cam = j % ncam;
+        DevView& V = m->next[cam];
+        rcs[j] = features_pack(m, V, cam, cam ? I2[j / ncam] : I1[j / ncam], pitch);
+        if (!rcs[j]) {
+            hipStream_t up = lockstep ? pr.side[j % BatchRec::kSide] : m->stream2;
+            mlaunch_upload(up, V.stage, V.I, (size_t)V.bpl * V.h);
+        }
+    });
+    for (int rc : rcs)
+        if (rc) return rc;
+    int rc = SVH_OK;
+    if (lockstep) {
+        hipStream_t pf = ms[0]->stream2;
+        HIP_TRY(pr.join_side(pf));
+        pr.reset();
+        t_rec = &pr;
+        for (int i = 0; i < K && !rc; i++) {
+            pr.begin_object();
+            for (int cam = 0; cam < ncam && !rc; cam++)
+                rc = features_enqueue(ms[i], ms[i]->next[cam], cam, nullptr, true, ms[i]->h_n + 4);
+        }
+        t_rec = nullptr;
+        if (rc) return rc;
+        if (pr.broken) {
+            pr.reset();
+            lockstep = false;   // (not reachable with equal parameters and sizes) issue them one by one below
+            HIP_TRY(hipStreamSynchronize(pf));
+        } else {
+            HIP_TRY(pr.flush(pf));
+            for (int i = 0; i < K; i++) ms[i]->next_stream = pf;
+        }
+    }
+    if (!lockstep) {
+        for (int i = 0; i < K; i++) {
+            for (int cam = 0; cam < ncam; cam++) {
+                rc = features_enqueue(ms[i], ms[i]->next[cam], cam, nullptr, true, ms[i]->h_n + 4, ms[i]->stream2);
+                if (rc) return rc;
+            }
+            ms[i]->next_stream = ms[i]->stream2;
+        }
+    }
+    return SVH_OK;
+}
+}  // namespace svh
+
+extern "C" {
+
+// The NEXT frame of K Matchers handed over early: packed, uploaded and its features computed into a third view
+// set on the objects' second streams, without waiting -- so that this device and host work overlaps the
+// matchFeatures / motion estimate of the frame before it.  The following pushBack of these objects (single or
+// batch entry) is called WITHOUT images and takes the prefetched frame.  One prefetched frame per object at a time.
+int32_t svh_matcher_prefetch_batch(svh_matcher* const* ms, int32_t K, const uint8_t* const* I1,
+                                   const uint8_t* const* I2, const int32_t* dims) {
+    if (!ms || K <= 0 || !I1 || !dims) return mfail(SVH_ERR_BAD_ARG, "null argument");
+    const int32_t w = dims[0], h = dims[1], pitch = dims[2];
+    if (w <= 0 || h <= 0 || pitch < w) return mfail(SVH_ERR_BAD_ARG, "image dimension mismatch");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return mfail(SVH_ERR_NO_DEVICE, "no HIP device visible: libsvhip has no CPU fallback");
+    const int ncam = (I2 && I2[0]) ? 2 : 1;
+    bool lockstep = K > 1;
+    for (int i = 0; i < K; i++) {
+        if (!ms[i] || !I1[i] || (ncam == 2 && !I2[i])) return mfail(SVH_ERR_BAD_ARG, "null matcher or image in the batch");
+        if (ms[i]->has_next) return mfail(SVH_ERR_BAD_ARG, "a prefetched frame is already pending");
+        for (int j = 0; j < i; j++)
+            if (ms[j] == ms[i]) return mfail(SVH_ERR_BAD_ARG, "the same matcher twice in one batch");
+        lockstep = lockstep && memcmp(&ms[i]->p, &ms[0]->p, sizeof(ms[0]->p)) == 0 && ms[i]->device == ms[0]->device;
+    }
+    // the rest runs on the prefetch thread (the caller's pointer arrays are copied, the images are read there:
+    // they must stay unchanged until the frame is taken)
+    std::vector<svh_matcher*> mv(ms, ms + K);
+    std::vector<const uint8_t*> a(I1, I1 + K), b2;
+    if (ncam == 2) b2.assign(I2, I2 + K);
+    std::shared_future<int32_t> job = PrefetchWorker::get().post(
+        [mv, a, b2, w, h, pitch, ncam, lockstep]() { return prefetch_body(mv, a, b2, w, h, pitch, ncam, lockstep); });
+    for (int i = 0; i < K; i++) {
+        ms[i]->has_next = true;
+        ms[i]->next_cams = ncam;
+        ms[i]->next_job = job;
+    }
+    return SVH_OK;
+}
+
 // K Matchers in lockstep (one frame of K sequences): the host packs the K x 2 images on the helper threads,
 // the device work of all K is recorded and issued as ONE launch per kernel (batch_rec.h) on ms[0]'s stream.
 // Results are those of K svh_matcher_push_back calls.  Objects must share parameters and image size;
@@ -917,8 +1155,18 @@ int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* 
 int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uint8_t* const* I1,
                                     const uint8_t* const* I2, const int32_t* dims, int32_t replace) {
     svh::ActiveCaller active_;
-    if (!ms || K < 0 || !I1 || !dims) return mfail(SVH_ERR_BAD_ARG, "null argument");
+    if (!ms || K < 0 || !dims) return mfail(SVH_ERR_BAD_ARG, "null argument");
     if (K == 0) return SVH_OK;
+    if (!I1) {
+        // no images: every object takes the frame handed over by svh_matcher_prefetch_batch
+        for (int i = 0; i < K; i++)
+            if (!ms[i] || !ms[i]->has_next) return mfail(SVH_ERR_BAD_ARG, "no images and no prefetched frame");
+        for (int i = 0; i < K; i++) {
+            const int32_t rc = push_take_prefetched(ms[i], replace);
+            if (rc) return rc;
+        }
+        return SVH_OK;
+    }
     bool lockstep = K > 1;
     for (int i = 0; i < K && lockstep; i++) {
         if (!ms[i]) return mfail(SVH_ERR_BAD_ARG, "null matcher in the batch");

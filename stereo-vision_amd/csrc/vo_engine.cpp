@@ -278,12 +278,10 @@ void svh_vo_destroy(svh_vo* v) {
     delete v;
 }
 
-int32_t svh_vo_process(svh_vo* v, const uint8_t* I1, const uint8_t* I2, const int32_t* dims, int32_t replace) {
-    svh::ActiveCaller active_;
-    if (!v || !dims) return svh::fail(SVH_ERR_BAD_ARG, "null argument");
+// VisualOdometryStereo::process after its pushBack   viso_stereo.cpp:47-68
+static int32_t process_after_push(svh_vo* v) {
     const svh_vo_params& P = v->p;
-    int32_t rc = svh_matcher_push_back(v->matcher, I1, I2, dims, replace);
-    if (rc < 0 && rc != SVH_ERR_BAD_ARG) return rc;   // bad dims: message printed, carry on like the reference
+    int32_t rc;
     if (!v->Tr_valid) {   // bootstrap (viso_stereo.cpp:47-53)
         rc = svh_matcher_match_features(v->matcher, 2, nullptr);
         if (rc < 0) return rc;
@@ -299,6 +297,14 @@ int32_t svh_vo_process(svh_vo* v, const uint8_t* I1, const uint8_t* I2, const in
     return update_motion(v);
 }
 
+int32_t svh_vo_process(svh_vo* v, const uint8_t* I1, const uint8_t* I2, const int32_t* dims, int32_t replace) {
+    svh::ActiveCaller active_;
+    if (!v || !dims) return svh::fail(SVH_ERR_BAD_ARG, "null argument");
+    const int32_t rc = svh_matcher_push_back(v->matcher, I1, I2, dims, replace);
+    if (rc < 0 && rc != SVH_ERR_BAD_ARG) return rc;   // bad dims: message printed, carry on like the reference
+    return process_after_push(v);
+}
+
 // One frame of K sequences: K VisualOdometryStereo objects in lockstep.  The Matcher steps go through the batched
 // Matcher entries, the K motion estimates are two launches.  libc rand() is consumed in the order of K
 // svh_vo_process calls (object by object: bucketing, then the RANSAC samples), so with the same srand the results
@@ -306,10 +312,12 @@ int32_t svh_vo_process(svh_vo* v, const uint8_t* I1, const uint8_t* I2, const in
 // (1 motion updated, 0 estimate failed); the call returns <0 on the first error, else the number of successes.
 // Objects that are still bootstrapping (no valid motion yet), or that differ in parameters, make the call run
 // them one after the other.
-int32_t svh_vo_process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const* I1, const uint8_t* const* I2,
-                             const int32_t* dims, int32_t replace, int32_t* ok) {
+static int32_t process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const* I1, const uint8_t* const* I2,
+                             const int32_t* dims, int32_t replace, int32_t* ok, const uint8_t* const* N1,
+                             const uint8_t* const* N2) {
     svh::ActiveCaller active_;
-    if (!vs || K < 0 || !I1 || !I2 || !dims) return svh::fail(SVH_ERR_BAD_ARG, "null argument");
+    // I1 == I2 == NULL: the objects take the frame handed over by svh_vo_prefetch_batch
+    if (!vs || K < 0 || (!I1 != !I2) || !dims) return svh::fail(SVH_ERR_BAD_ARG, "null argument");
     bool lockstep = K > 1;
     for (int i = 0; i < K; i++) {
         if (!vs[i]) return svh::fail(SVH_ERR_BAD_ARG, "null object in the batch");
@@ -319,9 +327,21 @@ int32_t svh_vo_process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const*
                    vs[i]->device == vs[0]->device;
     }
     int32_t good = 0;
+    std::vector<svh_matcher*> ms(K);
+    for (int i = 0; i < K; i++) ms[i] = vs[i]->matcher;
     if (!lockstep) {
+        // one by one, in the order of K svh_vo_process calls (pushBack draws no random numbers, so taking all
+        // K frames first -- which the hand-over of the next frame needs -- keeps the draw order)
         for (int i = 0; i < K; i++) {
-            const int32_t rc = svh_vo_process(vs[i], I1[i], I2[i], dims, replace);
+            const int32_t rc = svh_matcher_push_back(ms[i], I1 ? I1[i] : nullptr, I2 ? I2[i] : nullptr, dims, replace);
+            if (rc < 0 && rc != SVH_ERR_BAD_ARG) return rc;
+        }
+        if (N1) {
+            const int32_t rc = svh_matcher_prefetch_batch(ms.data(), K, N1, N2, dims);
+            if (rc < 0) return rc;
+        }
+        for (int i = 0; i < K; i++) {
+            const int32_t rc = process_after_push(vs[i]);
             if (rc < 0) return rc;
             if (ok) ok[i] = rc;
             good += rc > 0;
@@ -343,14 +363,14 @@ int32_t svh_vo_process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const*
     double tt[5] = {0, 0, 0, 0, 0};
     if (timing) tt[0] = now();
     const svh_vo_params& P = vs[0]->p;
-    std::vector<svh_matcher*> ms(K);
     std::vector<const double*> trs(K);
-    for (int i = 0; i < K; i++) {
-        ms[i] = vs[i]->matcher;
-        trs[i] = vs[i]->Tr;
-    }
+    for (int i = 0; i < K; i++) trs[i] = vs[i]->Tr;
     int32_t rc = svh_matcher_push_back_batch(ms.data(), K, I1, I2, dims, replace);
     if (rc < 0 && rc != SVH_ERR_BAD_ARG) return rc;
+    if (N1) {   // the next frame goes out now: its packing, upload and features overlap everything below
+        rc = svh_matcher_prefetch_batch(ms.data(), K, N1, N2, dims);
+        if (rc < 0) return rc;
+    }
     if (timing) tt[1] = now();
     rc = svh_matcher_match_features_batch(ms.data(), K, 2, trs.data());
     if (rc < 0) return rc;
@@ -418,6 +438,35 @@ int32_t svh_vo_process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const*
         acc.calls++;
     }
     return good;
+}
+
+int32_t svh_vo_process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const* I1, const uint8_t* const* I2,
+                             const int32_t* dims, int32_t replace, int32_t* ok) {
+    return process_batch(vs, K, I1, I2, dims, replace, ok, nullptr, nullptr);
+}
+
+// The pipelined form: processes the frame handed over before (svh_vo_prefetch_batch, or the `next` images of the
+// previous call) and hands over the next one (next_I1 / next_I2, or NULL at the end of the sequence) right after
+// the ring buffers rotated, so that its packing, upload and feature extraction overlap this frame's matching and
+// motion estimate.  Results are those of svh_vo_process_batch with the images passed directly.
+int32_t svh_vo_process_next_batch(svh_vo* const* vs, int32_t K, const uint8_t* const* next_I1,
+                                  const uint8_t* const* next_I2, const int32_t* dims, int32_t replace, int32_t* ok) {
+    if ((!next_I1) != (!next_I2)) return svh::fail(SVH_ERR_BAD_ARG, "null argument");
+    return process_batch(vs, K, nullptr, nullptr, dims, replace, ok, next_I1, next_I2);
+}
+
+// The NEXT frame of the K objects handed over early (svh_matcher_prefetch_batch).  Per iteration: prefetch frame
+// t+1, then svh_vo_process_batch without images for frame t (prefetched in the iteration before): the packing,
+// upload and feature extraction of t+1 overlap the matching and the motion estimate of t.
+int32_t svh_vo_prefetch_batch(svh_vo* const* vs, int32_t K, const uint8_t* const* I1, const uint8_t* const* I2,
+                              const int32_t* dims) {
+    if (!vs || K <= 0 || !I1 || !I2 || !dims) return svh::fail(SVH_ERR_BAD_ARG, "null argument");
+    std::vector<svh_matcher*> ms(K);
+    for (int i = 0; i < K; i++) {
+        if (!vs[i]) return svh::fail(SVH_ERR_BAD_ARG, "null object in the batch");
+        ms[i] = vs[i]->matcher;
+    }
+    return svh_matcher_prefetch_batch(ms.data(), K, I1, I2, dims);
 }
 
 int32_t svh_vo_process_matches(svh_vo* v, const svh_p_match* matches, int32_t n) {

@@ -732,22 +732,94 @@ def _ptr_array(arrs):
     return (C.c_void_p * len(arrs))(*[None if a is None else a.ctypes.data for a in arrs])
 
 
-def product_vo_process_batch(vos, I1s, I2s, replace=False):
-    """svh_vo_process_batch: one frame for K ProductVo objects; returns (n_ok, per-object return values)"""
+def product_vo_process_batch(vos, I1s, I2s, replace=False, shape=None):
+    """svh_vo_process_batch: one frame for K ProductVo objects; returns (n_ok, per-object return values).
+    I1s = I2s = None (+ shape = (h, w)): the objects take the frame handed over by product_vo_prefetch_batch"""
     import svhip as S
     lib = S.lib()
     lib.svh_vo_process_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p]
     K = len(vos)
+    p1 = p2 = None
+    if I1s is not None:
+        I1s = [np.ascontiguousarray(a, np.uint8) for a in I1s]
+        I2s = [np.ascontiguousarray(a, np.uint8) for a in I2s]
+        shape = I1s[0].shape
+        p1, p2 = _ptr_array(I1s), _ptr_array(I2s)
+    dims = (C.c_int32 * 3)(shape[1], shape[0], shape[1])
+    hs = (C.c_void_p * K)(*[v.h for v in vos])
+    ok = np.full(K, -99, np.int32)
+    rc = lib.svh_vo_process_batch(hs, K, p1, p2, dims, int(replace), _p(ok))
+    if rc < 0:
+        raise S.SvhError(rc, S.last_error())
+    return rc, ok
+
+
+def product_vo_process_next_batch(vos, next_I1s, next_I2s, shape, replace=False):
+    """svh_vo_process_next_batch: process the frame handed over before, hand over the next one (or None)"""
+    import svhip as S
+    lib = S.lib()
+    lib.svh_vo_process_next_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                              C.c_void_p]
+    K = len(vos)
+    p1 = p2 = None
+    if next_I1s is not None:
+        next_I1s = [np.ascontiguousarray(a, np.uint8) for a in next_I1s]
+        next_I2s = [np.ascontiguousarray(a, np.uint8) for a in next_I2s]
+        p1, p2 = _ptr_array(next_I1s), _ptr_array(next_I2s)
+    dims = (C.c_int32 * 3)(shape[1], shape[0], shape[1])
+    hs = (C.c_void_p * K)(*[v.h for v in vos])
+    ok = np.full(K, -99, np.int32)
+    rc = lib.svh_vo_process_next_batch(hs, K, p1, p2, dims, int(replace), _p(ok))
+    if rc < 0:
+        raise S.SvhError(rc, S.last_error())
+    return rc, ok
+
+
+def product_vo_prefetch_batch(vos, I1s, I2s):
+    """svh_vo_prefetch_batch: the NEXT frame of K ProductVo objects, handed over early (returns at once)"""
+    import svhip as S
+    lib = S.lib()
+    lib.svh_vo_prefetch_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    K = len(vos)
     I1s = [np.ascontiguousarray(a, np.uint8) for a in I1s]
     I2s = [np.ascontiguousarray(a, np.uint8) for a in I2s]
     dims = (C.c_int32 * 3)(I1s[0].shape[1], I1s[0].shape[0], I1s[0].shape[1])
     hs = (C.c_void_p * K)(*[v.h for v in vos])
-    ok = np.full(K, -99, np.int32)
-    rc = lib.svh_vo_process_batch(hs, K, _ptr_array(I1s), _ptr_array(I2s), dims, int(replace), _p(ok))
+    rc = lib.svh_vo_prefetch_batch(hs, K, _ptr_array(I1s), _ptr_array(I2s), dims)
     if rc < 0:
         raise S.SvhError(rc, S.last_error())
-    return rc, ok
+    return rc
+
+
+def product_matcher_prefetch(ms, I1s, I2s):
+    """svh_matcher_prefetch_batch"""
+    import svhip as S
+    lib = S.lib()
+    lib.svh_matcher_prefetch_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    K = len(ms)
+    hs = (C.c_void_p * K)(*[m.h for m in ms])
+    I1s = [np.ascontiguousarray(a, np.uint8) for a in I1s]
+    I2s = None if I2s is None else [np.ascontiguousarray(a, np.uint8) for a in I2s]
+    dims = (C.c_int32 * 3)(I1s[0].shape[1], I1s[0].shape[0], I1s[0].shape[1])
+    rc = lib.svh_matcher_prefetch_batch(hs, K, _ptr_array(I1s), None if I2s is None else _ptr_array(I2s), dims)
+    if rc < 0:
+        raise S.SvhError(rc, S.last_error())
+    return rc
+
+
+def product_matcher_take_prefetched(ms, shape, replace=False):
+    """svh_matcher_push_back_batch without images: the objects take their prefetched frame"""
+    import svhip as S
+    lib = S.lib()
+    lib.svh_matcher_push_back_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    K = len(ms)
+    hs = (C.c_void_p * K)(*[m.h for m in ms])
+    dims = (C.c_int32 * 3)(shape[1], shape[0], shape[1])
+    rc = lib.svh_matcher_push_back_batch(hs, K, None, None, dims, int(replace))
+    if rc < 0:
+        raise S.SvhError(rc, S.last_error())
+    return rc
 
 
 def product_matcher_batch(ms, I1s, I2s, method, Trs=None, replace=False, push=True):

@@ -247,3 +247,80 @@ def test_private_rand_objects_in_a_batch_equal_objects_alone_in_a_process():
             assert np.array_equal(vos[k].inliers(), w[2]), ("inliers", i, k)
             got = vos[k].matches()
             assert len(got) == len(w[3]) and (got == w[3]).all(), ("matches", i, k)
+
+
+@pytest.mark.parametrize("K", [1, 5])
+def test_prefetched_frames_equal_plain_calls(K):
+    """svh_matcher_prefetch_batch: frame t+1 is packed, uploaded and its features computed while frame t is matched;
+    feature tables and matches of every frame equal those of plain pushBack / matchFeatures calls (K = 1: the
+    one-by-one path of the entry; replace = 1 on one frame)"""
+    prm = H.matcher_defaults()
+    im = quad()
+    seqs = [variant(im, k) for k in range(K)]
+    frames = [(0, 1), (2, 3), (0, 1), (2, 3), (0, 1)]
+    replace = [False, False, False, True, False]
+    plain = [plain_matcher(prm) for _ in range(K)]
+    want = []
+    for f, (a, b) in enumerate(frames):
+        for k, m in enumerate(plain):
+            m.push_back(seqs[k][a], seqs[k][b], replace=replace[f])
+            m.match(2)
+        want.append([(m.matches().copy(), [m.features(tb).copy() for tb in range(8)]) for m in plain])
+    pre = [plain_matcher(prm) for _ in range(K)]
+    shape = seqs[0][0].shape
+    H.product_matcher_prefetch(pre, [s[frames[0][0]] for s in seqs], [s[frames[0][1]] for s in seqs])
+    for f in range(len(frames)):
+        H.product_matcher_take_prefetched(pre, shape, replace=replace[f])
+        if f + 1 < len(frames):   # the next frame goes out BEFORE this one is matched
+            a, b = frames[f + 1]
+            H.product_matcher_prefetch(pre, [s[a] for s in seqs], [s[b] for s in seqs])
+        H.product_matcher_batch(pre, None, None, 2, push=False)
+        for k in range(K):
+            got = pre[k].matches()
+            assert len(got) == len(want[f][k][0]) and (got == want[f][k][0]).all(), (f, k)
+            for tb in range(8):
+                assert np.array_equal(pre[k].features(tb), want[f][k][1][tb]), (f, k, tb)
+    # misuse: two prefetches in a row; images while a prefetched frame is pending; nothing to take
+    import svhip as S
+    H.product_matcher_prefetch(pre, [s[0] for s in seqs], [s[1] for s in seqs])
+    with pytest.raises(S.SvhError):
+        H.product_matcher_prefetch(pre, [s[0] for s in seqs], [s[1] for s in seqs])
+    with pytest.raises(S.SvhError):
+        H.product_matcher_batch(pre, [s[0] for s in seqs], [s[1] for s in seqs], None)
+    H.product_matcher_take_prefetched(pre, shape)
+    with pytest.raises(S.SvhError):
+        H.product_matcher_take_prefetched(pre, shape)
+
+
+@pytest.mark.parametrize("private", [True, False])
+def test_vo_pipelined_loop_equals_plain_loop(private):
+    """svh_vo_prefetch_batch + svh_vo_process_next_batch (frame t+1 handed over while frame t is matched) give the
+    return values, motions, inliers and matches of svh_vo_process_batch with the images passed directly --
+    bootstrap frames (one-by-one path) included; with libc rand() the draw order is the same in both loops"""
+    K, frames = 4, 8
+    prm = H.vo_defaults()
+    im = quad()
+    seqs = [variant(im, k) for k in range(K)]
+    pick = lambda i: ([s[0] if i % 2 == 0 else s[2] for s in seqs], [s[1] if i % 2 == 0 else s[3] for s in seqs])
+    seed = 0 if private else None
+    plain = [H.ProductVo(prm, private_rand=seed) for _ in range(K)]
+    LIBC.srand(11)
+    want = []
+    for i in range(frames):
+        _, ok = H.product_vo_process_batch(plain, *pick(i))
+        want.append((list(ok), [v.motion().copy() for v in plain], [v.inliers().copy() for v in plain],
+                     [v.matches().copy() for v in plain]))
+    assert sum(sum(o == 1 for o in w[0]) for w in want) >= K * (frames - 2)
+    pipe = [H.ProductVo(prm, private_rand=seed) for _ in range(K)]
+    LIBC.srand(11)
+    shape = seqs[0][0].shape
+    H.product_vo_prefetch_batch(pipe, *pick(0))
+    for i in range(frames):
+        nxt = pick(i + 1) if i + 1 < frames else (None, None)
+        _, ok = H.product_vo_process_next_batch(pipe, nxt[0], nxt[1], shape)
+        assert list(ok) == want[i][0], i
+        for k in range(K):
+            assert np.array_equal(pipe[k].motion(), want[i][1][k]), ("motion", i, k)
+            assert np.array_equal(pipe[k].inliers(), want[i][2][k]), ("inliers", i, k)
+            got = pipe[k].matches()
+            assert len(got) == len(want[i][3][k]) and (got == want[i][3][k]).all(), ("matches", i, k)

@@ -25,6 +25,8 @@ if which.startswith("replicas"):   # replicas, replicas16, ...
     out["vo_replicas"] = bench.vo_replicas_bench(ks=ks, frames=60)
 if which.startswith("lockstep"):   # lockstep, lockstep16, ...
     shapes = (tuple(int(x) for x in which[8:].split("x")),) if which[8:] else None   # lockstep2x8 = 2 threads x 8
+    pl = os.environ.get("LOCKSTEP_PIPELINED")   # 0 / 1: only that form
     out["vo_lockstep"] = bench.vo_lockstep_bench(frames=60, private_rand=os.environ.get("LOCKSTEP_LIBC_RAND") is None,
+                                                 pipelined=(False, True) if pl is None else (pl == "1",),
                                                  **({"shapes": shapes} if shapes else {}))
 print(json.dumps(out))

@@ -52,6 +52,7 @@ hipError_t hipStreamSynchronize(hipStream_t s) { if (s) reinterpret_cast<StubStr
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(new int(0)); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<int*>(e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { return hipSuccess; }
 hipError_t hipStreamQuery(hipStream_t s) {
     if (!s) return hipSuccess;
@@ -182,11 +183,18 @@ int main(int argc, char** argv) {
         p.f = 645.2; p.cu = 320.0; p.cv = 100.0; p.base = 0.57;
         std::vector<svh_vo*> vs(n);
         for (int i = 0; i < n; i++) vs[i] = svh_vo_create(&p);
-        std::vector<std::vector<uint8_t>> I1(n, std::vector<uint8_t>((size_t)W * H)), I2 = I1;
+        // two sets of image buffers: a frame handed over early is read (prefetch thread) until it is TAKEN by the
+        // next call, so the caller fills the other set meanwhile -- the contract of svh_vo_prefetch_batch
+        std::vector<std::vector<uint8_t>> Ia[2], Ib[2];
+        for (int q = 0; q < 2; q++) {
+            Ia[q].assign(n, std::vector<uint8_t>((size_t)W * H));
+            Ib[q] = Ia[q];
+        }
         std::vector<const uint8_t*> p1(n), p2(n);
         std::vector<int32_t> ok(n);
         const int32_t dims[3] = {W, H, W};
         for (int f = 0; f < frames; f++) {
+            std::vector<std::vector<uint8_t>>&I1 = Ia[f & 1], &I2 = Ib[f & 1];
             for (int i = 0; i < n; i++) {
                 for (size_t j = 0; j < I1[i].size(); j++) {
                     I1[i][j] = (uint8_t)(svh::mix((uint32_t)(j + 977 * f + 31 * i + 7777 * id)) >> 24);
@@ -195,7 +203,16 @@ int main(int argc, char** argv) {
                 p1[i] = I1[i].data();
                 p2[i] = I2[i].data();
             }
-            if (svh_vo_process_batch(vs.data(), n, p1.data(), p2.data(), dims, 0, ok.data()) < 0) bad++;
+            // thread 1: images with the call; thread 2: the pipelined loop (frame f handed over one call earlier)
+            if (id == 1) {
+                if (svh_vo_process_batch(vs.data(), n, p1.data(), p2.data(), dims, 0, ok.data()) < 0) bad++;
+            } else {
+                if (f == 0) {
+                    if (svh_vo_prefetch_batch(vs.data(), n, p1.data(), p2.data(), dims) < 0) bad++;
+                } else if (svh_vo_process_next_batch(vs.data(), n, p1.data(), p2.data(), dims, 0, ok.data()) < 0) {
+                    bad++;   // (processes frame f - 1, hands over frame f)
+                }
+            }
             for (int i = 0; i < n; i++) matches += svh_vo_num_matches(vs[i]);
         }
         for (svh_vo* v : vs) svh_vo_destroy(v);
