@@ -929,7 +929,7 @@ void svh_matcher_set_intrinsics(svh_matcher* m, double f, double cu, double cv, 
 
 // pushBack up to the device work: argument checks, ring-buffer rotation, buffers.  `src` = the two rows of images
 // takes the prefetched frame: waits for its device work, rotates it into `cur`
-static int32_t push_take_prefetched(svh_matcher* m, int32_t replace) {
+static int32_t push_take_prefetched(svh_matcher* m, int32_t replace, bool stream_waited = false) {
     if (m->next_job.valid()) {
         const int32_t rc = m->next_job.get();
         m->next_job = std::shared_future<int32_t>();
@@ -938,9 +938,11 @@ static int32_t push_take_prefetched(svh_matcher* m, int32_t replace) {
             return mfail(rc, "the hand-over of the prefetched frame failed on the prefetch thread");
         }
     }
-    HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY((hipError_t)wait_stream(m->next_stream));
-    HIP_TRY(hipGetLastError());
+    if (!stream_waited) {
+        HIP_TRY(hipSetDevice(m->device));
+        HIP_TRY((hipError_t)wait_stream(m->next_stream));
+        HIP_TRY(hipGetLastError());
+    }
     for (int k = 0; k < 2; k++) {
         if (!replace) {
             // ring buffer: current -> previous, prefetched -> current; the old previous buffers are recycled
@@ -1161,8 +1163,27 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
         // no images: every object takes the frame handed over by svh_matcher_prefetch_batch
         for (int i = 0; i < K; i++)
             if (!ms[i] || !ms[i]->has_next) return mfail(SVH_ERR_BAD_ARG, "no images and no prefetched frame");
+        // (the objects of a lockstep hand-over share one stream: wait for each distinct stream once)
+        std::vector<hipStream_t> waited;
         for (int i = 0; i < K; i++) {
-            const int32_t rc = push_take_prefetched(ms[i], replace);
+            svh_matcher* m = ms[i];
+            if (m->next_job.valid()) {
+                const int32_t rc = m->next_job.get();
+                m->next_job = std::shared_future<int32_t>();
+                if (rc) {
+                    m->has_next = false;
+                    return mfail(rc, "the hand-over of the prefetched frame failed on the prefetch thread");
+                }
+            }
+            if (std::find(waited.begin(), waited.end(), m->next_stream) == waited.end()) {
+                HIP_TRY(hipSetDevice(m->device));
+                HIP_TRY((hipError_t)wait_stream(m->next_stream));
+                waited.push_back(m->next_stream);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        for (int i = 0; i < K; i++) {
+            const int32_t rc = push_take_prefetched(ms[i], replace, true);
             if (rc) return rc;
         }
         return SVH_OK;

@@ -50,9 +50,11 @@ kt hd1080_b8 python $R/bench.py --workload hd1080 --batch 8 --no-extras --no-cpu
 kt sequence python $R/bench.py --workload sequence --no-extras --no-cpu-baseline --steps 20 --warmup 3
 kt matcher python $R/tools/gpu_legs.py matcher
 kt vo python $R/tools/gpu_legs.py vo
-kt vo_lockstep16 python $R/tools/gpu_legs.py lockstep1x16
+LOCKSTEP_PIPELINED=0 kt vo_lockstep16 python $R/tools/gpu_legs.py lockstep1x16
+LOCKSTEP_PIPELINED=1 kt vo_lockstep16_pipelined python $R/tools/gpu_legs.py lockstep1x16
 kt vo_replicas16 python $R/tools/gpu_legs.py replicas16
-SVH_MATCHER_TIMING=1 timeout 300 python $R/tools/gpu_legs.py lockstep1x16 2>&1 | python $R/tools/show_lockstep.py > $O/lockstep_phases.txt
+LOCKSTEP_PIPELINED=0 SVH_MATCHER_TIMING=1 timeout 300 python $R/tools/gpu_legs.py lockstep1x16 2>&1 | python $R/tools/show_lockstep.py > $O/lockstep_phases.txt
+LOCKSTEP_PIPELINED=1 SVH_MATCHER_TIMING=1 timeout 300 python $R/tools/gpu_legs.py lockstep1x16 2>&1 | python $R/tools/show_lockstep.py > $O/lockstep_phases_pipelined.txt
 LOCKSTEP_LIBC_RAND=1 timeout 300 python $R/tools/gpu_legs.py lockstep 2>&1 | python $R/tools/show_lockstep.py > $O/lockstep_libc_rand.txt
 python - <<PY
 import json, glob, os
