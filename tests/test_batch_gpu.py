@@ -324,3 +324,40 @@ def test_vo_pipelined_loop_equals_plain_loop(private):
             assert np.array_equal(pipe[k].inliers(), want[i][2][k]), ("inliers", i, k)
             got = pipe[k].matches()
             assert len(got) == len(want[i][3][k]) and (got == want[i][3][k]).all(), ("matches", i, k)
+
+
+@pytest.mark.parametrize("seed", range(300, 312))
+def test_param_fuzz_lockstep_equals_separate_calls(seed):
+    """random points of Matcher::parameters x method x ragged crop x predicted motion (helpers.fuzz_matcher_case,
+    the generator of the oracle fuzz in test_matcher_gpu.py), K objects with different crops of the same size:
+    the lockstep entries (plain and with the frame handed over early) equal the single calls, tables and matches"""
+    prm, method, crop, tr = H.fuzz_matcher_case(seed)
+    rng = np.random.default_rng(seed)
+    K = int(rng.integers(2, 7))
+    im = quad()
+    h, w = crop[0].stop - crop[0].start, crop[1].stop - crop[1].start
+    seqs = []
+    for k in range(K):
+        x0, y0 = int(rng.integers(0, im[0].shape[1] - w)), int(rng.integers(0, im[0].shape[0] - h))
+        seqs.append([np.ascontiguousarray(a[y0:y0 + h, x0:x0 + w]) for a in im])
+    stereo = method != 0 or bool(rng.integers(0, 2))     # flow may run on single images
+    second = (lambda s, j: s[j]) if stereo else (lambda s, j: None)
+    one = [plain_matcher(prm) for _ in range(K)]
+    for k, m in enumerate(one):
+        m.push_back(seqs[k][0], second(seqs[k], 1))
+        m.push_back(seqs[k][2], second(seqs[k], 3))
+        m.match(method, tr)
+    I2 = lambda j: [s[j] for s in seqs] if stereo else None
+    trs = None if tr is None else [tr] * K
+    bat = [plain_matcher(prm) for _ in range(K)]
+    H.product_matcher_batch(bat, [s[0] for s in seqs], I2(1), None)
+    H.product_matcher_batch(bat, [s[2] for s in seqs], I2(3), method, trs)
+    pre = [plain_matcher(prm) for _ in range(K)]
+    H.product_matcher_prefetch(pre, [s[0] for s in seqs], I2(1))
+    H.product_matcher_take_prefetched(pre, (h, w))
+    H.product_matcher_prefetch(pre, [s[2] for s in seqs], I2(3))
+    H.product_matcher_take_prefetched(pre, (h, w))
+    H.product_matcher_batch(pre, None, None, method, trs, push=False)
+    for k in range(K):
+        same_matcher_state(one[k], bat[k], ("lockstep", seed, k))
+        same_matcher_state(one[k], pre[k], ("handed over early", seed, k))
