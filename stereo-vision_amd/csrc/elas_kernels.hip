@@ -85,10 +85,6 @@ __device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
     const u32x4_t q = *(__attribute__((address_space(3))) const u32x4_t*)(uintptr_t)addr;
     return make_uint4(q.x, q.y, q.z, q.w);
 }
-__device__ __forceinline__ void lds_write16(uint32_t addr, const uint4& v) {
-    u32x4_t q = {v.x, v.y, v.z, v.w};
-    *(__attribute__((address_space(3))) u32x4_t*)(uintptr_t)addr = q;
-}
 __device__ __forceinline__ uint2 lds_read8(uint32_t addr) {
     const u32x2_t q = *(__attribute__((address_space(3))) const u32x2_t*)(uintptr_t)addr;
     return make_uint2(q.x, q.y);
@@ -264,205 +260,6 @@ __global__ __launch_bounds__(256) void k_descriptor_stream(DevImages img, int W,
             z2 = z1; z1 = Zc;
         }
     }
-}
-
-// ---------------------------------------------------------------------------
-// E1+E2 again, FOUR columns per lane on packed 16-bit pairs (round 4).  Same walk as k_descriptor_stream (a
-// wave walks a strip of columns down a segment of rows, everything of the last rows rides in registers), but a
-// lane owns the four pixels of one aligned-to-its-strip 32-bit word:
-//   * the vertical sums 1 2 1 / 1 0 -1 of its four columns are two v_pk_* operations per pair of columns, the
-//     horizontal step takes the neighbour pairs from the adjacent lanes (DPP) and v_alignbyte for the odd shifts;
-//   * du / dv of the four pixels are packed back into one word each; the byte triples / pairs a descriptor takes
-//     from one row (du at x-2, x, x+2; du at x-1, x, x, x+1; dv at x-1, x+1) are ONE v_perm_b32 per pixel and
-//     row over (left word, own word) or (own word, right word); merging the rows of a descriptor is one v_perm
-//     per output dword.
-// ~21 operations per pixel and row instead of ~54; lanes 0 and 63 only carry the halo words.  Every value is the
-// integer of the byte kernel (all intermediates fit 16 bits), so the descriptors are identical.
-// ---------------------------------------------------------------------------
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32_unaligned_t __attribute__((aligned(1)));
-__device__ __forceinline__ s16x2 dp_pair01(uint32_t w) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c010c00u)); }
-__device__ __forceinline__ s16x2 dp_pair23(uint32_t w) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c030c02u)); }
-// (a.hi, b.lo): the pair one column to the right of a, b being the next pair
-__device__ __forceinline__ s16x2 dp_mid(s16x2 a, s16x2 b) {
-    return __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbyte(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 2u));
-}
-__device__ __forceinline__ s16x2 dp_prev(s16x2 v) { return __builtin_bit_cast(s16x2, lane_prev(__builtin_bit_cast(int, v))); }
-__device__ __forceinline__ s16x2 dp_next(s16x2 v) { return __builtin_bit_cast(s16x2, lane_next(__builtin_bit_cast(int, v))); }
-__device__ __forceinline__ s16x2 dp_sobel_out(s16x2 v) {   // sat_u8((v >> 2) + 128)
-    const s16x2 lo = {0, 0}, hi = {255, 255}, off = {128, 128};
-    return __builtin_elementwise_min(__builtin_elementwise_max((v >> 2) + off, lo), hi);
-}
-// low bytes of four 16-bit values -> one word
-__device__ __forceinline__ uint32_t dp_bytes(s16x2 lo, s16x2 hi) {
-    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
-}
-// v_perm_b32 selector bytes: 0..3 = bytes of `lo` (second operand), 4..7 = bytes of `hi` (first operand)
-#define DP_SEL(b0, b1, b2, b3) ((uint32_t)(b0) | (uint32_t)(b1) << 8 | (uint32_t)(b2) << 16 | (uint32_t)(b3) << 24)
-
-constexpr int DP_LANES = 62;   // lanes 1 .. 62 write (4 columns each); 0 and 63 are halo lanes
-
-// kPlain: every row of the segment and every column of the strip carries a descriptor (no zero rows, no masks)
-template <int DS_ROWS, int DS_CHUNK, bool kPlain>
-__device__ __forceinline__ void descriptor_walk_pk(const DevImages& img, int W, int H, int half, int cols, int seg, int strip,
-                                                   uint8_t* __restrict__ desc_all, uint4* s_t) {
-    const int lane = threadIdx.x & 63;
-    const int pair = blockIdx.y >> 1, im = blockIdx.y & 1;
-    const int x = strip * cols + 4 * (lane - 1);        // first of this lane's four columns
-    const int ys = seg * DS_ROWS;
-    const bool writes = lane >= 1 && 4 * (lane - 1) < cols && x < W;
-    // One unconditional 32-bit load per lane and row, from an address that always lies inside the row: the last
-    // word of a row whose width is not a multiple of 4 is read at W-4 and shifted down, lanes left or right of
-    // the image read column 0 and are masked to zero (W >= 4: the engine's minimum width is far above).
-    const bool in_row = x >= 0 && x < W;
-    const int over = in_row && x + 3 >= W ? x + 4 - W : 0;           // bytes of the word beyond the row: 0 .. 3
-    const uint32_t lane_mask = in_row ? 0xFFFFFFFFu : 0u, lane_shift = 8u * (uint32_t)over;
-    const uint8_t* __restrict__ src = img.I[im] + (size_t)pair * img.stride + (in_row ? x - over : 0);
-    const int pitch = img.pitch;
-    // The 64 bytes a lane produces per row (4 pixels x 16) leave through LDS so that every store instruction of the
-    // wave writes 1 KB of consecutive memory: pixel p = 4 lane + i of the strip goes to slot p + (p >> 4) (the
-    // offset makes both the 64-byte-strided writes and the consecutive reads conflict-free), store j of lane l
-    // takes pixel 64 j + l.
-    uint32_t wr_addr[4], rd_addr[4];
-    bool st_ok[4];
-    const uint32_t t_base = lds_addr_of(s_t);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int pw = 4 * lane + i, pr = 64 * i + lane;
-        wr_addr[i] = t_base + (uint32_t)(pw + (pw >> 4)) * 16u;
-        rd_addr[i] = t_base + (uint32_t)(pr + (pr >> 4)) * 16u;
-        const int xc = strip * cols - 4 + pr;            // column of the pixel this lane stores in pass i
-        st_ok[i] = pr >= 4 && pr < 4 + cols && xc < W;
-    }
-    const int x_st = strip * cols - 4 + lane;            // column of pass 0 (+ 64 per pass)
-    uint4* __restrict__ dst = reinterpret_cast<uint4*>(desc_all + (size_t)blockIdx.y * W * H * 16);
-    // columns 3 .. W-4 carry descriptors: per pixel all ones / zero (only the first and last strip have zeros)
-    uint32_t cm[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) cm[i] = (x + i >= 3 && x + i < W - 3) ? 0xFFFFFFFFu : 0u;
-    const bool edge = __builtin_amdgcn_ballot_w64(writes && (cm[0] & cm[1] & cm[2] & cm[3]) == 0u) != 0;
-
-    s16x2 a1[2] = {{0, 0}, {0, 0}}, a2[2] = {{0, 0}, {0, 0}};     // image pairs (x, x+1), (x+2, x+3) of rows r-1, r-2
-    uint32_t D1 = 0, D2 = 0, D3 = 0, D4 = 0;     // own du words of the centre rows c-1 .. c-4
-    uint32_t V1 = 0, V2 = 0, V3 = 0;             // own dv words of rows c-1 .. c-3
-    uint32_t W1[4] = {0, 0, 0, 0}, W2[4] = {0, 0, 0, 0}, W3[4] = {0, 0, 0, 0};   // du[x-2] | du[x] << 8 | du[x+2] << 16, rows c-1 .. c-3
-    uint32_t Y1[4] = {0, 0, 0, 0}, Y2[4] = {0, 0, 0, 0};                         // du[x-1] | du[x] << 8 | du[x] << 16 | du[x+1] << 24, rows c-1, c-2
-    uint32_t Z1[4] = {0, 0, 0, 0}, Z2[4] = {0, 0, 0, 0};                         // dv[x-1] << 8 | dv[x+1] << 16, rows c-1, c-2
-    for (int r0 = ys - 3; r0 < ys + DS_ROWS + 3; r0 += DS_CHUNK) {
-        if (r0 - 3 >= H) break;                  // nothing below the image is written
-        uint32_t px[DS_CHUNK];
-#pragma unroll
-        for (int k = 0; k < DS_CHUNK; k++) {
-            const int r = r0 + k;
-            const int rc = r < 0 ? 0 : (r < H ? r : H - 1);
-            const uint32_t row_mask = (r >= 0 && r < H) ? lane_mask : 0u;      // (rows outside the image are zero)
-            const uint32_t w = *reinterpret_cast<const u32_unaligned_t*>(src + (size_t)rc * pitch);
-            px[k] = (w >> lane_shift) & row_mask;
-        }
-#pragma unroll
-        for (int k = 0; k < DS_CHUNK; k++) {
-            const int r = r0 + k;
-            const s16x2 p0 = dp_pair01(px[k]), p1 = dp_pair23(px[k]);
-            const s16x2 two = {2, 2};
-            // centre row c = r-1: vertical 1 2 1 and 1 0 -1 of the four columns, then across the columns
-            const s16x2 S0 = a2[0] + two * a1[0] + p0, S1 = a2[1] + two * a1[1] + p1;
-            const s16x2 T0 = a2[0] - p0, T1 = a2[1] - p1;
-            a2[0] = a1[0]; a2[1] = a1[1];
-            a1[0] = p0; a1[1] = p1;
-            const s16x2 SL = dp_prev(S1), SR = dp_next(S0), TL = dp_prev(T1), TR = dp_next(T0);
-            const s16x2 Sm0 = dp_mid(SL, S0), Sm1 = dp_mid(S0, S1), Sm2 = dp_mid(S1, SR);   // columns (x-1,x) (x+1,x+2) (x+3,x+4)
-            const s16x2 Tm0 = dp_mid(TL, T0), Tm1 = dp_mid(T0, T1), Tm2 = dp_mid(T1, TR);
-            const uint32_t Dw = dp_bytes(dp_sobel_out(Sm0 - Sm1), dp_sobel_out(Sm1 - Sm2));
-            const uint32_t Vw = dp_bytes(dp_sobel_out(Tm0 + two * T0 + Tm1), dp_sobel_out(Tm1 + two * T1 + Tm2));
-            const uint32_t DL = (uint32_t)lane_prev((int)Dw), DR = (uint32_t)lane_next((int)Dw);
-            const uint32_t VL = (uint32_t)lane_prev((int)Vw), VR = (uint32_t)lane_next((int)Vw);
-            // per pixel and row: the bytes a descriptor takes from this row (perm(hi, lo, sel): 0-3 = lo, 4-7 = hi)
-            uint32_t Wc[4], Yc[4], Zc[4];
-            Wc[0] = __builtin_amdgcn_perm(Dw, DL, DP_SEL(2, 4, 6, 0x0c));      // x-2, x, x+2
-            Wc[1] = __builtin_amdgcn_perm(Dw, DL, DP_SEL(3, 5, 7, 0x0c));      // x-1, x+1, x+3
-            Wc[2] = __builtin_amdgcn_perm(DR, Dw, DP_SEL(0, 2, 4, 0x0c));      // x, x+2, x+4
-            Wc[3] = __builtin_amdgcn_perm(DR, Dw, DP_SEL(1, 3, 5, 0x0c));      // x+1, x+3, x+5
-            Yc[0] = __builtin_amdgcn_perm(Dw, DL, DP_SEL(3, 4, 4, 5));         // x-1, x, x, x+1
-            Yc[1] = __builtin_amdgcn_perm(Dw, Dw, DP_SEL(0, 1, 1, 2));
-            Yc[2] = __builtin_amdgcn_perm(Dw, Dw, DP_SEL(1, 2, 2, 3));
-            Yc[3] = __builtin_amdgcn_perm(DR, Dw, DP_SEL(2, 3, 3, 4));
-            Zc[0] = __builtin_amdgcn_perm(Vw, VL, DP_SEL(0x0c, 3, 5, 0x0c));   // -, x-1, x+1, -
-            Zc[1] = __builtin_amdgcn_perm(Vw, Vw, DP_SEL(0x0c, 0, 2, 0x0c));
-            Zc[2] = __builtin_amdgcn_perm(Vw, Vw, DP_SEL(0x0c, 1, 3, 0x0c));
-            Zc[3] = __builtin_amdgcn_perm(VR, Vw, DP_SEL(0x0c, 2, 4, 0x0c));
-            // descriptors of row y = c-2 (descriptor.cpp:88-117)
-            const int y = r - 3;
-            if (y >= ys && y < ys + DS_ROWS && y < H) {
-                bool inside = true;
-                if (!kPlain) {
-                    inside = y >= 3 && y < H - 3;
-                    if (half) inside = inside && y >= 4 && (y & 1) == 0;
-                }
-                {
-                    uint4 out[4];
-                    if (inside) {   // (wave-uniform)
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            out[i].x = __builtin_amdgcn_perm(W3[i], D4, DP_SEL(i, 4, 5, 6));        // du(c-4, x) | W(c-3) << 8
-                            out[i].y = Y2[i];
-                            out[i].z = __builtin_amdgcn_perm(Dw, W1[i], DP_SEL(0, 1, 2, 4 + i));    // W(c-1) | du(c, x) << 24
-                            const uint32_t t = __builtin_amdgcn_perm(Z2[i], V3, DP_SEL(i, 5, 6, 0x0c));   // dv(c-3, x) | Z(c-2)
-                            out[i].w = __builtin_amdgcn_perm(V1, t, DP_SEL(0, 1, 2, 4 + i));        // ... | dv(c-1, x) << 24
-                        }
-                        if (!kPlain && edge) {   // (wave-uniform: the first and the last strip)
-#pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                out[i].x &= cm[i]; out[i].y &= cm[i]; out[i].z &= cm[i]; out[i].w &= cm[i];
-                            }
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; i++) lds_write16(wr_addr[i], out[i]);
-                        // (one wave writes and reads its own buffer: LDS operations of a wave complete in order)
-#pragma unroll
-                        for (int i = 0; i < 4; i++) out[i] = lds_read16(rd_addr[i]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; i++) out[i] = make_uint4(0, 0, 0, 0);
-                    }
-                    // streamed out, read again only after the whole group's descriptors are written
-                    uint4* q = dst + ((ptrdiff_t)y * W + x_st);   // (x_st < 0 only where pass 0 does not store)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        if (!st_ok[i]) continue;
-                        __builtin_nontemporal_store(out[i].x, &q[64 * i].x);
-                        __builtin_nontemporal_store(out[i].y, &q[64 * i].y);
-                        __builtin_nontemporal_store(out[i].z, &q[64 * i].z);
-                        __builtin_nontemporal_store(out[i].w, &q[64 * i].w);
-                    }
-                }
-            }
-            D4 = D3; D3 = D2; D2 = D1; D1 = Dw;
-            V3 = V2; V2 = V1; V1 = Vw;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                W3[i] = W2[i]; W2[i] = W1[i]; W1[i] = Wc[i];
-                Y2[i] = Y1[i]; Y1[i] = Yc[i];
-                Z2[i] = Z1[i]; Z1[i] = Zc[i];
-            }
-        }
-    }
-}
-
-template <int DS_ROWS, int DS_CHUNK>
-__global__ __launch_bounds__(256) void k_descriptor_pk(DevImages img, int W, int H, int half, int strips, int cols,
-                                                       int nwaves, uint8_t* __restrict__ desc_all) {
-    const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (wid >= nwaves) return;
-    const int seg = wid / strips, strip = wid - seg * strips;
-    const int ys = seg * DS_ROWS;
-    // the common case (all but the image's border strips / segments, full resolution): no zero rows, no masks
-    const bool plain = !half && ys >= 3 && ys + DS_ROWS <= H - 3 && strip > 0 && strip < strips - 1;
-    __shared__ uint4 s_turn[4][272];   // per wave: 256 pixels + 16 slots of skew
-    uint4* s_t = s_turn[threadIdx.x >> 6];
-    if (plain)
-        descriptor_walk_pk<DS_ROWS, DS_CHUNK, true>(img, W, H, half, cols, seg, strip, desc_all, s_t);
-    else
-        descriptor_walk_pk<DS_ROWS, DS_CHUNK, false>(img, W, H, half, cols, seg, strip, desc_all, s_t);
 }
 
 // ---------------------------------------------------------------------------
@@ -2312,16 +2109,6 @@ void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t g, int
     // than 42 .. 90 rows, all within 2 %
     constexpr int rows = 26, chunk = 16;
     static_assert((rows + 6) % chunk == 0, "the walk is a whole number of load chunks");
-    static const bool packed = !(getenv("SVH_DESC_PK") && atoi(getenv("SVH_DESC_PK")) == 0);
-    if (packed) {
-        // four columns per lane: the strips are balanced (1242 columns: 6 strips of 208 = 52 writing lanes)
-        const int strips = (W + 4 * DP_LANES - 1) / (4 * DP_LANES);
-        const int cols = 4 * ((W + 4 * strips - 1) / (4 * strips));
-        const int segs = (H + rows - 1) / rows, nwaves = strips * segs;
-        LAUNCH("k_descriptor", (k_descriptor_pk<rows, chunk>), dim3((nwaves + 3) / 4, 2 * g), dim3(256), img, W, H,
-               half, strips, cols, nwaves, desc);
-        return;
-    }
     const int strips = (W + DS_COLS - 1) / DS_COLS, segs = (H + rows - 1) / rows, nwaves = strips * segs;
     LAUNCH("k_descriptor", (k_descriptor_stream<rows, chunk>), dim3((nwaves + 3) / 4, 2 * g), dim3(256), img, W, H,
            half, strips, nwaves, desc);
