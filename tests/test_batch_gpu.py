@@ -292,12 +292,13 @@ def test_prefetched_frames_equal_plain_calls(K):
         H.product_matcher_take_prefetched(pre, shape)
 
 
-@pytest.mark.parametrize("private", [True, False])
-def test_vo_pipelined_loop_equals_plain_loop(private):
+@pytest.mark.parametrize("private,K", [(True, 4), (False, 4), (True, 1)])
+def test_vo_pipelined_loop_equals_plain_loop(private, K):
     """svh_vo_prefetch_batch + svh_vo_process_next_batch (frame t+1 handed over while frame t is matched) give the
     return values, motions, inliers and matches of svh_vo_process_batch with the images passed directly --
-    bootstrap frames (one-by-one path) included; with libc rand() the draw order is the same in both loops"""
-    K, frames = 4, 8
+    bootstrap frames (one-by-one path) included; with libc rand() the draw order is the same in both loops;
+    K = 1: a single object through the same entries"""
+    frames = 8
     prm = H.vo_defaults()
     im = quad()
     seqs = [variant(im, k) for k in range(K)]
