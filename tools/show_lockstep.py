@@ -1,3 +1,4 @@
+"""stdin: output of tools/gpu_legs.py lockstep... (stdout + stderr) -> one line per run + the phase timing lines"""
 import json,sys
 for line in sys.stdin:
     line=line.strip()
