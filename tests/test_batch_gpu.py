@@ -362,3 +362,35 @@ def test_param_fuzz_lockstep_equals_separate_calls(seed):
     for k in range(K):
         same_matcher_state(one[k], bat[k], ("lockstep", seed, k))
         same_matcher_state(one[k], pre[k], ("handed over early", seed, k))
+
+
+def test_lockstep_results_do_not_depend_on_batch_composition():
+    """size-independent properties of the lockstep entries: an object's tables and matches are the same whatever
+    its position in the batch, whoever its neighbours are and however large K is (1344x391, K = 2 .. 24), and
+    pushing the same frame again with replace = 1 changes nothing"""
+    prm = H.matcher_defaults()
+    im = quad()
+    rng = np.random.default_rng(5)
+    pool = [variant(im, k) for k in range(24)]
+    ref = {}
+    for K in (24, 2, 7):
+        ids = [int(i) for i in rng.permutation(24)[:K]]
+        if 0 not in ids:
+            ids[0] = 0
+        ms = [plain_matcher(prm) for _ in ids]
+        H.product_matcher_batch(ms, [pool[i][0] for i in ids], [pool[i][1] for i in ids], None)
+        H.product_matcher_batch(ms, [pool[i][2] for i in ids], [pool[i][3] for i in ids], 2)
+        for m, i in zip(ms, ids):
+            got = (m.matches().copy(), [m.features(tb).copy() for tb in range(8)])
+            if i in ref:
+                assert len(got[0]) == len(ref[i][0]) and (got[0] == ref[i][0]).all(), (K, i)
+                for tb in range(8):
+                    assert np.array_equal(got[1][tb], ref[i][1][tb]), (K, i, tb)
+            else:
+                ref[i] = got
+        # the same current frame once more, replacing it: identical state
+        H.product_matcher_batch(ms, [pool[i][2] for i in ids], [pool[i][3] for i in ids], 2, replace=True)
+        for m, i in zip(ms, ids):
+            got = m.matches()
+            assert len(got) == len(ref[i][0]) and (got == ref[i][0]).all(), ("replace", K, i)
+    assert len(ref[0][0]) > 1000
