@@ -38,6 +38,34 @@ public:
     }
     using VisualOdometry::process;
 
+    // ---- extensions (not in the reference): K objects, one frame each, as ONE call (svh_vo_process_batch) ----
+    // ok[i] (optional) = what process() of object i would have returned; returns the number of updated motions,
+    // negative on an error.  Per object the results are those of K process() calls in this order.
+    static int32_t processBatch(VisualOdometryStereo* const* vos, int32_t K, uint8_t* const* I1, uint8_t* const* I2,
+                                int32_t* dims, bool replace = false, int32_t* ok = 0) {
+        std::vector<svh_vo*> h((size_t)K);
+        for (int32_t i = 0; i < K; i++) h[i] = vos[i]->_vo;
+        return svh_vo_process_batch(h.data(), K, I1, I2, dims, replace ? 1 : 0, ok);
+    }
+    // the pipelined loop: prefetchBatch hands over the first frame, every processNextBatch processes the frame
+    // handed over before and hands over the next one (nextI1 = nextI2 = 0 after the last frame); the images of a
+    // handed-over frame stay untouched until it has been processed
+    static int32_t prefetchBatch(VisualOdometryStereo* const* vos, int32_t K, uint8_t* const* I1, uint8_t* const* I2,
+                                 int32_t* dims) {
+        std::vector<svh_vo*> h((size_t)K);
+        for (int32_t i = 0; i < K; i++) h[i] = vos[i]->_vo;
+        return svh_vo_prefetch_batch(h.data(), K, I1, I2, dims);
+    }
+    static int32_t processNextBatch(VisualOdometryStereo* const* vos, int32_t K, uint8_t* const* nextI1,
+                                    uint8_t* const* nextI2, int32_t* dims, bool replace = false, int32_t* ok = 0) {
+        std::vector<svh_vo*> h((size_t)K);
+        for (int32_t i = 0; i < K; i++) h[i] = vos[i]->_vo;
+        return svh_vo_process_next_batch(h.data(), K, nextI1, nextI2, dims, replace ? 1 : 0, ok);
+    }
+    // bucketing / RANSAC samples from a private generator with glibc's srand(seed) sequence instead of the
+    // process-wide rand() (seed 0 = what the reference's constructor seeds)
+    void usePrivateRand(uint32_t seed = 0) { svh_vo_set_private_rand(_vo, 1, seed); }
+
 private:
     static svh_vo_params to_abi(const parameters& p) {
         svh_vo_params q;

@@ -5,6 +5,7 @@ unbatched calls are themselves pinned to the reference by test_matcher_gpu.py / 
 here also checks a batched object against the golden reference output directly."""
 import ctypes as C
 import os
+import subprocess
 import threading
 
 import numpy as np
@@ -394,3 +395,14 @@ def test_lockstep_results_do_not_depend_on_batch_composition():
             got = m.matches()
             assert len(got) == len(ref[i][0]) and (got == ref[i][0]).all(), ("replace", K, i)
     assert len(ref[0][0]) > 1000
+
+
+def test_cxx_classes_lockstep_loops_agree():
+    """tests/cxx/vo_lockstep.cpp: demo.cpp's frame loop for K VisualOdometryStereo objects of include/viso_stereo.h --
+    K process() calls, one processBatch(), and the pipelined prefetchBatch / processNextBatch loop -- compiled with
+    g++ against include/ only; the three loops must report the same return values, motions and inlier sets"""
+    exe = os.path.join(H.ROOT, "tests", "cxx", "vo_lockstep")
+    subprocess.check_call(["make", "-C", os.path.join(H.ROOT, "tests", "cxx"), "vo_lockstep"])
+    args = [os.path.join(H.GOLDEN, "viso_%s.pgm" % k) for k in ("I1p", "I2p", "I1c", "I2c")]
+    r = subprocess.run([exe] + args + ["6", "7"], capture_output=True, text=True)
+    assert r.returncode == 0 and "vo_lockstep: OK" in r.stdout, r.stdout + r.stderr
