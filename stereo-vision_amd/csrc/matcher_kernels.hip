@@ -978,6 +978,9 @@ __global__ __launch_bounds__(256) void k_upload_b(const UploadJob* J) {
     if (i < a.n16) a.dev[i] = a.host[i];
 }
 struct Copy4Job { uint32_t* dst; const uint32_t* src; size_t n4; };
+__global__ __launch_bounds__(256) void k_copy4(Copy4Job a) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) a.dst[i] = a.src[i];
+}
 __global__ __launch_bounds__(256) void k_copy4_b(const Copy4Job* J) {
     const Copy4Job a = J[blockIdx.z];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) a.dst[i] = a.src[i];
@@ -1025,9 +1028,16 @@ void mlaunch_upload(void* stream, const uint8_t* pinned, uint8_t* dev, size_t by
 
 // small transfers between pinned host and device memory, either direction (bytes: a multiple of 4)
 void mlaunch_copy(void* stream, void* dst, const void* src, size_t bytes, int kind) {
-    if (t_rec) {
-        const Copy4Job a = {static_cast<uint32_t*>(dst), static_cast<const uint32_t*>(src), bytes / 4};
-        return t_rec->add(b_copy4, a, (unsigned)std::min<size_t>((bytes / 4 + 255) / 256, 64));
+    const Copy4Job a = {static_cast<uint32_t*>(dst), static_cast<const uint32_t*>(src), bytes / 4};
+    const unsigned gx = (unsigned)std::min<size_t>((bytes / 4 + 255) / 256, 64);
+    if (t_rec) return t_rec->add(b_copy4, a, gx);
+    // Small transfers go by a kernel as well: both ends are device-addressable (pinned host memory), and a copy
+    // kernel in the stream's own queue spares the hand-over to a DMA engine and back (~15 us per copy; a frame has
+    // five of them between kernels that wait for each other).
+    static const bool by_kernel = !(getenv("SVH_MATCHER_COPY_KERNEL") && atoi(getenv("SVH_MATCHER_COPY_KERNEL")) == 0);
+    if (by_kernel && bytes % 4 == 0 && bytes > 0 && bytes <= ((size_t)1 << 20)) {
+        hipLaunchKernelGGL(k_copy4, dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
+        return;
     }
     (void)hipMemcpyAsync(dst, src, bytes, (hipMemcpyKind)kind, (hipStream_t)stream);
 }
