@@ -755,6 +755,15 @@ def product_vo_process_batch(vos, I1s, I2s, replace=False, shape=None):
     return rc, ok
 
 
+def _held(arrs):
+    """images of a frame handed over early are read by the library until the frame is taken: they must be the
+    caller's own contiguous uint8 arrays (a temporary copy made here would be freed too early)"""
+    for a in arrs:
+        if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags.c_contiguous):
+            raise ValueError("hand-over needs contiguous uint8 arrays that the caller keeps alive")
+    return list(arrs)
+
+
 def product_vo_process_next_batch(vos, next_I1s, next_I2s, shape, replace=False):
     """svh_vo_process_next_batch: process the frame handed over before, hand over the next one (or None)"""
     import svhip as S
@@ -764,8 +773,7 @@ def product_vo_process_next_batch(vos, next_I1s, next_I2s, shape, replace=False)
     K = len(vos)
     p1 = p2 = None
     if next_I1s is not None:
-        next_I1s = [np.ascontiguousarray(a, np.uint8) for a in next_I1s]
-        next_I2s = [np.ascontiguousarray(a, np.uint8) for a in next_I2s]
+        next_I1s, next_I2s = _held(next_I1s), _held(next_I2s)
         p1, p2 = _ptr_array(next_I1s), _ptr_array(next_I2s)
     dims = (C.c_int32 * 3)(shape[1], shape[0], shape[1])
     hs = (C.c_void_p * K)(*[v.h for v in vos])
@@ -782,8 +790,7 @@ def product_vo_prefetch_batch(vos, I1s, I2s):
     lib = S.lib()
     lib.svh_vo_prefetch_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     K = len(vos)
-    I1s = [np.ascontiguousarray(a, np.uint8) for a in I1s]
-    I2s = [np.ascontiguousarray(a, np.uint8) for a in I2s]
+    I1s, I2s = _held(I1s), _held(I2s)
     dims = (C.c_int32 * 3)(I1s[0].shape[1], I1s[0].shape[0], I1s[0].shape[1])
     hs = (C.c_void_p * K)(*[v.h for v in vos])
     rc = lib.svh_vo_prefetch_batch(hs, K, _ptr_array(I1s), _ptr_array(I2s), dims)
@@ -799,8 +806,8 @@ def product_matcher_prefetch(ms, I1s, I2s):
     lib.svh_matcher_prefetch_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     K = len(ms)
     hs = (C.c_void_p * K)(*[m.h for m in ms])
-    I1s = [np.ascontiguousarray(a, np.uint8) for a in I1s]
-    I2s = None if I2s is None else [np.ascontiguousarray(a, np.uint8) for a in I2s]
+    I1s = _held(I1s)
+    I2s = None if I2s is None else _held(I2s)
     dims = (C.c_int32 * 3)(I1s[0].shape[1], I1s[0].shape[0], I1s[0].shape[1])
     rc = lib.svh_matcher_prefetch_batch(hs, K, _ptr_array(I1s), None if I2s is None else _ptr_array(I2s), dims)
     if rc < 0:
