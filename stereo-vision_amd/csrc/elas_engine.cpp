@@ -135,6 +135,7 @@ struct Lane {
     // device
     uint8_t* img = nullptr;        // [gcap][2][N]       staged host images
     uint8_t* desc = nullptr;       // [gcap][2][N*16]
+    bool desc_fly = false;         // the group in flight left only the Sobel planes there (descriptors_on_the_fly)
     int16_t* dcan = nullptr;       // [gcap][nc]
     int32_t* owner = nullptr;      // [gcap][2][N]
     int64_t owner_hi = 0;          // every value stored in owner[] so far is <= owner_hi
@@ -558,6 +559,7 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         G.mask = L.mask;
         G.lists = L.lists;
         G.desc = L.desc;
+        G.desc_fly = L.desc_fly ? 1 : 0;
         G.owner = L.owner;
         // triangle ownership is stored as owner_base + 1 + index; the base moves above everything
         // written so far, so the 2 x N x g map is never cleared (one memset when int32 would overflow)
@@ -760,8 +762,27 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
             img.I[0] = L.img; img.I[1] = L.img + N;
             img.stride = 2 * N; img.pitch = W;
         }
-        launch_descriptor(cx, img, g, W, H, p.subsampling, L.desc);
-        launch_support(cx, p, d, g, L.desc, L.dcan);
+        {
+            // E1 writes the Sobel planes only when both matchers will assemble their descriptor rows themselves
+            // (the descriptor taps of the parity tests need the full maps)
+            std::vector<int32_t> Pt;
+            int32_t pr = 2;
+            prior_table(p, Pt, &pr);
+            int32_t absmax = 0;
+            for (int32_t dd = 0; dd <= pr && dd < (int32_t)Pt.size(); dd++)
+                absmax = std::max(absmax, (int32_t)std::min<int64_t>(std::llabs((long long)Pt[dd]), INT32_MAX));
+            static const int fly_env = getenv("SVH_DESC_FLY") ? atoi(getenv("SVH_DESC_FLY")) : 1;
+            L.desc_fly = (!tapping || fly_env == 2) && descriptors_on_the_fly(p, d, absmax, pr, L.lists != nullptr);
+        }
+        if (tapping && L.desc_fly) {
+            // SVH_DESC_FLY=2 (tests): the descriptor taps come from the full kernel, then the planes replace them
+            launch_descriptor(cx, img, g, W, H, p.subsampling, L.desc, false);
+            int rc2 = tap_dev(L, taps, SVH_ELAS_DESC1, L.desc, N * 16); if (rc2) return rc2;
+            rc2 = tap_dev(L, taps, SVH_ELAS_DESC2, L.desc + N * 16, N * 16); if (rc2) return rc2;
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        launch_descriptor(cx, img, g, W, H, p.subsampling, L.desc, L.desc_fly);
+        launch_support(cx, p, d, g, L.desc, L.dcan, L.desc_fly);
         const int sm = g_stage_mode.load();
         L.resident = !L.force_host && L.stage_ok &&
                      (sm == 1 || (sm < 0 && prefer_device && stage_device_preferred(p, d, prefer_device > 1)));
@@ -785,8 +806,10 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
             }
             if (tapping) {
                 HIP_TRY(hipStreamSynchronize(s));
-                rc = tap_dev(L, taps, SVH_ELAS_DESC1, L.desc, N * 16); if (rc) return rc;
-                rc = tap_dev(L, taps, SVH_ELAS_DESC2, L.desc + N * 16, N * 16); if (rc) return rc;
+                if (!L.desc_fly) {
+                    rc = tap_dev(L, taps, SVH_ELAS_DESC1, L.desc, N * 16); if (rc) return rc;
+                    rc = tap_dev(L, taps, SVH_ELAS_DESC2, L.desc + N * 16, N * 16); if (rc) return rc;
+                }
                 tap_host(taps, SVH_ELAS_DCAN_RAW, L.h_dcan, nc);
             }
             launch_stage_device(cx, p, d, g, L.stg, reinterpret_cast<GroupHdr*>(L.prior_dev),
@@ -841,8 +864,10 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
     if (g_hostprof) g_hp_pairs += g;
     t1 = now_ms();
     if (tapping) {
-        rc = tap_dev(L, taps, SVH_ELAS_DESC1, L.desc, N * 16); if (rc) return rc;
-        rc = tap_dev(L, taps, SVH_ELAS_DESC2, L.desc + N * 16, N * 16); if (rc) return rc;
+        if (!L.desc_fly) {
+            rc = tap_dev(L, taps, SVH_ELAS_DESC1, L.desc, N * 16); if (rc) return rc;
+            rc = tap_dev(L, taps, SVH_ELAS_DESC2, L.desc + N * 16, N * 16); if (rc) return rc;
+        }
         tap_host(taps, SVH_ELAS_DCAN_RAW, L.h_dcan, nc);
     }
 

@@ -263,6 +263,142 @@ __global__ __launch_bounds__(256) void k_descriptor_stream(DevImages img, int W,
 }
 
 // ---------------------------------------------------------------------------
+// Descriptors on the fly (round 4).  k_descriptor_stream writes 32 N bytes per pair (16 per pixel and image) that
+// the support and dense matchers read back once: its duration is that write.  In this form E1 only stores the
+// two Sobel planes (du, dv: 1 byte per pixel each, k_sobel_planes) and the matchers assemble the descriptor rows
+// they stage in LDS themselves (fly_desc4: 16 aligned 32-bit loads and ~32 v_perm for four adjacent pixels).
+// The planes live at the start of the pair's descriptor buffer: slot z = 2 pair + image holds du at +0 and dv at
+// + H * pitch, pitch = roundup(W, 4) + 16, column x at byte 8 + x (so the words x-4 .. x+7 of a row always exist).
+// ---------------------------------------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32_unaligned_t __attribute__((aligned(1)));
+__device__ __forceinline__ s16x2 dp_pair01(uint32_t w) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c010c00u)); }
+__device__ __forceinline__ s16x2 dp_pair23(uint32_t w) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, w, 0x0c030c02u)); }
+// (a.hi, b.lo): the pair one column to the right of a, b being the next pair
+__device__ __forceinline__ s16x2 dp_mid(s16x2 a, s16x2 b) {
+    return __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbyte(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 2u));
+}
+__device__ __forceinline__ s16x2 dp_prev(s16x2 v) { return __builtin_bit_cast(s16x2, lane_prev(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ s16x2 dp_next(s16x2 v) { return __builtin_bit_cast(s16x2, lane_next(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ s16x2 dp_sobel_out(s16x2 v) {   // sat_u8((v >> 2) + 128)
+    const s16x2 lo = {0, 0}, hi = {255, 255}, off = {128, 128};
+    return __builtin_elementwise_min(__builtin_elementwise_max((v >> 2) + off, lo), hi);
+}
+__device__ __forceinline__ uint32_t dp_bytes(s16x2 lo, s16x2 hi) {   // low bytes of four 16-bit values -> one word
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
+}
+// v_perm_b32 selector bytes: 0..3 = bytes of `lo` (second operand), 4..7 = bytes of `hi` (first operand)
+#define DP_SEL(b0, b1, b2, b3) ((uint32_t)(b0) | (uint32_t)(b1) << 8 | (uint32_t)(b2) << 16 | (uint32_t)(b3) << 24)
+
+__host__ __device__ __forceinline__ int fly_pitch(int W) { return ((W + 3) & ~3) + 16; }
+
+// E1 alone: filter::sobel3x3 (filter.cpp:408-416) of both images of a group into the two planes.  A lane owns the
+// four pixels of one image word (packed 16-bit column sums, neighbour pairs by DPP), a wave walks SP_ROWS rows.
+constexpr int SP_ROWS = 30;
+__global__ __launch_bounds__(256) void k_sobel_planes(DevImages img, int W, int H, int strips, int cols, int nwaves,
+                                                      uint8_t* __restrict__ desc_all) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (wid >= nwaves) return;
+    const int seg = wid / strips, strip = wid - seg * strips;
+    const int pair = blockIdx.y >> 1, im = blockIdx.y & 1;
+    const int x = strip * cols + 4 * (lane - 1);        // first of this lane's four columns
+    const int ys = seg * SP_ROWS;
+    const int pitch = fly_pitch(W);
+    const bool writes = lane >= 1 && 4 * (lane - 1) < cols && x < W;
+    // one unconditional 32-bit load per lane and row from an address inside the row (see k_descriptor_pk's note:
+    // the last word of a row is read at W-4 and shifted down, lanes beside the image are masked to zero)
+    const bool in_row = x >= 0 && x < W;
+    const int over = in_row && x + 3 >= W ? x + 4 - W : 0;
+    const uint32_t lane_mask = in_row ? 0xFFFFFFFFu : 0u, lane_shift = 8u * (uint32_t)over;
+    const uint8_t* __restrict__ src = img.I[im] + (size_t)pair * img.stride + (in_row ? x - over : 0);
+    uint8_t* du = desc_all + (size_t)blockIdx.y * W * H * 16 + 8 + (writes ? x : 0);
+    uint8_t* dv = du + (size_t)H * pitch;
+    s16x2 a1[2] = {{0, 0}, {0, 0}}, a2[2] = {{0, 0}, {0, 0}};     // image pairs of rows r-1, r-2
+    constexpr int kChunk = 16;
+    static_assert((SP_ROWS + 2) % kChunk == 0, "the walk is a whole number of load chunks");
+    for (int r0 = ys - 1; r0 <= ys + SP_ROWS; r0 += kChunk) {   // centre row c = r - 1 runs over ys-2 .. ys+SP_ROWS-1
+        if (r0 - 1 >= H) break;
+        uint32_t px[kChunk];
+#pragma unroll
+        for (int k = 0; k < kChunk; k++) {       // the chunk's loads go out before its arithmetic
+            const int r = r0 + k;
+            const int rc = r < 0 ? 0 : (r < H ? r : H - 1);
+            const uint32_t row_mask = (r >= 0 && r < H) ? lane_mask : 0u;
+            px[k] = (*reinterpret_cast<const u32_unaligned_t*>(src + (size_t)rc * img.pitch) >> lane_shift) & row_mask;
+        }
+#pragma unroll
+        for (int k = 0; k < kChunk; k++) {
+            const int r = r0 + k;
+            const s16x2 p0 = dp_pair01(px[k]), p1 = dp_pair23(px[k]);
+            const s16x2 two = {2, 2};
+            const s16x2 S0 = a2[0] + two * a1[0] + p0, S1 = a2[1] + two * a1[1] + p1;
+            const s16x2 T0 = a2[0] - p0, T1 = a2[1] - p1;
+            a2[0] = a1[0]; a2[1] = a1[1];
+            a1[0] = p0; a1[1] = p1;
+            const s16x2 SL = dp_prev(S1), SR = dp_next(S0), TL = dp_prev(T1), TR = dp_next(T0);
+            const s16x2 Sm0 = dp_mid(SL, S0), Sm1 = dp_mid(S0, S1), Sm2 = dp_mid(S1, SR);
+            const s16x2 Tm0 = dp_mid(TL, T0), Tm1 = dp_mid(T0, T1), Tm2 = dp_mid(T1, TR);
+            const uint32_t Dw = dp_bytes(dp_sobel_out(Sm0 - Sm1), dp_sobel_out(Sm1 - Sm2));
+            const uint32_t Vw = dp_bytes(dp_sobel_out(Tm0 + two * T0 + Tm1), dp_sobel_out(Tm1 + two * T1 + Tm2));
+            const int c = r - 1;
+            if (writes && c >= ys && c < ys + SP_ROWS && c < H) {
+                *reinterpret_cast<uint32_t*>(du + (size_t)c * pitch) = Dw;
+                *reinterpret_cast<uint32_t*>(dv + (size_t)c * pitch) = Vw;
+            }
+        }
+    }
+}
+
+// The descriptors (descriptor.cpp:88-117) of the four pixels x .. x+3 (x a multiple of 4, x < W) of row `line`, from
+// the planes of one image.  Zero outside columns 3 .. W-4 / rows 3 .. H-4, like the descriptor kernel writes them.
+__device__ __forceinline__ void fly_desc4(const uint8_t* __restrict__ du, int W, int H, int x, int line, uint4 out[4]) {
+    const int pitch = fly_pitch(W);
+    if (line < 3 || line >= H - 3) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const uint8_t* dv = du + (size_t)H * pitch;
+    const uint8_t* pu = du + (size_t)line * pitch + 8 + x;
+    const uint8_t* pv = dv + (size_t)line * pitch + 8 + x;
+    auto ld = [](const uint8_t* q) { return *reinterpret_cast<const uint32_t*>(q); };
+    const uint32_t Um2 = ld(pu - 2 * pitch), Up2 = ld(pu + 2 * pitch);
+    const uint32_t UaL = ld(pu - pitch - 4), Ua = ld(pu - pitch), UaR = ld(pu - pitch + 4);     // row line-1
+    const uint32_t UcL = ld(pu - 4), Uc = ld(pu), UcR = ld(pu + 4);                             // row line
+    const uint32_t UbL = ld(pu + pitch - 4), Ub = ld(pu + pitch), UbR = ld(pu + pitch + 4);     // row line+1
+    const uint32_t Vm1 = ld(pv - pitch), Vp1 = ld(pv + pitch);
+    const uint32_t VcL = ld(pv - 4), Vc = ld(pv), VcR = ld(pv + 4);
+    uint32_t Wa[4], Wb[4], Y[4], Z[4];
+    // du[x-2] | du[x] << 8 | du[x+2] << 16 of rows line-1 (Wa) and line+1 (Wb)
+    Wa[0] = __builtin_amdgcn_perm(Ua, UaL, DP_SEL(2, 4, 6, 0x0c));  Wb[0] = __builtin_amdgcn_perm(Ub, UbL, DP_SEL(2, 4, 6, 0x0c));
+    Wa[1] = __builtin_amdgcn_perm(Ua, UaL, DP_SEL(3, 5, 7, 0x0c));  Wb[1] = __builtin_amdgcn_perm(Ub, UbL, DP_SEL(3, 5, 7, 0x0c));
+    Wa[2] = __builtin_amdgcn_perm(UaR, Ua, DP_SEL(0, 2, 4, 0x0c));  Wb[2] = __builtin_amdgcn_perm(UbR, Ub, DP_SEL(0, 2, 4, 0x0c));
+    Wa[3] = __builtin_amdgcn_perm(UaR, Ua, DP_SEL(1, 3, 5, 0x0c));  Wb[3] = __builtin_amdgcn_perm(UbR, Ub, DP_SEL(1, 3, 5, 0x0c));
+    // du[x-1] | du[x] << 8 | du[x] << 16 | du[x+1] << 24 of row line
+    Y[0] = __builtin_amdgcn_perm(Uc, UcL, DP_SEL(3, 4, 4, 5));
+    Y[1] = __builtin_amdgcn_perm(Uc, Uc, DP_SEL(0, 1, 1, 2));
+    Y[2] = __builtin_amdgcn_perm(Uc, Uc, DP_SEL(1, 2, 2, 3));
+    Y[3] = __builtin_amdgcn_perm(UcR, Uc, DP_SEL(2, 3, 3, 4));
+    // dv[x-1] << 8 | dv[x+1] << 16 of row line
+    Z[0] = __builtin_amdgcn_perm(Vc, VcL, DP_SEL(0x0c, 3, 5, 0x0c));
+    Z[1] = __builtin_amdgcn_perm(Vc, Vc, DP_SEL(0x0c, 0, 2, 0x0c));
+    Z[2] = __builtin_amdgcn_perm(Vc, Vc, DP_SEL(0x0c, 1, 3, 0x0c));
+    Z[3] = __builtin_amdgcn_perm(VcR, Vc, DP_SEL(0x0c, 2, 4, 0x0c));
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint4 o;
+        o.x = __builtin_amdgcn_perm(Wa[i], Um2, DP_SEL(i, 4, 5, 6));          // du(line-2, x) | W(line-1) << 8
+        o.y = Y[i];
+        o.z = __builtin_amdgcn_perm(Up2, Wb[i], DP_SEL(0, 1, 2, 4 + i));      // W(line+1) | du(line+2, x) << 24
+        const uint32_t t = __builtin_amdgcn_perm(Z[i], Vm1, DP_SEL(i, 5, 6, 0x0c));   // dv(line-1, x) | Z(line)
+        o.w = __builtin_amdgcn_perm(Vp1, t, DP_SEL(0, 1, 2, 4 + i));          // ... | dv(line+1, x) << 24
+        const bool in = x + i >= 3 && x + i < W - 3;
+        out[i] = in ? o : make_uint4(0, 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // E3+E4  support candidate matching
 //   Elas::computeMatchingDisparity   libelas/src/elas.cpp:322-445
 //   Elas::computeSupportMatches      libelas/src/elas.cpp:449-493
@@ -361,9 +497,9 @@ struct StripView {
 // and the ratio test -- which was ~40 % of the instructions of a search.  A quarter wave reads 16
 // consecutive 16-byte slots, so the ds_read_b128 stay conflict-free.  `act`: this lane's
 // candidate takes part; u is per lane (uniform inside a row of 16).  Returns d or -1 per lane.
-__device__ __forceinline__ int support_match_rows(const StripView& own, const StripView& oth, const uint4 centre,
+__device__ __forceinline__ int support_match_rows(const StripView& own, const StripView& oth, const int centre_texture,
                                                   int u, bool right, bool act, const SupportParams& P, int gl) {
-    act = act && u >= 5 && u <= P.W - 6 && (int)texture16(centre) >= P.support_texture;
+    act = act && u >= 5 && u <= P.W - 6 && centre_texture >= P.support_texture;
     const int dmin = P.disp_min > 0 ? P.disp_min : 0;
     int dmax = right ? P.W - u - 5 : u - 5;
     dmax = dmax < P.disp_max ? dmax : P.disp_max;
@@ -441,7 +577,24 @@ __device__ __forceinline__ int support_match_rows(const StripView& own, const St
     return act && good ? (int)(m1 & 0xFFFFu) : -1;
 }
 
-template <int kSB, int kST>
+// one descriptor from the Sobel planes (fly form; byte loads)
+__device__ __forceinline__ uint4 fly_desc1(const uint8_t* __restrict__ du, int W, int H, int x, int line) {
+    if (line < 3 || line >= H - 3 || x < 3 || x >= W - 3) return make_uint4(0, 0, 0, 0);
+    const int pitch = fly_pitch(W);
+    const uint8_t* pu = du + (size_t)line * pitch + 8 + x;
+    const uint8_t* pv = pu + (size_t)H * pitch;
+    auto U = [&](int dy, int dx) { return (uint32_t)pu[dy * pitch + dx]; };
+    auto V = [&](int dy, int dx) { return (uint32_t)pv[dy * pitch + dx]; };
+    uint4 o;
+    o.x = U(-2, 0) | U(-1, -2) << 8 | U(-1, 0) << 16 | U(-1, 2) << 24;
+    const uint32_t c = U(0, 0);
+    o.y = U(0, -1) | c << 8 | c << 16 | U(0, 1) << 24;
+    o.z = U(1, -2) | U(1, 0) << 8 | U(1, 2) << 16 | U(2, 0) << 24;
+    o.w = V(-1, 0) | V(0, -1) << 8 | V(0, 1) << 16 | V(1, 0) << 24;
+    return o;
+}
+
+template <int kSB, int kST, bool kFly>
 __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__ desc_all,
                                                      int16_t* __restrict__ dcan_all,
                                                      SupportParams P) {
@@ -480,6 +633,42 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
     const int wl = xl1 - xl0 + 1, wr = xr1 - xr0 + 1;
     uint4* sL = s_strip;
     uint4* sR = s_strip + 2 * wl;
+    __shared__ uint16_t s_texL[kFly ? kSB : 1];
+    uint16_t* s_texR = reinterpret_cast<uint16_t*>(s_strip + 2 * (wl + wr));   // (fly: wr texture values behind the strips)
+    if (kFly) {
+        // the four strips (rows v-2 / v+2 of both images) assembled from the Sobel planes, four aligned pixels per task
+        const uint8_t* pl1 = desc_all + (size_t)(2 * pair) * N16 * 16;
+        const uint8_t* pl2 = pl1 + N16 * 16;
+        const int al0 = xl0 & ~3, ar0 = xr0 & ~3;
+        const int nl = (xl1 - al0) / 4 + 1, nr = (xr1 - ar0) / 4 + 1;      // tasks per row of the left / right strip
+        for (int task = (int)threadIdx.x; task < 2 * (nl + nr); task += kST) {
+            const bool rgt = task >= 2 * nl;
+            const int j = rgt ? task - 2 * nl : task, n = rgt ? nr : nl;
+            const int row = j >= n, x = (rgt ? ar0 : al0) + 4 * (j - row * n);
+            uint4 o[4];
+            fly_desc4(rgt ? pl2 : pl1, P.W, P.H, x, v + (row ? 2 : -2), o);
+            const int x0 = rgt ? xr0 : xl0, x1 = rgt ? xr1 : xl1, w = rgt ? wr : wl;
+            uint4* dst = (rgt ? sR : sL) + row * w - x0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (x + i >= x0 && x + i <= x1) dst[x + i] = o[i];
+        }
+        // descriptor texture of the centre row v: the right image over its strip (the backward search starts at any
+        // column), the left image at the block's lattice columns
+        for (int task = (int)threadIdx.x; task < nr + kSB; task += kST) {
+            if (task < nr) {
+                const int x = ar0 + 4 * task;
+                uint4 o[4];
+                fly_desc4(pl2, P.W, P.H, x, v, o);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (x + i >= xr0 && x + i <= xr1) s_texR[x + i - xr0] = (uint16_t)texture16(o[i]);
+            } else {
+                const int c = task - nr, u = (uc0 + c) * P.step;
+                s_texL[c] = (uint16_t)(c < ncand && u < P.W ? texture16(fly_desc1(pl1, P.W, P.H, u, v)) : 0u);
+            }
+        }
+    } else {
     // (sL and sR are adjacent: one pass over both strips, up to six loads per thread in flight)
     stage_slots<6>(s_strip, 2 * (wl + wr), (int)threadIdx.x, kST, [&](int i) {
         const bool rgt = i >= 2 * wl;
@@ -487,6 +676,7 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
         const int row = j >= w, x = j - row * w;
         return (rgt ? d2 : d1)[(size_t)(v + (row ? 2 : -2)) * P.W + (rgt ? xr0 : xl0) + x];
     });
+    }
     __syncthreads();
     const StripView L = {sL, xl0, wl}, R = {sR, xr0, wr};
     // Four candidates per wave, one per row of 16 lanes (rows 2k and 2k+1 take candidates 8 apart).
@@ -510,8 +700,8 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
         const bool have = c < ncand;
         const int uc = uc0 + (have ? c : 0), u = uc * P.step;
         const bool in = have && uc > 0 && u >= 5 && u <= P.W - 6;
-        const uint4 c1 = in ? d1[(size_t)v * P.W + u] : make_uint4(0, 0, 0, 0);
-        const int d = support_match_rows(L, R, c1, u, false, in, P, gl);
+        const int t1 = !in ? 0 : kFly ? (int)s_texL[c] : (int)texture16(d1[(size_t)v * P.W + u]);
+        const int d = support_match_rows(L, R, t1, u, false, in, P, gl);
         if (gl == 0 && c < kSB) s_fwd[c] = (int16_t)(have ? d : -1);
     }
     __syncthreads();
@@ -541,8 +731,8 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
         const int d = have ? (int)s_fwd[c] : 0;
         const int uc = uc0 + c, u = uc * P.step;
         const int ub = have ? u - d : 5;   // >= 5 because d <= u-5
-        const uint4 c2 = have ? d2[(size_t)v * P.W + ub] : make_uint4(0, 0, 0, 0);
-        const int dd = support_match_rows(R, L, c2, ub, true, have, P, gl);
+        const int t2 = !have ? 0 : kFly ? (int)s_texR[ub - xr0] : (int)texture16(d2[(size_t)v * P.W + ub]);
+        const int dd = support_match_rows(R, L, t2, ub, true, have, P, gl);
         const int diff = d > dd ? d - dd : dd - d;
         const int out = (dd >= 0 && diff <= P.lr_threshold) ? d : -1;
         if (have && gl == 0) dcan[c] = (int16_t)out;
@@ -1394,9 +1584,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(kIters <= 5
     line = line > 2 ? line : 2;
     const int cr = v / P.grid_size, cells = P.gw * P.gh;
     {
-        const uint4* l1 = reinterpret_cast<const uint4*>(G.desc) + (size_t)(2 * pair) * N + (size_t)line * P.W;
-        dma_slots(s_rows, l1, P.W, wave, nwaves, lane);
-        dma_slots(s_rows + P.W, l1 + N, P.W, wave, nwaves, lane);
+        if (G.desc_fly) {
+            // the two descriptor rows are assembled from the Sobel planes: four adjacent pixels per task
+            const int nq = (P.W + 3) >> 2;
+            for (int task = tid; task < 2 * nq; task += (int)blockDim.x) {
+                const int im = task >= nq, x = 4 * (task - im * nq);
+                uint4 o[4];
+                fly_desc4(G.desc + (size_t)(2 * pair + im) * N * 16, P.W, P.H, x, line, o);
+                uint4* dst = s_rows + im * P.W + x;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (x + i < P.W) dst[i] = o[i];
+            }
+        } else {
+            const uint4* l1 = reinterpret_cast<const uint4*>(G.desc) + (size_t)(2 * pair) * N + (size_t)line * P.W;
+            dma_slots(s_rows, l1, P.W, wave, nwaves, lane);
+            dma_slots(s_rows + P.W, l1 + N, P.W, wave, nwaves, lane);
+        }
         const int rq = P.gw * ML_CAP * 2 / 16;   // uint4 per side
         const uint4* r1 = reinterpret_cast<const uint4*>(G.lists + ((size_t)(2 * pair) * cells + (size_t)cr * P.gw) * ML_CAP);
         const uint4* r2 = reinterpret_cast<const uint4*>(G.lists + ((size_t)(2 * pair + 1) * cells + (size_t)cr * P.gw) * ML_CAP);
@@ -2104,7 +2308,16 @@ struct Timed {
 // launchers
 // ---------------------------------------------------------------------------
 void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t g, int32_t W, int32_t H,
-                       int32_t half, uint8_t* desc) {
+                       int32_t half, uint8_t* desc, bool fly) {
+    if (fly) {
+        // E1 only: the Sobel planes; the matchers assemble the descriptors they stage (see k_sobel_planes)
+        const int strips = (W + 4 * 62 - 1) / (4 * 62);
+        const int cols = 4 * ((W + 4 * strips - 1) / (4 * strips));
+        const int segs = (H + SP_ROWS - 1) / SP_ROWS, nwaves = strips * segs;
+        LAUNCH("k_descriptor", k_sobel_planes, dim3((nwaves + 3) / 4, 2 * g), dim3(256), img, W, H, strips, cols,
+               nwaves, desc);
+        return;
+    }
     // 26 rows per wave, 16 loads in flight: shorter walks (more waves) measured marginally better
     // than 42 .. 90 rows, all within 2 %
     constexpr int rows = 26, chunk = 16;
@@ -2114,8 +2327,26 @@ void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t g, int
            half, strips, nwaves, desc);
 }
 
+// candidates per block of the LDS-staged support kernel, 0 when the strips do not fit (generic kernel)
+static int support_strip(const svh_elas_params& p, const Dims& d, size_t* lds_out) {
+    static const int sb_env = getenv("SVH_SUPPORT_SB") ? atoi(getenv("SVH_SUPPORT_SB")) : 64;
+    constexpr size_t kSupportStatic = 512;
+    auto strip_lds = [&](int sb) {
+        const int span = (sb - 1) * d.step;
+        const size_t wl = (size_t)std::min(d.W, span + 2 * p.disp_max + 5);
+        const size_t wr = (size_t)std::min(d.W, span + p.disp_max + 5);
+        return 2 * (wl + wr) * sizeof(uint4);
+    };
+    int sb = sb_env == 32 ? 32 : 64;
+    if (sb == 64 && strip_lds(64) + 2 * (size_t)d.W + 16 + kSupportStatic > 64 * 1024) sb = 32;
+    // (+ the right strip's texture values of the fly form: 2 bytes per column, counted always)
+    const size_t lds = strip_lds(sb) + 2 * (size_t)std::min(d.W, (sb - 1) * d.step + p.disp_max + 5) + 16;
+    if (lds_out) *lds_out = lds;
+    return lds + kSupportStatic <= 64 * 1024 ? sb : 0;
+}
+
 void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
-                    const uint8_t* desc, int16_t* dcan) {
+                    const uint8_t* desc, int16_t* dcan, bool fly) {
     SupportParams P;
     P.W = d.W; P.H = d.H; P.Wc = d.Wc; P.Hc = d.Hc; P.step = d.step; P.npairs = g;
     P.disp_min = p.disp_min; P.disp_max = p.disp_max;
@@ -2126,28 +2357,20 @@ void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d
     // candidates per 512-thread block: 64 (two forward rounds).  32: 341 vs 316 us per isolated 32-pair
     // launch.  A whole lattice row per 1024-thread block (79 KB of LDS) is faster alone (304 us) and slower
     // in the pipeline (29.1 vs 29.5 k pairs/s): two such blocks take a CU's LDS away from everything else.
-    static const int sb_env = getenv("SVH_SUPPORT_SB") ? atoi(getenv("SVH_SUPPORT_SB")) : 64;
     // strip by fit: 64 candidates per block, else 32 (large candidate_stepsize or disp_max), else the generic
     // kernel; the kernel's static LDS (s_fwd, s_todo, s_ntodo) counts against the 64 KB limit
-    constexpr size_t kSupportStatic = 512;
-    auto strip_lds = [&](int sb) {
-        const int span = (sb - 1) * d.step;
-        const size_t wl = (size_t)std::min(d.W, span + 2 * p.disp_max + 5);
-        const size_t wr = (size_t)std::min(d.W, span + p.disp_max + 5);
-        return 2 * (wl + wr) * sizeof(uint4);
-    };
-    int sb = sb_env == 32 ? 32 : 64;
-    if (sb == 64 && strip_lds(64) + kSupportStatic > 64 * 1024) sb = 32;
-    const size_t lds = strip_lds(sb);
-    if (lds + kSupportStatic <= 64 * 1024) {
+    size_t lds = 0;
+    const int sb = support_strip(p, d, &lds);
+    if (sb) {
         Timed timed_(cx, "k_support");
         // (pairs * lattice rows rounded up to 8) * chunks blocks: XCD-aware order, see the kernel
         const int chunks = (d.Wc + sb - 1) / sb;
         const dim3 grid((unsigned)(((d.Hc * g + 7) / 8) * 8 * chunks), 1, 1);
-        if (sb == 32)
-            hipLaunchKernelGGL((k_support_lds<32, 512>), grid, dim3(512), lds, (hipStream_t)cx.stream, desc, dcan, P);
-        else
-            hipLaunchKernelGGL((k_support_lds<64, 512>), grid, dim3(512), lds, (hipStream_t)cx.stream, desc, dcan, P);
+        hipStream_t st = (hipStream_t)cx.stream;
+        if (sb == 32 && fly) hipLaunchKernelGGL((k_support_lds<32, 512, true>), grid, dim3(512), lds, st, desc, dcan, P);
+        else if (sb == 32) hipLaunchKernelGGL((k_support_lds<32, 512, false>), grid, dim3(512), lds, st, desc, dcan, P);
+        else if (fly) hipLaunchKernelGGL((k_support_lds<64, 512, true>), grid, dim3(512), lds, st, desc, dcan, P);
+        else hipLaunchKernelGGL((k_support_lds<64, 512, false>), grid, dim3(512), lds, st, desc, dcan, P);
     } else {
         const int cands = d.Wc * d.Hc;
         LAUNCH("k_support", k_support, dim3((cands + 3) / 4, g), dim3(256), desc, dcan, P);
@@ -2192,6 +2415,49 @@ void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
            p.subsampling, fix_all);
 }
 
+// Does the dense matcher take its list form (k_match_list) for these parameters?  Used by launch_match and -- before
+// the descriptor stage -- by the engine, which lets E1 write the Sobel planes only when BOTH matchers stage their
+// descriptor rows themselves (descriptors_on_the_fly).
+static bool match_list_usable(const svh_elas_params& p, const Dims& d, int32_t prior_absmax, int32_t plane_radius,
+                              bool have_lists, MatchList* Qout, size_t* lds_out) {
+    static const bool ordered = getenv("SVH_MATCH_ORDERED") != nullptr;
+    const bool keyed_ok = !ordered && prior_absmax < (1 << 19) && p.disp_max < 512 && plane_radius <= 15 &&
+                          d.W < 65536 && p.grid_size > 1;
+    static const bool list_off = getenv("SVH_MATCH_LIST") && atoi(getenv("SVH_MATCH_LIST")) == 0;
+    if (!(keyed_ok && !list_off && !p.subsampling && d.gwords <= 8 && have_lists && prior_absmax < 28000 &&
+          d.DW <= 8 * 256))
+        return false;
+    MatchList Q;
+    Q.Wr = (d.W + 7) / 8 * 8;
+    const int iters = (d.DW + 255) / 256;
+    Q.kIters = iters <= 5 ? 5 : 8;
+    const size_t ldsl = (size_t)2 * d.W * sizeof(uint4) + (size_t)2 * d.gw * ML_CAP * sizeof(uint16_t) +
+                        (size_t)2 * Q.Wr * sizeof(int16_t);
+    constexpr size_t kListStatic = 256;   // s_band, s_neg
+    bool ok = ldsl + kListStatic <= 160 * 1024;
+    if (ok && ldsl + kListStatic > 64 * 1024) {
+        ok = hipFuncSetAttribute((const void*)k_match_list<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024 - (int)kListStatic) == hipSuccess &&
+             hipFuncSetAttribute((const void*)k_match_list<false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024 - (int)kListStatic) == hipSuccess &&
+             hipFuncSetAttribute((const void*)k_match_list<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024 - (int)kListStatic) == hipSuccess &&
+             hipFuncSetAttribute((const void*)k_match_list<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024 - (int)kListStatic) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+    }
+    if (Qout) *Qout = Q;
+    if (lds_out) *lds_out = ldsl;
+    return ok;
+}
+
+bool descriptors_on_the_fly(const svh_elas_params& p, const Dims& d, int32_t prior_absmax, int32_t plane_radius,
+                            bool have_lists) {
+    static const bool off = getenv("SVH_DESC_FLY") && atoi(getenv("SVH_DESC_FLY")) == 0;
+    return !off && !p.subsampling && d.W >= 8 && support_strip(p, d, nullptr) != 0 &&
+           match_list_usable(p, d, prior_absmax, plane_radius, have_lists, nullptr, nullptr);
+}
+
 bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                   const GroupDev& G, const DevMaps* lr_out, bool write_raw) {
     MatchParams P;
@@ -2221,28 +2487,15 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
         if (!use_keyed) (void)hipGetLastError();
     }
     // round 4: the list form of the keyed kernel (per-cell candidate records, v_sad_hi_u8 keys, LDS-DMA staging)
-    static const bool list_off = getenv("SVH_MATCH_LIST") && atoi(getenv("SVH_MATCH_LIST")) == 0;
-    if (keyed_ok && !list_off && !p.subsampling && d.gwords <= 8 && G.lists && G.prior_absmax < 28000 &&
-        d.DW <= 8 * 256) {
+    {
         MatchList Q;
-        Q.Wr = (d.W + 7) / 8 * 8;
+        size_t ldsl = 0;
+        const bool ok = match_list_usable(p, d, G.prior_absmax, G.plane_radius, G.lists != nullptr, &Q, &ldsl);
         const int iters = (d.DW + 255) / 256;
         const int half = std::min(256, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
-        Q.kIters = iters <= 5 ? 5 : 8;
-        const size_t ldsl = (size_t)2 * d.W * sizeof(uint4) + (size_t)2 * d.gw * ML_CAP * sizeof(uint16_t) +
-                            (size_t)2 * Q.Wr * sizeof(int16_t);
-        constexpr size_t kListStatic = 256;   // s_band, s_neg
-        bool ok = ldsl + kListStatic <= 160 * 1024;
-        if (ok && ldsl + kListStatic > 64 * 1024) {
-            ok = hipFuncSetAttribute((const void*)k_match_list<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024 - (int)kListStatic) == hipSuccess &&
-                 hipFuncSetAttribute((const void*)k_match_list<false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024 - (int)kListStatic) == hipSuccess &&
-                 hipFuncSetAttribute((const void*)k_match_list<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024 - (int)kListStatic) == hipSuccess &&
-                 hipFuncSetAttribute((const void*)k_match_list<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024 - (int)kListStatic) == hipSuccess;
-            if (!ok) (void)hipGetLastError();
+        if (!ok && G.desc_fly) {
+            fprintf(stderr, "svhip: descriptors were left as Sobel planes but the list matcher is not usable\n");
+            abort();   // (descriptors_on_the_fly() and this selection are the same function: not reachable)
         }
         if (ok) {
             Timed timed_(cx, "k_match");

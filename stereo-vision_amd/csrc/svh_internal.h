@@ -153,6 +153,7 @@ struct GroupDev {
     int32_t plane_radius;
     int32_t owner_base;        // owner[] holds owner_base + 1 + triangle; values <= owner_base are stale
     int32_t prior_absmax;      // max |P[dd]|, dd <= plane_radius (selects the keyed match kernel)
+    int32_t desc_fly;          // `desc` holds the Sobel planes only (k_sobel_planes): the matchers assemble descriptors
 };
 
 // k_lattice + k_delaunay + k_stage_pack: from S.dcan to the packed support / triangle lists and
@@ -160,10 +161,14 @@ struct GroupDev {
 void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                          const StageDev& S, GroupHdr* hdr, int32_t* support, int32_t* tri);
 
+// fly: E1 writes the two Sobel planes into `desc` instead of the descriptors (see descriptors_on_the_fly)
 void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t g, int32_t W, int32_t H,
-                       int32_t half, uint8_t* desc);
+                       int32_t half, uint8_t* desc, bool fly);
+// true when both matchers will stage their descriptor rows from the Sobel planes for these parameters
+bool descriptors_on_the_fly(const svh_elas_params& p, const Dims& d, int32_t prior_absmax, int32_t plane_radius,
+                            bool have_lists);
 void launch_support(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
-                    const uint8_t* desc, int16_t* dcan);
+                    const uint8_t* desc, int16_t* dcan, bool fly);
 // planes + raster records + grid bit sets for the whole group.  total_sup / total_tri < 0: the
 // counts are in the device header (device-built), the launch is sized for `tri_bound` triangles
 // and the kernels stride over whatever is there

@@ -206,3 +206,22 @@ def test_device_resident_batch_keeps_failed_pairs_untouched(dev_stage, capfd):
     assert np.all(D1[2] == -7.0) and np.all(D2[2] == -7.0)
     for i in (0, 1, 3, 4):
         assert np.array_equal(D1[i], H1[i]) and np.array_equal(D2[i], H2[i])
+
+
+def test_every_stage_with_descriptors_on_the_fly():
+    """The parity tests read every stage through taps, and with taps on the engine keeps the full descriptor maps
+    (the DESC stages are one of them).  Without taps -- the production path -- E1 only writes the two Sobel planes
+    and the support and dense matchers assemble the descriptor rows they stage themselves
+    (descriptors_on_the_fly).  SVH_DESC_FLY=2 selects that form under taps as well (the DESC taps then come from
+    the full kernel run first): this file and test_elas_gpu.py run once more that way, every stage bit-exact."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("SVH_DESC_FLY") == "2":
+        pytest.skip("already the inner run")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, SVH_DESC_FLY="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_stage_gpu.py"), os.path.join(here, "test_elas_gpu.py")],
+                       env=env, capture_output=True, text=True, cwd=here, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
