@@ -37,10 +37,10 @@ struct BatchRec {
     static constexpr int kSide = 3;
     hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
     hipEvent_t side_done[kSide] = {nullptr, nullptr, nullptr};
-    // a recorder whose launches outlive the call that flushed them (prefetch): flush() leaves an event, reuse()
-    // waits for it before the arena is written again
+    // a recorder whose launches outlive the call that flushed them (prefetch): flush() notes its stream, reuse()
+    // waits for that stream before the arena is written again
     bool track = false, flush_pending = false;
-    hipEvent_t flushed = nullptr;
+    hipStream_t last_stream = nullptr;
     hipError_t reuse();
     hipError_t ensure_side();                 // creates them on first use (current device)
     hipError_t join_side(hipStream_t s);      // s waits for everything issued on the side streams so far

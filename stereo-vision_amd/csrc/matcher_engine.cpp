@@ -27,6 +27,7 @@
 #include <condition_variable>
 #include <functional>
 #include <future>
+#include <memory>
 #include <mutex>
 #include <deque>
 #include <string>
@@ -109,12 +110,7 @@ hipError_t BatchRec::flush(hipStream_t s) {
     used += need;
     slots.clear();
     if (track) {
-        if (!flushed) {
-            e = hipEventCreateWithFlags(&flushed, hipEventDisableTiming);
-            if (e != hipSuccess) return e;
-        }
-        e = hipEventRecord(flushed, s);
-        if (e != hipSuccess) return e;
+        last_stream = s;
         flush_pending = true;
     }
     return hipGetLastError();
@@ -135,9 +131,14 @@ hipError_t BatchRec::join_side(hipStream_t s) {
     for (int i = 0; i < kSide; i++) {
         if (!side[i]) continue;
         hipError_t e = hipEventRecord(side_done[i], side[i]);
-        if (e != hipSuccess) return e;
-        e = hipStreamWaitEvent(s, side_done[i], 0);
-        if (e != hipSuccess) return e;
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, side_done[i], 0);
+        if (e != hipSuccess) {
+            // (seen once in a while with several threads in the runtime: "event last recorded in a capturing
+            // stream"; the host waits for the side stream instead)
+            (void)hipGetLastError();
+            e = hipStreamSynchronize(side[i]);
+            if (e != hipSuccess) return e;
+        }
     }
     return hipSuccess;
 }
@@ -153,8 +154,6 @@ void BatchRec::release() {
         side[i] = nullptr;
         side_done[i] = nullptr;
     }
-    if (flushed) (void)hipEventDestroy(flushed);
-    flushed = nullptr;
     flush_pending = false;
 }
 
@@ -172,8 +171,10 @@ BatchRec& prefetch_recorder() {
 }
 
 hipError_t BatchRec::reuse() {
-    if (flushed && flush_pending) {
-        const hipError_t e = hipEventSynchronize(flushed);
+    // (a stream wait, not an event: events recorded on this thread and waited for on streams that another thread
+    // synchronises at the same moment came back as "event last recorded in a capturing stream" now and then)
+    if (flush_pending) {
+        const hipError_t e = hipStreamSynchronize(last_stream);
         if (e != hipSuccess) return e;
         flush_pending = false;
     }
@@ -369,6 +370,7 @@ struct svh_matcher {
     int next_cams = 0;
     hipStream_t next_stream = nullptr;        // where the prefetch was issued (waited for when the frame is taken)
     std::shared_future<int32_t> next_job;     // its host side, on the prefetch thread
+    std::shared_ptr<std::string> next_why;    // ... and its error text, if it failed
     int32_t dims_p[3], dims_c[3];
     // scratch
     int4* slots[2] = {nullptr, nullptr};      // NMS scratch, one set per camera (the cameras'
@@ -935,7 +937,7 @@ static int32_t push_take_prefetched(svh_matcher* m, int32_t replace, bool stream
         m->next_job = std::shared_future<int32_t>();
         if (rc) {
             m->has_next = false;
-            return mfail(rc, "the hand-over of the prefetched frame failed on the prefetch thread");
+            return mfail(rc, "the hand-over of the prefetched frame failed on the prefetch thread: " + (m->next_why ? *m->next_why : std::string()));
         }
     }
     if (!stream_waited) {
@@ -1060,9 +1062,12 @@ static int32_t prefetch_body(const std::vector<svh_matcher*>& ms, const std::vec
         }
     }
     // one stream for the whole prefetch when the objects run in lockstep, else each object's second stream
+    // The lockstep hand-over runs on a stream of the prefetch thread's own recorder: it outlives every Matcher, so the
+    // recorder may wait for it before it reuses its arena whatever happened to the objects of the last hand-over.
     BatchRec& pr = prefetch_recorder();
-    HIP_TRY(pr.reuse());
     HIP_TRY(pr.ensure_side());
+    HIP_TRY(pr.reuse());
+    hipStream_t const pf_own = pr.side[0];
     std::vector<int> rcs((size_t)K * ncam, 0);
     batch_parallel_for(K * ncam, [&](int j) {
         (void)hipSetDevice(ms[0]->device);
@@ -1071,16 +1076,16 @@ static int32_t prefetch_body(const std::vector<svh_matcher*>& ms, const std::vec
         DevView& V = m->next[cam];
         rcs[j] = features_pack(m, V, cam, cam ? I2[j / ncam] : I1[j / ncam], pitch);
         if (!rcs[j]) {
-            hipStream_t up = lockstep ? pr.side[j % BatchRec::kSide] : m->stream2;
-            mlaunch_upload(up, V.stage, V.I, (size_t)V.bpl * V.h);
+            // (all on the stream the features follow on: this work is hidden behind the frame before, so the
+            // uploads need not overlap each other -- and the hand-over needs no events)
+            mlaunch_upload(lockstep ? pf_own : m->stream2, V.stage, V.I, (size_t)V.bpl * V.h);
         }
     });
     for (int rc : rcs)
         if (rc) return rc;
     int rc = SVH_OK;
     if (lockstep) {
-        hipStream_t pf = ms[0]->stream2;
-        HIP_TRY(pr.join_side(pf));
+        hipStream_t pf = pf_own;
         pr.reset();
         t_rec = &pr;
         for (int i = 0; i < K && !rc; i++) {
@@ -1140,12 +1145,17 @@ int32_t svh_matcher_prefetch_batch(svh_matcher* const* ms, int32_t K, const uint
     std::vector<svh_matcher*> mv(ms, ms + K);
     std::vector<const uint8_t*> a(I1, I1 + K), b2;
     if (ncam == 2) b2.assign(I2, I2 + K);
-    std::shared_future<int32_t> job = PrefetchWorker::get().post(
-        [mv, a, b2, w, h, pitch, ncam, lockstep]() { return prefetch_body(mv, a, b2, w, h, pitch, ncam, lockstep); });
+    std::shared_ptr<std::string> why = std::make_shared<std::string>();
+    std::shared_future<int32_t> job = PrefetchWorker::get().post([mv, a, b2, w, h, pitch, ncam, lockstep, why]() {
+        const int32_t rc = prefetch_body(mv, a, b2, w, h, pitch, ncam, lockstep);
+        if (rc) *why = svh_last_error();   // (this thread's message: handed to the thread that takes the frame)
+        return rc;
+    });
     for (int i = 0; i < K; i++) {
         ms[i]->has_next = true;
         ms[i]->next_cams = ncam;
         ms[i]->next_job = job;
+        ms[i]->next_why = why;
     }
     return SVH_OK;
 }
@@ -1172,7 +1182,7 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
                 m->next_job = std::shared_future<int32_t>();
                 if (rc) {
                     m->has_next = false;
-                    return mfail(rc, "the hand-over of the prefetched frame failed on the prefetch thread");
+                    return mfail(rc, "the hand-over of the prefetched frame failed on the prefetch thread: " + (m->next_why ? *m->next_why : std::string()));
                 }
             }
             if (std::find(waited.begin(), waited.end(), m->next_stream) == waited.end()) {

@@ -66,6 +66,9 @@ hipError_t hipStreamQuery(hipStream_t s) {
 namespace svh {
 static thread_local std::string t_err;
 int fail(int code, const std::string& msg) { t_err = msg; return code; }
+}  // namespace svh
+extern "C" const char* svh_last_error(void) { return svh::t_err.c_str(); }
+namespace svh {
 
 // ---------------------------------------------------------------- stub launchers
 static uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
