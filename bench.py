@@ -309,7 +309,15 @@ def vo_lockstep_bench(shapes=((1, 4), (1, 16), (1, 32), (2, 8), (2, 16), (4, 8))
         good = [0] * T
         go = threading.Barrier(T + 1)
 
+        errs = []
+
         def worker(g):
+            try:
+                work(g)
+            except Exception as e:   # noqa: BLE001  (a failed call must not look like a fast one)
+                errs.append(repr(e))
+
+        def work(g):
             vos, even, odd = groups[g]
             go.wait()
             if pipe:   # frame i + 1 is handed over while frame i is matched
@@ -334,6 +342,11 @@ def vo_lockstep_bench(shapes=((1, 4), (1, 16), (1, 32), (2, 8), (2, 16), (4, 8))
         dt = time.perf_counter() - t0
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
         cpu = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
+        if errs:
+            out.append({"calling_threads": T, "objects_per_call": K, "pipelined": pipe, "frames_per_s": None,
+                        "error": errs[0]})
+            del groups
+            continue
         out.append({"calling_threads": T, "objects_per_call": K, "pipelined": pipe, "frames_per_s": T * K * frames / dt,
                     "call_ms": 1e3 * dt / frames, "frames_ok": int(sum(good)), "frames": T * K * frames,
                     "host_cores_used": round(cpu / dt, 2)})
