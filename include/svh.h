@@ -86,7 +86,12 @@ typedef struct svh_elas svh_elas;
  *                          (default: spin while at most two threads are inside the library, poll otherwise)
  *   SVH_WAIT_US=n          sleep of the ELAS batch / stream workers between completion polls (40; 0 = spin)
  *   SVH_H2D_STRIDED=0, SVH_D2H_STRIDED=0   one copy per image / map instead of one strided copy per group
- *   SVH_MATCH_LIST=0       dense matching with round 3's k_match_keyed instead of k_match_list (A/B runs)   */
+ *   SVH_MATCH_LIST=0       dense matching with round 3's k_match_keyed instead of k_match_list (A/B runs)
+ *   SVH_DESC_FLY=0         E1 writes the 16-byte descriptor maps; default: only the two Sobel planes, the support and
+ *                          dense matchers assemble the descriptor rows they stage (same results, 27 % less HBM traffic)
+ *   SVH_MATCHER_COPY_KERNEL=0   small pinned transfers of the Matcher / visual odometry by hipMemcpyAsync instead of a
+ *                          copy kernel in the stream's own queue
+ * (the full list with defaults: INTEGRATION.md, "Environment switches")                                      */
 /* Elas::Elas(parameters) -- libelas/src/elas.h:151.  Cheap: callers build one
  * per frame (stereomapper/stereothread.cpp:113); device buffers live in a
  * process-wide pool keyed by (device, width, height).                        */
