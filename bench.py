@@ -539,6 +539,10 @@ def main():
                     help="skip the secondary legs (synthetic, host buffers, latency, Matcher, VO, map)")
     ap.add_argument("--cpu-budget", type=float, default=5.0, help="seconds per CPU baseline leg")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
+    ap.add_argument("--devcount", default="",
+                    help="comma-separated hardware counters collected DEVICE-WIDE over the timed region by "
+                         "tools/libdevcount.so (rocprofiler-sdk device counting service: the kernels are NOT "
+                         "serialised, unlike rocprofv3 --pmc); one set per run; result under `devcount`")
     ap.add_argument("--kitti-dir", default="",
                     help="--workload sequence on a real KITTI raw drive directory (image_00/, image_01/ "
                          "with data/ and timestamps.txt) instead of the 430-frame substitute")
@@ -591,6 +595,11 @@ def main():
     # every stream has its own (round 3: 28.2 k pairs/s at 8, 29.6 k at 16, 29.3-29.6 k at 24-32; round 2
     # measured 4 -> 8 at +4 %).  Must be set before the runtime starts; an explicit setting of the caller wins.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    devcount_so = os.path.join(ROOT, "tools", "libdevcount.so")
+    if args.devcount:
+        if not os.path.exists(devcount_so):
+            raise SystemExit("bench.py --devcount: build tools/libdevcount.so first (make -C tools)")
+        os.environ["ROCP_TOOL_LIBRARIES"] = devcount_so     # read when the HIP runtime starts
     import torch
     import torch.distributed as dist
 
@@ -756,6 +765,18 @@ def main():
         run_stream(max(1, args.warmup))      # opens the stream; its workers and lanes stay up from here on
     barrier()
     import resource
+    dc = dc_names = dc_first = None
+    if args.devcount and rank == 0:
+        dc = C.CDLL(devcount_so)
+        dc.svh_devcount_start.argtypes = [C.c_char_p]
+        dc.svh_devcount_sample.argtypes = [C.POINTER(C.c_double), C.c_int]
+        dc_names = [x for x in args.devcount.split(",") if x]
+        rc = dc.svh_devcount_start(",".join(dc_names).encode())
+        if rc != 0:
+            raise SystemExit("bench.py --devcount: svh_devcount_start -> %d" % rc)
+        buf = (C.c_double * len(dc_names))()
+        dc.svh_devcount_sample(buf, len(dc_names))
+        dc_first = list(buf)
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     if api == "stream":
@@ -767,6 +788,17 @@ def main():
             step()
     torch.cuda.synchronize()
     elapsed_local = time.perf_counter() - t0
+    devcount = None
+    if dc is not None:
+        buf = (C.c_double * len(dc_names))()
+        rc = dc.svh_devcount_sample(buf, len(dc_names))
+        dc.svh_devcount_stop()
+        devcount = {"counters": {n: buf[i] - dc_first[i] for i, n in enumerate(dc_names)},
+                    "first_sample": {n: dc_first[i] for i, n in enumerate(dc_names)},
+                    "region_s": elapsed_local, "pairs": B * args.steps, "rc": rc,
+                    "how": "rocprofiler-sdk device counting service on the whole device (tools/devcount.cpp), started "
+                           "before and sampled after the timed region; the workers' kernels overlap as in every run "
+                           "(nothing is serialised); values are sums over the counter's instances"}
     if stm_box[0] is not None:
         stm_box[0].close()
         stm_box[0] = None
@@ -1056,6 +1088,8 @@ def main():
             "ranks": ranks,
             "roofline": roofline,
         }
+        if devcount is not None:
+            out["devcount"] = devcount
         if args.workload == "hd1080" and all(r_["oracle_mismatch_px_first_two_pairs"] is not None for r_ in ranks):
             out["outputs_match_oracle"] = all(r_["oracle_mismatch_px_first_two_pairs"] == 0 for r_ in ranks)
             out["oracle_check"] = "every rank: D1 and D2 of its first two pairs after the last timed step == the " \

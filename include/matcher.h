@@ -128,7 +128,7 @@ private:
     Matcher(const Matcher&);
     Matcher& operator=(const Matcher&);
     static void report(int32_t rc, const char* what) {
-        if (rc < 0 && rc != SVH_ERR_BAD_ARG)
+        if (rc < 0 && rc != SVH_ERR_BAD_DIMS)   // (bad dimensions: the library has printed the reference's message)
             std::cerr << "ERROR: Matcher::" << what << " failed on the device (" << rc
                       << "): " << svh_last_error() << std::endl;
     }

@@ -29,6 +29,8 @@ extern "C" {
 #define SVH_ERR_HIP           -2  /* HIP runtime failure; svh_last_error() has text   */
 #define SVH_ERR_UNSUPPORTED   -3  /* parameter combination not implemented on device  */
 #define SVH_ERR_NO_DEVICE     -4
+#define SVH_ERR_BAD_DIMS      -7  /* Matcher::pushBack with bad dimensions: "ERROR: Image dimension mismatch!" on
+                                     stderr and the call is ignored, as in the reference (matcher.cpp:110-114) */
 
 /* ------------------------------------------------------------------------ */
 /* ELAS parameters: field-for-field Elas::parameters (libelas/src/elas.h:59-148),
@@ -72,6 +74,12 @@ void svh_elas_params_default(svh_elas_params* p, int32_t setting);
 const char* svh_version(void);
 /* thread-local text of the last failure on the calling thread */
 const char* svh_last_error(void);
+/* TEST HOOK -- fault injection at the HIP layer: "<malloc|launch|copy|wait>:<n>[:<count>]" makes the n-th call of
+ * that kind (counted from now, process-wide) fail, and count-1 more after it (0: all of them); "" or NULL
+ * disarms.  Also read once from the environment variable SVH_TEST_FAIL_AT.  A HIP failure, real or injected,
+ * surfaces as SVH_ERR_HIP from the entry that was running (per pair / per object in the batch, stream and
+ * lockstep entries), with svh_last_error() naming the call and one line on stderr; the object stays usable. */
+int32_t     svh_test_fail_at(const char* spec);
 int32_t     svh_device_count(void);
 /* bind the calling thread's subsequent svh_* objects to a HIP device */
 int32_t     svh_set_device(int32_t device);

@@ -86,9 +86,9 @@ struct BatchRec {
 
 // non-null: the launchers record into it (set and cleared by the batch entries on their own thread)
 extern thread_local BatchRec* t_rec;
-// the calling thread's recorder (its arena is kept for the thread's lifetime)
-BatchRec& batch_recorder();
-BatchRec& prefetch_recorder();
+// the calling thread's recorder for a device (arena and side streams are kept for the thread's lifetime)
+BatchRec& batch_recorder(int device);
+BatchRec& prefetch_recorder(int device);
 // fn(0..n-1) on the library's parked helper threads and the caller; returns when all are done
 void batch_parallel_for(int n, const std::function<void(int)>& fn);
 

@@ -52,11 +52,63 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+// ---- fault injection (svh_internal.h) --------------------------------------------------------------------------
+namespace {
+enum { FI_MALLOC, FI_LAUNCH, FI_COPY, FI_WAIT, FI_KINDS };
+std::atomic<int> g_fi_kind{-1};          // -1: nothing armed
+std::atomic<int64_t> g_fi_first{0}, g_fi_count{1};
+std::atomic<int64_t> g_fi_seen[FI_KINDS];
+int fi_kind_of(const char* t) {
+    if (strstr(t, "hipMalloc") || strstr(t, "hipHostMalloc")) return FI_MALLOC;
+    if (strstr(t, "hipMemcpy") || strstr(t, "hipMemset")) return FI_COPY;
+    if (strstr(t, "hipGetLastError")) return FI_LAUNCH;
+    if (strstr(t, "_wait") || strstr(t, "Synchronize") || strstr(t, "hipEventQuery")) return FI_WAIT;
+    return -1;
+}
+bool fi_parse(const char* spec) {
+    static const char* names[FI_KINDS] = {"malloc", "launch", "copy", "wait"};
+    g_fi_kind.store(-1);
+    if (!spec || !*spec) return true;
+    const char* colon = strchr(spec, ':');
+    if (!colon) return false;
+    int kind = -1;
+    for (int k = 0; k < FI_KINDS; k++)
+        if (strlen(names[k]) == (size_t)(colon - spec) && !strncmp(spec, names[k], colon - spec)) kind = k;
+    if (kind < 0) return false;
+    char* end = nullptr;
+    const long long n = strtoll(colon + 1, &end, 10);
+    long long cnt = 1;
+    if (end && *end == ':') cnt = strtoll(end + 1, nullptr, 10);
+    if (n < 1 || cnt < 0) return false;
+    for (auto& c : g_fi_seen) c.store(0);
+    g_fi_first.store(n);
+    g_fi_count.store(cnt);
+    g_fi_kind.store(kind);
+    return true;
+}
+struct FiEnv {
+    FiEnv() {
+        const char* e = getenv("SVH_TEST_FAIL_AT");
+        if (e && !fi_parse(e)) fprintf(stderr, "svhip: SVH_TEST_FAIL_AT=%s is not <malloc|launch|copy|wait>:<n>[:<count>]\n", e);
+    }
+} g_fi_env;
+}   // namespace
+bool fi_armed() { return g_fi_kind.load(std::memory_order_relaxed) >= 0; }
+bool fi_hit(const char* expr_text) {
+    const int kind = g_fi_kind.load(std::memory_order_relaxed);
+    if (kind < 0 || fi_kind_of(expr_text) != kind) return false;
+    const int64_t i = g_fi_seen[kind].fetch_add(1) + 1, first = g_fi_first.load(), cnt = g_fi_count.load();
+    return i >= first && (cnt == 0 || i < first + cnt);
+}
+void report_hip_failure(const char* entry) { fprintf(stderr, "svhip: %s: %s\n", entry, t_error.c_str()); }
+
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
+        const bool inj_ = fi_armed() && fi_hit(#expr);                                      \
+        hipError_t e_ = inj_ ? hipErrorUnknown : (expr);                                    \
         if (e_ != hipSuccess)                                                               \
-            return fail(SVH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+            return fail(SVH_ERR_HIP, std::string(#expr) + ": " +                            \
+                                     (inj_ ? "injected failure (SVH_TEST_FAIL_AT)" : hipGetErrorString(e_))); \
     } while (0)
 
 static double now_ms() {
@@ -510,8 +562,34 @@ static hipError_t event_wait(Lane& L, hipEvent_t ev) {
     }
 }
 
+static int run_group_body(Lane& L, const svh_elas_params& p, const int32_t* dims, const GroupIO& io,
+                          int32_t* status, Taps* taps, svh_elas* timing, int mode, int prefer_device);
+
+// A HIP failure anywhere in a group: nothing of that group may still be running when the caller hears of it (its
+// output buffers may go away next), and the lane must be fit for the next group.  The lane's streams are drained
+// (best effort: a lost device fails these calls too), the sticky error is cleared, events recorded for the timer are
+// dropped and the flags a half-issued group leaves behind are reset.  The maps of the group are untouched when the
+// failure came before its first output was written (allocation, upload, any launch check or wait of phase A and of
+// the host stage); a failure of the final wait is reported with the maps already written.
 static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, const GroupIO& io,
                      int32_t* status, Taps* taps, svh_elas* timing, int mode = RG_ALL, int prefer_device = 0) {
+    const int rc = run_group_body(L, p, dims, io, status, taps, timing, mode, prefer_device);
+    if (rc == SVH_ERR_HIP) {
+        const std::string keep = t_error;
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+        if (L.copy_stream) (void)hipStreamSynchronize(L.copy_stream);
+        (void)hipGetLastError();
+        L.prof.used = 0;
+        L.resident = false;
+        L.force_host = false;
+        L.P_key[0] = -1;      // the prior table may not have reached the device
+        t_error = keep;
+    }
+    return rc;
+}
+
+static int run_group_body(Lane& L, const svh_elas_params& p, const int32_t* dims, const GroupIO& io,
+                          int32_t* status, Taps* taps, svh_elas* timing, int mode, int prefer_device) {
     const int32_t W = dims[0], H = dims[1], g = io.g;
     int rc = check_params(p, W, H);
     if (rc) return rc;
@@ -592,7 +670,9 @@ static int run_group(Lane& L, const svh_elas_params& p, const int32_t* dims, con
         launch_owner(cx, p, d, g, total_tri, G);
         const bool tiles = !tapping && post_tiles_ok(p);   // gap + mean (+ speckle mask) tile kernels
         // the row kernel also applies the L/R check (its inputs are the row it just matched)
-        const bool lr_done = launch_match(cx, p, d, g, G, &out, tapping);
+        const char* match_err = nullptr;
+        const bool lr_done = launch_match(cx, p, d, g, G, &out, tapping, &match_err);
+        if (match_err) return fail(SVH_ERR_HIP, std::string("launch_match: ") + match_err);
         early_d2 = !io.out_device && lr_done && !tapping && p.postprocess_only_left;
         if (early_d2) {
             if (!L.copy_stream) {
@@ -997,6 +1077,8 @@ struct svh_elas_stream {
     uint64_t next_ticket = 0;
     int32_t popped_in_head = 0, inflight = 0;
     bool stop = false;
+    bool closing = false;        // svh_elas_stream_close has begun: pushes are refused, blocked ones return
+    int32_t users = 0;           // producers inside stream_push (close waits for them before the stream goes away)
     std::vector<std::thread> workers;
 };
 
@@ -1223,6 +1305,7 @@ int32_t svh_elas_process(svh_elas* e, const uint8_t* I1, const uint8_t* I2, floa
     int32_t st = SVH_OK;
     rc = run_group(*L, e->p, dims, io, &st, &e->taps, e);
     release_lane(L);
+    if (rc == SVH_ERR_HIP) report_hip_failure("svh_elas_process");
     return rc ? rc : st;
 }
 
@@ -1349,6 +1432,7 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
     }
     for (auto& m : errs)
         if (!m.empty()) t_error = m;
+    if (first_bad == SVH_ERR_HIP) report_hip_failure("svh_elas_process_batch");
     return first_bad;
 }
 
@@ -1415,17 +1499,16 @@ static void stream_close_open(svh_elas_stream* s) {
     s->cv_work.notify_one();
 }
 
+// A stream worker holds its two lanes only WHILE IT HAS GROUPS IN FLIGHT (round 5; until then for the stream's
+// lifetime, so that a second stream on the device found the pool empty, its workers blocked in acquire_lanes()
+// for ever and svh_elas_stream_close() of it hung in join()).  Taking and returning lanes is a mutex and a
+// vector pop; the lanes keep their buffers, so a busy stream loses nothing, and any number of streams, batch
+// calls and single calls share the pool: a worker asks for both lanes at once (no hold-and-wait) and gives them
+// back as soon as its queue runs dry.
 static void stream_worker(svh_elas_stream* s) {
     t_device = s->device;
     (void)hipSetDevice(s->device);
     Lane* slot[2] = {nullptr, nullptr};
-    acquire_lanes(s->device, 2, slot);
-    for (Lane* L : slot)
-        if (L) {
-            L->parallel_host = false;
-            L->poll_wait = true;      // the workers sleep between polls: a stream must not cost a core per lane
-            (void)L->ensure(s->p, s->dims[0], s->dims[1], s->G);
-        }
     auto take = [&](bool block) -> std::shared_ptr<StreamGroup> {
         std::unique_lock<std::mutex> lk(s->mu);
         if (block) s->cv_work.wait(lk, [&] { return s->stop || !s->ready.empty(); });
@@ -1455,10 +1538,16 @@ static void stream_worker(svh_elas_stream* s) {
     for (;;) {
         std::shared_ptr<StreamGroup> cur = take(true);
         if (!cur) break;
+        acquire_lanes(s->device, 2, slot);
+        for (Lane* L : slot) {
+            L->parallel_host = false;
+            L->poll_wait = true;      // the workers sleep between polls: a stream must not cost a core per lane
+            (void)L->ensure(s->p, s->dims[0], s->dims[1], s->G);   // (a failure is reported by the group's run_group)
+        }
         int k = 0;
         note(*cur, run_group(*slot[k], s->p, s->dims, stream_io(*cur, s->dims[2]), cur->status, nullptr, nullptr, RG_A, 2));
         while (cur) {
-            std::shared_ptr<StreamGroup> nxt = slot[1] ? take(false) : nullptr;
+            std::shared_ptr<StreamGroup> nxt = take(false);
             if (nxt) {
                 finish(1 - k);
                 note(*nxt, run_group(*slot[1 - k], s->p, s->dims, stream_io(*nxt, s->dims[2]), nxt->status, nullptr,
@@ -1476,13 +1565,13 @@ static void stream_worker(svh_elas_stream* s) {
             }
             cur = nxt;
         }
-    }
-    for (Lane* L : slot)
-        if (L) {
+        for (Lane*& L : slot) {
             L->poll_wait = false;
             L->parallel_host = true;
             release_lane(L);
+            L = nullptr;
         }
+    }
 }
 
 svh_elas_stream* svh_elas_stream_open(svh_elas* e, const int32_t* dims, int32_t depth) {
@@ -1499,6 +1588,7 @@ svh_elas_stream* svh_elas_stream_open(svh_elas* e, const int32_t* dims, int32_t 
     const int lanes = std::max(1, g_lanes.load());
     s->depth = depth > 0 ? depth : lanes * 2 * s->G;
     // a worker keeps two groups in flight: no more workers than the depth can feed
+    // (and no more than the pool has lane pairs for: 2 * lanes + 2 lanes per device)
     const int nw = std::max(1, std::min(lanes, (s->depth + 2 * s->G - 1) / (2 * s->G)));
     for (int w = 0; w < nw; w++) s->workers.emplace_back(stream_worker, s);
     return s;
@@ -1508,8 +1598,16 @@ static int32_t stream_push(svh_elas_stream* s, bool device, const uint8_t* I1, c
                            float* D2, uint64_t* ticket) {
     if (!s || !I1 || !I2 || !D1 || !D2) return fail(SVH_ERR_BAD_ARG, "null argument");
     std::unique_lock<std::mutex> lk(s->mu);
-    if (s->stop) return fail(SVH_ERR_BAD_ARG, "stream is closing");
-    s->cv_space.wait(lk, [&] { return s->inflight < s->depth; });
+    if (s->stop || s->closing) return fail(SVH_ERR_BAD_ARG, "stream is closing");
+    // (a producer blocked here while the stream is closed: close() wakes it, it leaves with an error, and
+    // close() waits for `users` to reach zero before the stream is deleted)
+    s->users++;
+    s->cv_space.wait(lk, [&] { return s->stop || s->closing || s->inflight < s->depth; });
+    if (s->stop || s->closing) {
+        s->users--;
+        s->cv_done.notify_all();
+        return fail(SVH_ERR_BAD_ARG, "stream is closing");
+    }
     StreamGroup* g = s->open.get();
     if (g && g->device != device) {
         stream_close_open(s);
@@ -1556,8 +1654,9 @@ static int32_t stream_push(svh_elas_stream* s, bool device, const uint8_t* I1, c
     s->next_ticket++;
     s->inflight++;
     if (g->n >= s->G) stream_close_open(s);
-    lk.unlock();
+    s->users--;
     s->cv_push.notify_all();
+    s->cv_done.notify_all();
     return SVH_OK;
 }
 
@@ -1593,7 +1692,10 @@ int32_t svh_elas_stream_pop(svh_elas_stream* s, uint64_t* ticket, int32_t* statu
     const int32_t j = s->popped_in_head++;
     if (ticket) *ticket = g->first + (uint64_t)j;
     if (status) *status = g->rc != SVH_OK ? g->rc : g->status[j];
-    if (g->rc < 0) t_error = g->err;
+    if (g->rc < 0) {
+        t_error = g->err;
+        if (g->rc == SVH_ERR_HIP && j == 0) report_hip_failure("svh_elas_stream (group)");
+    }
     if (s->popped_in_head >= g->n) {
         s->order.pop_front();
         s->popped_in_head = 0;
@@ -1647,9 +1749,13 @@ int32_t svh_elas_stream_close(svh_elas_stream* s) {
     if (!s) return fail(SVH_ERR_BAD_ARG, "null argument");
     {
         std::unique_lock<std::mutex> lk(s->mu);
+        s->closing = true;              // no new pairs; producers blocked on a full stream return an error
+        s->cv_space.notify_all();
         stream_close_open(s);
-        // every pushed pair completes (the callers' buffers are written or left untouched as promised)
+        // every pushed pair completes (the callers' buffers are written or left untouched as promised) and
+        // every producer has left stream_push
         s->cv_done.wait(lk, [&] {
+            if (s->users > 0) return false;
             for (auto& g : s->order)
                 if (!g->done) return false;
             return true;
@@ -1676,6 +1782,9 @@ int32_t svh_elas_support_from_candidates(const svh_elas_params* p, int32_t width
     return n;
 }
 
+
+/* tests: arm / disarm the fault injection ("" or NULL disarms); see svh_internal.h */
+int32_t svh_test_fail_at(const char* spec) { return fi_parse(spec) ? SVH_OK : fail(SVH_ERR_BAD_ARG, "bad fault specification"); }
 
 int32_t svh_elas_set_stage(int32_t where) {
     g_stage_mode.store(where < 0 ? -1 : (where ? 1 : 0));

@@ -485,8 +485,10 @@ __global__ __launch_bounds__(256) void k_support(const uint8_t* __restrict__ des
 // = consecutive disparities = consecutive 16-byte slots).
 // candidates per block (kSB) and threads per block (kST) are template parameters
 
+// stride of a strip row in slots: the width rounded up to 1 (mod 4)
+__host__ __device__ __forceinline__ int support_stride(int w) { return ((w + 2) & ~3) + 1; }
 struct StripView {
-    const uint4* base;   // LDS, two rows of `w` slots: row 0 = v-2, row 1 = v+2
+    const uint4* base;   // LDS, two rows at a stride of `w` slots: row 0 = v-2, row 1 = v+2
     int x0, w;
     __device__ __forceinline__ uint4 at(int row, int x) const { return base[row * w + (x - x0)]; }
 };
@@ -631,23 +633,30 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
     xl1 = xl1 < P.W - 1 ? xl1 : P.W - 1;
     xr1 = xr1 < P.W - 1 ? xr1 : P.W - 1;
     const int wl = xl1 - xl0 + 1, wr = xr1 - xr0 + 1;
+    // row strides == 1 (mod 4): the four strip rows then start at slots == 0, 1, 2, 3 (mod 4), see the staging loop
+    const int wls = support_stride(wl), wrs = support_stride(wr);
     uint4* sL = s_strip;
-    uint4* sR = s_strip + 2 * wl;
+    uint4* sR = s_strip + 2 * wls;
     __shared__ uint16_t s_texL[kFly ? kSB : 1];
-    uint16_t* s_texR = reinterpret_cast<uint16_t*>(s_strip + 2 * (wl + wr));   // (fly: wr texture values behind the strips)
+    uint16_t* s_texR = reinterpret_cast<uint16_t*>(s_strip + 2 * (wls + wrs));   // (fly: wr texture values behind the strips)
     if (kFly) {
         // the four strips (rows v-2 / v+2 of both images) assembled from the Sobel planes, four aligned pixels per task
         const uint8_t* pl1 = desc_all + (size_t)(2 * pair) * N16 * 16;
         const uint8_t* pl2 = pl1 + N16 * 16;
         const int al0 = xl0 & ~3, ar0 = xr0 & ~3;
         const int nl = (xl1 - al0) / 4 + 1, nr = (xr1 - ar0) / 4 + 1;      // tasks per row of the left / right strip
-        for (int task = (int)threadIdx.x; task < 2 * (nl + nr); task += kST) {
-            const bool rgt = task >= 2 * nl;
-            const int j = rgt ? task - 2 * nl : task, n = rgt ? nr : nl;
-            const int row = j >= n, x = (rgt ? ar0 : al0) + 4 * (j - row * n);
+        // Lane l takes strip row (l & 3) -- left v-2, left v+2, right v-2, right v+2 -- and the rows start at slots
+        // == 0, 1, 2, 3 (mod 4): the 8 lanes of a ds_write_b128 group store to 8 different slots modulo 8, no bank
+        // conflicts (round 4, consecutive tasks of one row on consecutive lanes: 4-way on every store).
+        const int nmax = nl > nr ? nl : nr;
+        for (int task = (int)threadIdx.x; task < 4 * nmax; task += kST) {
+            const int row = task & 1, j = task >> 2;
+            const bool rgt = (task & 2) != 0;
+            if (j >= (rgt ? nr : nl)) continue;
+            const int x = (rgt ? ar0 : al0) + 4 * j;
             uint4 o[4];
             fly_desc4(rgt ? pl2 : pl1, P.W, P.H, x, v + (row ? 2 : -2), o);
-            const int x0 = rgt ? xr0 : xl0, x1 = rgt ? xr1 : xl1, w = rgt ? wr : wl;
+            const int x0 = rgt ? xr0 : xl0, x1 = rgt ? xr1 : xl1, w = rgt ? wrs : wls;
             uint4* dst = (rgt ? sR : sL) + row * w - x0;
 #pragma unroll
             for (int i = 0; i < 4; i++)
@@ -670,15 +679,16 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
         }
     } else {
     // (sL and sR are adjacent: one pass over both strips, up to six loads per thread in flight)
-    stage_slots<6>(s_strip, 2 * (wl + wr), (int)threadIdx.x, kST, [&](int i) {
-        const bool rgt = i >= 2 * wl;
-        const int j = rgt ? i - 2 * wl : i, w = rgt ? wr : wl;
-        const int row = j >= w, x = j - row * w;
+    // (the padding slots behind a row are filled with the row's last column)
+    stage_slots<6>(s_strip, 2 * (wls + wrs), (int)threadIdx.x, kST, [&](int i) {
+        const bool rgt = i >= 2 * wls;
+        const int j = rgt ? i - 2 * wls : i, w = rgt ? wrs : wls, wreal = rgt ? wr : wl;
+        const int row = j >= w, xx = j - row * w, x = xx < wreal ? xx : wreal - 1;
         return (rgt ? d2 : d1)[(size_t)(v + (row ? 2 : -2)) * P.W + (rgt ? xr0 : xl0) + x];
     });
     }
     __syncthreads();
-    const StripView L = {sL, xl0, wl}, R = {sR, xr0, wr};
+    const StripView L = {sL, xl0, wls}, R = {sR, xr0, wrs};
     // Four candidates per wave, one per row of 16 lanes (rows 2k and 2k+1 take candidates 8 apart).
     // A ds_read_b128 is served in four phases of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19,
     // 28-31} and the same in the upper half (MI355X_MICROARCH.md, LDS) -- i.e. half of one row plus
@@ -1392,6 +1402,7 @@ __device__ __forceinline__ void dma_slots(uint4* dst, const uint4* src, int n, i
 struct MatchList {
     int kIters;      // pixels per thread (template argument of the launch)
     int Wr;          // raw-row stride (int16)
+    int Ws;          // descriptor-row stride in LDS (slots): >= W and == 2 (mod 4), see the staging loop
 };
 
 // per-pixel quantities both forms of the scan need
@@ -1578,20 +1589,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(kIters <= 5
     if (!G.hdr->active[pair]) return;
     const size_t N = (size_t)P.W * P.H;
     uint4* s_rows = s_dyn;
-    uint16_t* s_rec = reinterpret_cast<uint16_t*>(s_dyn + 2 * P.W);
+    uint16_t* s_rec = reinterpret_cast<uint16_t*>(s_dyn + 2 * Q.Ws);
     int16_t* s_raw = reinterpret_cast<int16_t*>(s_rec + 2 * P.gw * ML_CAP);
     int line = v < P.H - 3 ? v : P.H - 3;
     line = line > 2 ? line : 2;
     const int cr = v / P.grid_size, cells = P.gw * P.gh;
     {
         if (G.desc_fly) {
-            // the two descriptor rows are assembled from the Sobel planes: four adjacent pixels per task
+            // The two descriptor rows are assembled from the Sobel planes, four adjacent pixels per task.  A lane
+            // stores its four 16-byte slots one after the other, and a ds_write_b128 is served in groups of 8 lanes
+            // over 32 banks: with consecutive tasks on consecutive lanes all 8 lanes of a group hit one of two slots
+            // modulo 8 (4-way conflicts on every store: round 4's 1.4 M conflict cycles per 4-pair launch).  Round 5:
+            // even lanes take the left image, odd lanes the right one, and the second row starts at a slot == 2
+            // (mod 4), so a group's 8 stores fall on four different slots modulo 8 (2-way: 16 LDS cycles against
+            // the 13 the store's data transfer takes anyway).  No data is moved between lanes.
             const int nq = (P.W + 3) >> 2;
             for (int task = tid; task < 2 * nq; task += (int)blockDim.x) {
-                const int im = task >= nq, x = 4 * (task - im * nq);
+                const int im = task & 1, x = 4 * (task >> 1);
                 uint4 o[4];
                 fly_desc4(G.desc + (size_t)(2 * pair + im) * N * 16, P.W, P.H, x, line, o);
-                uint4* dst = s_rows + im * P.W + x;
+                uint4* dst = s_rows + im * Q.Ws + x;
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     if (x + i < P.W) dst[i] = o[i];
@@ -1599,7 +1616,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(kIters <= 5
         } else {
             const uint4* l1 = reinterpret_cast<const uint4*>(G.desc) + (size_t)(2 * pair) * N + (size_t)line * P.W;
             dma_slots(s_rows, l1, P.W, wave, nwaves, lane);
-            dma_slots(s_rows + P.W, l1 + N, P.W, wave, nwaves, lane);
+            dma_slots(s_rows + Q.Ws, l1 + N, P.W, wave, nwaves, lane);
         }
         const int rq = P.gw * ML_CAP * 2 / 16;   // uint4 per side
         const uint4* r1 = reinterpret_cast<const uint4*>(G.lists + ((size_t)(2 * pair) * cells + (size_t)cr * P.gw) * ML_CAP);
@@ -1644,7 +1661,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(kIters <= 5
                                 (uint32_t)__builtin_amdgcn_readfirstlane(s_band[rad + 1]),
                                 (uint32_t)__builtin_amdgcn_readfirstlane(s_band[rad + 2]));
     const uint32_t rows_addr = lds_addr_of(s_rows), rec_addr = lds_addr_of(s_rec) + (uint32_t)(side * P.gw * ML_CAP * 2);
-    const uint32_t own_base = rows_addr + (uint32_t)(side * P.W) * 16u, oth_base = rows_addr + (uint32_t)((1 - side) * P.W) * 16u;
+    const uint32_t own_base = rows_addr + (uint32_t)(side * Q.Ws) * 16u, oth_base = rows_addr + (uint32_t)((1 - side) * Q.Ws) * 16u;
     float* out_row = G.Draw + (size_t)z * P.DW * P.DH + (size_t)v * P.DW;
     int16_t* raw_row = s_raw + side * Q.Wr;
     uint32_t cold = 0;     // pixels (bit k) of this wave that need the checked form
@@ -2335,7 +2352,7 @@ static int support_strip(const svh_elas_params& p, const Dims& d, size_t* lds_ou
         const int span = (sb - 1) * d.step;
         const size_t wl = (size_t)std::min(d.W, span + 2 * p.disp_max + 5);
         const size_t wr = (size_t)std::min(d.W, span + p.disp_max + 5);
-        return 2 * (wl + wr) * sizeof(uint4);
+        return 2 * (size_t)(support_stride((int)wl) + support_stride((int)wr)) * sizeof(uint4);
     };
     int sb = sb_env == 32 ? 32 : 64;
     if (sb == 64 && strip_lds(64) + 2 * (size_t)d.W + 16 + kSupportStatic > 64 * 1024) sb = 32;
@@ -2429,9 +2446,10 @@ static bool match_list_usable(const svh_elas_params& p, const Dims& d, int32_t p
         return false;
     MatchList Q;
     Q.Wr = (d.W + 7) / 8 * 8;
+    Q.Ws = ((d.W + 1) & ~3) + 2;
     const int iters = (d.DW + 255) / 256;
     Q.kIters = iters <= 5 ? 5 : 8;
-    const size_t ldsl = (size_t)2 * d.W * sizeof(uint4) + (size_t)2 * d.gw * ML_CAP * sizeof(uint16_t) +
+    const size_t ldsl = (size_t)2 * Q.Ws * sizeof(uint4) + (size_t)2 * d.gw * ML_CAP * sizeof(uint16_t) +
                         (size_t)2 * Q.Wr * sizeof(int16_t);
     constexpr size_t kListStatic = 256;   // s_band, s_neg
     bool ok = ldsl + kListStatic <= 160 * 1024;
@@ -2458,8 +2476,11 @@ bool descriptors_on_the_fly(const svh_elas_params& p, const Dims& d, int32_t pri
            match_list_usable(p, d, prior_absmax, plane_radius, have_lists, nullptr, nullptr);
 }
 
+// returns false with *error set when the group cannot be matched (a HIP refusal between the descriptor stage and
+// here: the caller reports SVH_ERR_HIP for the group)
 bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
-                  const GroupDev& G, const DevMaps* lr_out, bool write_raw) {
+                  const GroupDev& G, const DevMaps* lr_out, bool write_raw, const char** error) {
+    if (error) *error = nullptr;
     MatchParams P;
     P.W = d.W; P.H = d.H; P.DW = d.DW; P.DH = d.DH; P.gw = d.gw; P.gh = d.gh; P.gwords = d.gwords;
     P.grid_size = p.grid_size; P.sub = p.subsampling; P.disp_max = p.disp_max;
@@ -2494,8 +2515,11 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
         const int iters = (d.DW + 255) / 256;
         const int half = std::min(256, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
         if (!ok && G.desc_fly) {
-            fprintf(stderr, "svhip: descriptors were left as Sobel planes but the list matcher is not usable\n");
-            abort();   // (descriptors_on_the_fly() and this selection are the same function: not reachable)
+            // descriptors_on_the_fly() and this selection are the same function of the same arguments; what can
+            // differ between the two calls is the driver's answer to the LDS opt-in.  The descriptor maps of this
+            // group do not exist, so it cannot fall back: the group fails, the next one decides again.
+            if (error) *error = "the list matcher was refused after the descriptor stage had left only the Sobel planes";
+            return false;
         }
         if (ok) {
             Timed timed_(cx, "k_match");

@@ -48,6 +48,7 @@
 #include <algorithm>
 
 #include "svh_internal.h"
+#include "dt_core.h"
 
 namespace svh {
 
@@ -400,397 +401,27 @@ __global__ __launch_bounds__(512) void k_lattice(StageDev S, LatticeParams P) {
 // ===========================================================================
 // Delaunay
 // ===========================================================================
-struct Vtx {
-    int id;   // input index, -1 = the ghost vertex
-    int xy;   // x | y << 16
-};
-__device__ __forceinline__ int vx(const Vtx& v) { return v.xy & 0xffff; }
-__device__ __forceinline__ int vy(const Vtx& v) { return (int)((unsigned)v.xy >> 16); }
-
-// Triangle records of one triangulation; handle = record * 4 + orientation, 0 = "outer space";
-// handle algebra as in csrc/delaunay.cpp.  Two storages with the same interface:
-//   MeshG  global memory (L2-resident): 32-bit fields, the packed coordinates of a corner sit next
-//          to its index, so a predicate needs no second dependent load;
-//   MeshL  LDS: 16-bit fields (record r: slots 3r..3r+2 of ids[] and nbr[]), coordinates through
-//          the vertex table -- a quarter of the latency per hop; used when 28 bytes per point fit.
-struct MeshG {
-    int* ids;
-    int* xys;
-    unsigned* nbr;
-    __device__ __forceinline__ unsigned sym(unsigned h) const { return nbr[h]; }
-    __device__ __forceinline__ Vtx corner(unsigned t4, int k) const {
-        Vtx v;
-        v.id = ids[t4 + k];
-        v.xy = xys[t4 + k];
-        return v;
-    }
-    __device__ __forceinline__ void set_corner(unsigned t4, int k, const Vtx& v) const {
-        ids[t4 + k] = v.id;
-        xys[t4 + k] = v.xy;
-    }
-    __device__ __forceinline__ void bond(unsigned a, unsigned b) const {
-        nbr[a] = b;
-        nbr[b] = a;
-    }
-    __device__ __forceinline__ unsigned make_rec(int t) const {
-        *reinterpret_cast<int4*>(ids + 4 * (size_t)t) = make_int4(-1, -1, -1, 0);
-        *reinterpret_cast<int4*>(xys + 4 * (size_t)t) = make_int4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(nbr + 4 * (size_t)t) = make_uint4(0, 0, 0, 0);
-        return (unsigned)t * 4u;
-    }
-};
-struct MeshL {
-    unsigned short* ids;
-    unsigned short* nbr;
-    const int* vxy;   // packed coordinates by vertex index
-    __device__ __forceinline__ unsigned sym(unsigned h) const { return nbr[h - (h >> 2)]; }
-    __device__ __forceinline__ Vtx corner(unsigned t4, int k) const {
-        const unsigned id = ids[t4 - (t4 >> 2) + k];
-        Vtx v;
-        v.id = id == 0xffffu ? -1 : (int)id;
-        v.xy = id == 0xffffu ? 0 : vxy[id];
-        return v;
-    }
-    __device__ __forceinline__ void set_corner(unsigned t4, int k, const Vtx& v) const {
-        ids[t4 - (t4 >> 2) + k] = (unsigned short)v.id;
-    }
-    __device__ __forceinline__ void bond(unsigned a, unsigned b) const {
-        nbr[a - (a >> 2)] = (unsigned short)b;
-        nbr[b - (b >> 2)] = (unsigned short)a;
-    }
-    __device__ __forceinline__ unsigned make_rec(int t) const {
-        for (int k = 0; k < 3; k++) {
-            ids[3 * t + k] = 0xffffu;
-            nbr[3 * t + k] = 0;
-        }
-        return (unsigned)t * 4u;
-    }
-};
-__device__ __forceinline__ int p1(int o) { return (0x09 >> (2 * o)) & 3; }   // (o + 1) % 3
-__device__ __forceinline__ int p2(int o) { return (0x12 >> (2 * o)) & 3; }   // (o + 2) % 3
-__device__ __forceinline__ unsigned hnext(unsigned h) { return (h & ~3u) | (unsigned)p1(h & 3); }
-__device__ __forceinline__ unsigned hprev(unsigned h) { return (h & ~3u) | (unsigned)p2(h & 3); }
-template <class M> __device__ __forceinline__ unsigned sym(const M& m, unsigned h) { return m.sym(h); }
-template <class M> __device__ __forceinline__ Vtx org(const M& m, unsigned h) { return m.corner(h & ~3u, p1(h & 3)); }
-template <class M> __device__ __forceinline__ Vtx dest(const M& m, unsigned h) { return m.corner(h & ~3u, p2(h & 3)); }
-template <class M> __device__ __forceinline__ Vtx apex(const M& m, unsigned h) { return m.corner(h & ~3u, h & 3); }
-template <class M> __device__ __forceinline__ void set_org(const M& m, unsigned h, const Vtx& v) { m.set_corner(h & ~3u, p1(h & 3), v); }
-template <class M> __device__ __forceinline__ void set_dest(const M& m, unsigned h, const Vtx& v) { m.set_corner(h & ~3u, p2(h & 3), v); }
-template <class M> __device__ __forceinline__ void set_apex(const M& m, unsigned h, const Vtx& v) { m.set_corner(h & ~3u, h & 3, v); }
-template <class M> __device__ __forceinline__ void bond(const M& m, unsigned a, unsigned b) { m.bond(a, b); }
-template <class M> __device__ __forceinline__ unsigned make_rec(const M& m, int t) { return m.make_rec(t); }
-
-// exact predicates: coordinates are integers in [0, 2^14)
-__device__ __forceinline__ int ccw(const Vtx& a, const Vtx& b, const Vtx& c) {
-    const int l = (vx(a) - vx(c)) * (vy(b) - vy(c));
-    const int r = (vy(a) - vy(c)) * (vx(b) - vx(c));
-    return l > r ? 1 : (l < r ? -1 : 0);
-}
-__device__ __forceinline__ int incircle(const Vtx& a, const Vtx& b, const Vtx& c, const Vtx& d) {
-    const int adx = vx(a) - vx(d), ady = vy(a) - vy(d);
-    const int bdx = vx(b) - vx(d), bdy = vy(b) - vy(d);
-    const int cdx = vx(c) - vx(d), cdy = vy(c) - vy(d);
-    const long long al = adx * adx + ady * ady, bl = bdx * bdx + bdy * bdy, cl = cdx * cdx + cdy * cdy;
-    const long long det = al * (long long)(bdx * cdy - cdx * bdy) + bl * (long long)(cdx * ady - adx * cdy) +
-                          cl * (long long)(adx * bdy - bdx * ady);
-    return det > 0 ? 1 : (det < 0 ? -1 : 0);
-}
-const Vtx kGhost = {-1, 0};
-
-// leaves of the recursion (triangle.cpp:5953-6103 / delaunay.cpp recurse, n == 2 and n == 3)
-template <class M>
-__device__ void dt_leaf(const M& m, const int* order, const int* oxy, int s, int n, int ctr, unsigned* farleft,
-                        unsigned* farright) {
-    Vtx a[3];
-    for (int k = 0; k < n; k++) {
-        a[k].id = order[s + k];
-        a[k].xy = oxy[s + k];
-    }
-    if (n == 2) {
-        unsigned L = make_rec(m, ctr), R = make_rec(m, ctr + 1);
-        set_org(m, L, a[0]);
-        set_dest(m, L, a[1]);
-        set_org(m, R, a[1]);
-        set_dest(m, R, a[0]);
-        bond(m, L, R);
-        L = hprev(L); R = hnext(R);
-        bond(m, L, R);
-        L = hprev(L); R = hnext(R);
-        bond(m, L, R);
-        *farright = R;
-        *farleft = hprev(R);
-        return;
-    }
-    unsigned mid = make_rec(m, ctr), t1 = make_rec(m, ctr + 1), t2 = make_rec(m, ctr + 2), t3 = make_rec(m, ctr + 3);
-    const int area = ccw(a[0], a[1], a[2]);
-    if (area == 0) {
-        set_org(m, mid, a[0]); set_dest(m, mid, a[1]);
-        set_org(m, t1, a[1]);  set_dest(m, t1, a[0]);
-        set_org(m, t2, a[2]);  set_dest(m, t2, a[1]);
-        set_org(m, t3, a[1]);  set_dest(m, t3, a[2]);
-        bond(m, mid, t1);
-        bond(m, t2, t3);
-        mid = hnext(mid); t1 = hprev(t1); t2 = hnext(t2); t3 = hprev(t3);
-        bond(m, mid, t3);
-        bond(m, t1, t2);
-        mid = hnext(mid); t1 = hprev(t1); t2 = hnext(t2); t3 = hprev(t3);
-        bond(m, mid, t1);
-        bond(m, t2, t3);
-        *farleft = t1;
-        *farright = t2;
-    } else {
-        const Vtx p = area > 0 ? a[1] : a[2];
-        const Vtx q = area > 0 ? a[2] : a[1];
-        set_org(m, mid, a[0]); set_dest(m, t1, a[0]); set_org(m, t3, a[0]);
-        set_dest(m, mid, p);   set_org(m, t1, p);     set_dest(m, t2, p);
-        set_apex(m, mid, q);   set_org(m, t2, q);     set_dest(m, t3, q);
-        bond(m, mid, t1);
-        mid = hnext(mid);
-        bond(m, mid, t2);
-        mid = hnext(mid);
-        bond(m, mid, t3);
-        t1 = hprev(t1); t2 = hnext(t2);
-        bond(m, t1, t2);
-        t1 = hprev(t1); t3 = hprev(t3);
-        bond(m, t1, t3);
-        t2 = hnext(t2); t3 = hprev(t3);
-        bond(m, t2, t3);
-        *farleft = t1;
-        *farright = area > 0 ? t2 : hnext(t1);
-    }
-}
-
-// merge of two triangulated halves (triangle.cpp:5638-5934 / delaunay.cpp merge); the two seam
-// records are ctr and ctr + 1
-template <class M>
-__device__ void dt_merge(const M& m, unsigned* farleft, unsigned innerleft, unsigned innerright, unsigned* farright,
-                         int axis, int ctr) {
-    Vtx il_dest = dest(m, innerleft), il_apex = apex(m, innerleft);
-    Vtx ir_org = org(m, innerright), ir_apex = apex(m, innerright);
-    if (axis == 1) {
-        // horizontal cut: the extreme handles go from leftmost / rightmost to bottommost / topmost
-        Vtx fl_pt = org(m, *farleft), fl_apex = apex(m, *farleft);
-        Vtx fr_pt = dest(m, *farright);
-        while (vy(fl_apex) < vy(fl_pt)) {
-            *farleft = sym(m, hnext(*farleft));
-            fl_pt = fl_apex;
-            fl_apex = apex(m, *farleft);
-        }
-        unsigned chk = sym(m, innerleft);
-        Vtx cv = apex(m, chk);
-        while (vy(cv) > vy(il_dest)) {
-            innerleft = hnext(chk);
-            il_apex = il_dest;
-            il_dest = cv;
-            chk = sym(m, innerleft);
-            cv = apex(m, chk);
-        }
-        while (vy(ir_apex) < vy(ir_org)) {
-            innerright = sym(m, hnext(innerright));
-            ir_org = ir_apex;
-            ir_apex = apex(m, innerright);
-        }
-        chk = sym(m, *farright);
-        cv = apex(m, chk);
-        while (vy(cv) > vy(fr_pt)) {
-            *farright = hnext(chk);
-            fr_pt = cv;
-            chk = sym(m, *farright);
-            cv = apex(m, chk);
-        }
-    }
-    // lower common tangent
-    bool moved;
-    do {
-        moved = false;
-        if (ccw(il_dest, il_apex, ir_org) > 0) {
-            innerleft = sym(m, hprev(innerleft));
-            il_dest = il_apex;
-            il_apex = apex(m, innerleft);
-            moved = true;
-        }
-        if (ccw(ir_apex, ir_org, il_dest) > 0) {
-            innerright = sym(m, hnext(innerright));
-            ir_org = ir_apex;
-            ir_apex = apex(m, innerright);
-            moved = true;
-        }
-    } while (moved);
-
-    unsigned lcand = sym(m, innerleft), rcand = sym(m, innerright);
-    unsigned base = make_rec(m, ctr);
-    bond(m, base, innerleft);
-    base = hnext(base);
-    bond(m, base, innerright);
-    base = hnext(base);
-    set_org(m, base, ir_org);
-    set_dest(m, base, il_dest);
-    if (il_dest.id == org(m, *farleft).id) *farleft = hnext(base);
-    if (ir_org.id == dest(m, *farright).id) *farright = hprev(base);
-
-    Vtx lowerleft = il_dest, lowerright = ir_org;
-    Vtx upperleft = apex(m, lcand), upperright = apex(m, rcand);
-    // The walk is a chain of dependent loads (handle -> neighbour handle -> its apex -> its
-    // coordinates).  The triangle behind each candidate edge (nx*, its apex nap*) is therefore
-    // fetched for BOTH sides at once and kept while that side stands still: the two hulls are
-    // disjoint records, and a new seam edge on one side touches nothing the other side has cached.
-    unsigned nxL = 0, nxR = 0;
-    Vtx napL = kGhost, napR = kGhost;
-    bool haveL = false, haveR = false;
-    for (;;) {
-        if (!haveL) nxL = sym(m, hprev(lcand));
-        if (!haveR) nxR = sym(m, hnext(rcand));
-        if (!haveL) napL = apex(m, nxL);
-        if (!haveR) napR = apex(m, nxR);
-        haveL = haveR = true;
-        const bool leftdone = ccw(upperleft, lowerleft, lowerright) <= 0;
-        const bool rightdone = ccw(upperright, lowerleft, lowerright) <= 0;
-        if (leftdone && rightdone) {
-            unsigned top = make_rec(m, ctr + 1);
-            set_org(m, top, lowerleft);
-            set_dest(m, top, lowerright);
-            bond(m, top, base);
-            top = hnext(top);
-            bond(m, top, rcand);
-            top = hnext(top);
-            bond(m, top, lcand);
-            if (axis == 1) {
-                // back to leftmost / rightmost anchors
-                Vtx fl_pt = org(m, *farleft);
-                Vtx fr_pt = dest(m, *farright), fr_apex = apex(m, *farright);
-                unsigned chk = sym(m, *farleft);
-                Vtx cv = apex(m, chk);
-                while (vx(cv) < vx(fl_pt)) {
-                    *farleft = hprev(chk);
-                    fl_pt = cv;
-                    chk = sym(m, *farleft);
-                    cv = apex(m, chk);
-                }
-                while (vx(fr_apex) > vx(fr_pt)) {
-                    *farright = sym(m, hprev(*farright));
-                    fr_pt = fr_apex;
-                    fr_apex = apex(m, *farright);
-                }
-            }
-            return;
-        }
-        if (!leftdone && napL.id >= 0) {
-            // strip left-side edges that fail the in-circle test (flips in place)
-            bool bad = incircle(lowerleft, lowerright, upperleft, napL) > 0;
-            while (bad) {
-                unsigned nx = hnext(nxL);
-                const unsigned topc = sym(m, nx);
-                nx = hnext(nx);
-                const unsigned sidec = sym(m, nx);
-                bond(m, nx, topc);
-                bond(m, lcand, sidec);
-                lcand = hnext(lcand);
-                const unsigned outerc = sym(m, lcand);   // (after the bonds: tiny hulls share several edges)
-                nx = hprev(nx);
-                bond(m, nx, outerc);
-                set_org(m, lcand, lowerleft);
-                set_dest(m, lcand, kGhost);
-                set_apex(m, lcand, napL);
-                set_org(m, nx, kGhost);
-                set_dest(m, nx, upperleft);
-                set_apex(m, nx, napL);
-                upperleft = napL;
-                nxL = sidec;
-                napL = apex(m, nxL);
-                bad = napL.id >= 0 && incircle(lowerleft, lowerright, upperleft, napL) > 0;
-            }
-        }
-        if (!rightdone && napR.id >= 0) {
-            bool bad = incircle(lowerleft, lowerright, upperright, napR) > 0;
-            while (bad) {
-                unsigned nx = hprev(nxR);
-                const unsigned topc = sym(m, nx);
-                nx = hprev(nx);
-                const unsigned sidec = sym(m, nx);
-                bond(m, nx, topc);
-                bond(m, rcand, sidec);
-                rcand = hprev(rcand);
-                const unsigned outerc = sym(m, rcand);
-                nx = hnext(nx);
-                bond(m, nx, outerc);
-                set_org(m, rcand, kGhost);
-                set_dest(m, rcand, lowerright);
-                set_apex(m, rcand, napR);
-                set_org(m, nx, upperright);
-                set_dest(m, nx, kGhost);
-                set_apex(m, nx, napR);
-                upperright = napR;
-                nxR = sidec;
-                napR = apex(m, nxR);
-                bad = napR.id >= 0 && incircle(lowerleft, lowerright, upperright, napR) > 0;
-            }
-        }
-        if (leftdone || (!rightdone && incircle(upperleft, lowerleft, lowerright, upperright) > 0)) {
-            // new edge lowerleft -> upperright
-            bond(m, base, rcand);
-            base = hprev(rcand);
-            set_dest(m, base, lowerleft);
-            lowerright = upperright;
-            rcand = sym(m, base);
-            upperright = apex(m, rcand);
-            haveR = false;
-        } else {
-            // new edge upperleft -> lowerright (also on a co-circular tie)
-            bond(m, base, lcand);
-            base = hnext(lcand);
-            set_org(m, base, lowerright);
-            lowerleft = upperleft;
-            lcand = sym(m, base);
-            upperleft = apex(m, lcand);
-            haveL = false;
-        }
-    }
-}
+// Triangle records, leaves and the merge of two halves: csrc/dt_core.h (shared with the CPU check
+// tests/cxx/dt_core_check.cpp).  Round 5: records are fetched whole, their corners carry the coordinates.
+using namespace dt;
 
 struct DtParams {
     int lds_ints;                 // ints of dynamic LDS of a k_delaunay block
-    int lds_cap;                  // points whose records fit the block's LDS (28 bytes per point)
+    int lds_cap;                  // points whose records fit the block's LDS (48 bytes per point)
     int xoff;                     // added to x: the left corner points lie at -d in the right image
     int W, H, sup_cap, rec_cap;   // W: columns the points may use (image width + disp_max: the two
-};                                // right-image corner points of addCornerSupportPoints lie at W-1+d)
-
-// node (s, n) reached from the root (0, m) along the top `depth` bits of `path` (MSB first);
-// returns false when a leaf is met before `depth`.  base = first record of the node.
-__device__ __forceinline__ bool dt_descend(int m, int depth, unsigned path, int* s, int* n, int* base) {
-    int ss = 0, nn = m, bb = 1;
-    for (int k = depth - 1; k >= 0; k--) {
-        if (nn <= 3) return false;
-        const int h = nn >> 1;
-        if ((path >> k) & 1) {
-            bb += 2 * h - 2;
-            ss += h;
-            nn -= h;
-        } else {
-            nn = h;
-        }
-    }
-    *s = ss; *n = nn; *base = bb;
-    return true;
-}
-// segment of position i at `depth` (stops at leaves): start, size
-__device__ __forceinline__ void dt_segment(int m, int depth, int i, int* s, int* n) {
-    int ss = 0, nn = m;
-    for (int k = 0; k < depth && nn > 3; k++) {
-        const int h = nn >> 1;
-        if (i < ss + h) nn = h;
-        else { ss += h; nn -= h; }
-    }
-    *s = ss; *n = nn;
-}
+                                  // right-image corner points of addCornerSupportPoints lie at W-1+d)
+    int spread;                   // depths with at most this many nodes give consecutive nodes to different waves
+};
 
 // The recursion of the divide and conquer, bottom-up: all nodes of one depth are independent (one
 // lane each), leaves at `depth` first, the root last.  FL / FR: hull handles (farleft, farright)
 // of the nodes of a depth, by first vertex, two depths alternating.
 template <int kT, class M>
 __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const int* order, const int* oxy,
-                                         unsigned* FL, unsigned* FR, int sup_cap, int64_t* dbg, bool stamp) {
+                                         unsigned* FL, unsigned* FR, int sup_cap, int64_t* dbg, bool stamp, int spread) {
     const int tid = threadIdx.x;
-    if (tid == 0) make_rec(mesh, 0);   // record 0 = outer space
+    if (tid == 0) mesh.make_rec(0);   // record 0 = outer space
     __syncthreads();
     for (int d = depth; d >= 0; d--) {
         unsigned* fl = FL + (size_t)(d & 1) * sup_cap;
@@ -798,29 +429,17 @@ __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const 
         const unsigned* cfl = FL + (size_t)((d + 1) & 1) * sup_cap;
         const unsigned* cfr = FR + (size_t)((d + 1) & 1) * sup_cap;
         const unsigned tasks = 1u << d;
-        // Large triangulations (1024 threads, records in L2): consecutive nodes go to DIFFERENT waves (lane
-        // l of wave w takes node l * waves + w).  The merges of one depth run the same code but branch
-        // apart at every seam step, and every step is a chain of L2 round trips: sixteen waves keep sixteen
-        // chains in flight where one wave kept one (1920x1080: build 1 290 -> 940 us).  With the records in
-        // LDS (KITTI size, 256 threads) the same spreading is slower (634 -> 744 us): there a step is
-        // instruction-bound and the lanes of one wave share most of it.
+        // Which lane takes which node.  A merge is ~250 instructions per seam step on ONE lane, and two merges on
+        // lanes of the same wave branch apart at every step (flip or not, which side the new seam edge takes), so
+        // they largely run one after the other.  Near the root, where a depth has only a few nodes, consecutive
+        // nodes therefore go to DIFFERENT waves (lane l of wave w takes node l * waves + w): the waves sit on
+        // different SIMDs and run side by side.  Deep in the tree (hundreds of short merges of similar shape) the
+        // lanes of a wave share most of the code and the dense assignment is the faster one (round 3: spreading
+        // EVERY depth of a KITTI-size set 634 -> 744 us; large sets with their records in L2 spread always).
         constexpr unsigned kWaves = kT / 64;
-        const unsigned j0 = kT >= 1024 ? (unsigned)(tid & 63) * kWaves + (unsigned)(tid >> 6) : (unsigned)tid;
-        for (unsigned j = j0; j < tasks; j += kT) {
-            int s, n, base;
-            if (!dt_descend(m, d, j, &s, &n, &base)) continue;
-            unsigned a, b;
-            if (n <= 3) {
-                dt_leaf(mesh, order, oxy, s, n, base, &a, &b);
-            } else {
-                const int h = n >> 1;
-                a = cfl[s];
-                b = cfr[s + h];
-                dt_merge(mesh, &a, cfr[s], cfl[s + h], &b, d & 1, base + 2 * n - 4);
-            }
-            fl[s] = a;
-            fr[s] = b;
-        }
+        const bool spr = kT >= 1024 || tasks <= (unsigned)spread;
+        const unsigned j0 = spr ? (unsigned)(tid & 63) * kWaves + (unsigned)(tid >> 6) : (unsigned)tid;
+        for (unsigned j = j0; j < tasks; j += kT) dt_node<true>(mesh, m, d, j, order, oxy, cfl, cfr, fl, fr);
         __syncthreads();
         if (stamp && tid == 0 && 11 + (depth - d) < 30) dbg[11 + (depth - d)] = wall_clock64();
     }
@@ -832,7 +451,7 @@ __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const 
 //              bucket lists when they fit (the rank of a point walks its column and its row bucket:
 //              dependent reads, ~10 per point -- from LDS instead of L2);
 //   cut order  the two rank lists, the partition buffer and the prefix counts (16 bytes per point);
-//   build      the triangle records (28 bytes per point) when they fit.
+//   build      the triangle records (48 bytes per point: two 24-byte records) when they fit.
 // kT = 256 for KITTI-size lattices; 1024 for large ones (1920x1080: 6-12 k points per side), where
 // the chunked loops of the first two phases are 4x shorter per thread.
 // ---------------------------------------------------------------------------
@@ -1105,24 +724,19 @@ __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
     unsigned* FR = S.fr + (size_t)slot * 2 * P.sup_cap;
     __syncthreads();   // the histograms are dead: the LDS block is reused for the records
     if (m <= P.lds_cap) {
-        const int nrec = 2 * m + 2;
         MeshL ml;
-        ml.ids = reinterpret_cast<unsigned short*>(s_hist);
-        ml.nbr = ml.ids + 3 * nrec;
-        int* vxy = reinterpret_cast<int*>(ml.nbr + 3 * nrec);   // 12 * nrec bytes in: 4-byte aligned
-        ml.vxy = vxy;
-        for (int p = tid; p < m; p += kT) vxy[p] = pxy[p];
-        dt_build<kT>(ml, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0);
+        ml.base = reinterpret_cast<unsigned char*>(s_hist);      // 24 bytes per record, 2m + 2 records
+        dt_build<kT>(ml, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0, P.spread);
         // corner indices out for k_stage_pack (records 1 .. 2m-2)
         // (after coincident points were dropped the triangulation's point p is support point dmap[p])
-        auto sid = [&](unsigned a) { return a == 0xffffu ? -1 : (remap ? dmap[a] : (int)a); };
+        auto sid = [&](int a) { return a < 0 ? -1 : (remap ? dmap[a] : a); };
         for (int t = 1 + tid; t < 2 * m - 1; t += kT) {
-            const unsigned a0 = ml.ids[3 * t], a1 = ml.ids[3 * t + 1], a2 = ml.ids[3 * t + 2];
-            *reinterpret_cast<int4*>(mg.ids + 4 * (size_t)t) = make_int4(sid(a0), sid(a1), sid(a2), 0);
+            const Rec rc = ml.load((unsigned)t * 4u);
+            *reinterpret_cast<int4*>(mg.ids + 4 * (size_t)t) = make_int4(sid(rc.id0), sid(rc.id1), sid(rc.id2), 0);
         }
         __syncthreads();
     } else {
-        dt_build<kT>(mg, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0);
+        dt_build<kT>(mg, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0, P.spread);
         if (remap) {
             for (int t = 1 + tid; t < 2 * m - 1; t += kT) {
                 int4 v = *reinterpret_cast<const int4*>(mg.ids + 4 * (size_t)t);
@@ -1243,29 +857,42 @@ static int dt_columns(const svh_elas_params& p, const Dims& d) { return d.W + 2 
 // large lattices (1920x1080: 83 k cells, 6-12 k support points per side) get the whole LDS of a CU: the
 // rank lists of the cut-order phase take 16 bytes per point
 static bool dt_large(const Dims& d) { return (size_t)d.Wc * d.Hc / 8 * 16 > 63 * 1024; }
-// the 1024-thread form needs the 159 KB opt-in of the CURRENT device: asked once per device, and a refusal
-// (a part with 64 KB of LDS per workgroup) sends large lattices through the 256-thread / 63 KB form instead
-static bool dt_big_lds_ok() {
+// More than 64 KB of dynamic LDS needs an opt-in per kernel and device: asked once per device; a refusal (a part
+// with 64 KB of LDS per workgroup) sends large lattices through the 256-thread / 63 KB form and keeps the small
+// form at 63 KB (records of larger point sets then live in L2).
+static int dt_small_threads() {
+    static const int t = getenv("SVH_DT_THREADS") ? atoi(getenv("SVH_DT_THREADS")) : 256;
+    return t == 512 ? 512 : 256;
+}
+static bool dt_lds_optin(bool big, size_t bytes) {
     static std::mutex mu;
-    static int state[64];   // 0 unknown, 1 granted, 2 refused
+    static int state[2][64];   // 0 unknown, 1 granted, 2 refused
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     std::lock_guard<std::mutex> lk(mu);
-    if (state[dev] == 0) {
-        const bool ok = hipFuncSetAttribute((const void*)k_delaunay<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            159 * 1024) == hipSuccess;
+    if (state[big][dev] == 0) {
+        const void* fn = big ? (const void*)k_delaunay<1024>
+                             : (dt_small_threads() == 512 ? (const void*)k_delaunay<512> : (const void*)k_delaunay<256>);
+        const bool ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
         if (!ok) (void)hipGetLastError();
-        state[dev] = ok ? 1 : 2;
+        state[big][dev] = ok ? 1 : 2;
     }
-    return state[dev] == 1;
+    return state[big][dev] == 1;
+}
+// KITTI-size lattices: 96 KB = 2 046 points per side with their records in LDS at 48 bytes per point (the crops
+// have <= 1 761); round 4 kept 28-byte records in 54 KB so that a CU hosting a triangulation still fitted two
+// blocks of k_match_list beside it -- with whole-record reads the build is short enough to pay for the one block
+// (SVH_DT_LDS_KB overrides: A/B in profiles/r05_delaunay.txt)
+static size_t dt_small_kb() {
+    static const size_t kb = getenv("SVH_DT_LDS_KB") ? (size_t)atoi(getenv("SVH_DT_LDS_KB")) : 96;
+    return std::min<size_t>(159, std::max<size_t>(kb, 8));
 }
 static size_t dt_lds_bytes(const svh_elas_params& p, const Dims& d, bool big) {
     const size_t hist = 4 * (size_t)(2 * (dt_columns(p, d) + d.H) + 2);
-    // KITTI-size lattices: 54 KB (1 973 points per side in LDS; the crops have <= 1 761) instead of the 63 KB the
-    // kernel could take: a CU that hosts one triangulation then still fits TWO 52 KB blocks of k_match_list beside
-    // it instead of one (pipelined bench 33.2-33.4 -> 33.4-33.7 k pairs/s; 48 KB spills records to L2: 31.6-32.1 k)
-    static const size_t small_kb = getenv("SVH_DT_LDS_KB") ? (size_t)atoi(getenv("SVH_DT_LDS_KB")) : 54;
-    return big ? std::max<size_t>(hist, 159 * 1024) : std::max<size_t>(hist, std::min<size_t>(63, std::max<size_t>(small_kb, 8)) * 1024);
+    if (big) return std::max<size_t>(hist, 159 * 1024);
+    size_t want = dt_small_kb() * 1024;
+    if (want > 63 * 1024 && !dt_lds_optin(false, dt_small_kb() * 1024)) want = 63 * 1024;
+    return std::max<size_t>(hist, want);
 }
 
 bool stage_device_ok(const svh_elas_params& p, const Dims& d) {
@@ -1312,16 +939,19 @@ void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Di
     DtParams D;
     D.W = dt_columns(p, d); D.H = d.H; D.sup_cap = S.sup_cap; D.rec_cap = S.rec_cap;
     D.xoff = std::max(p.disp_max, 0);
-    const bool big = dt_large(d) && dt_big_lds_ok();
+    static const int dt_spread = getenv("SVH_DT_SPREAD") ? atoi(getenv("SVH_DT_SPREAD")) : 16;
+    D.spread = dt_spread;
+    const bool big = dt_large(d) && dt_lds_optin(true, 159 * 1024);
     const size_t dt_lds = dt_lds_bytes(p, d, big);
     D.lds_ints = (int)(dt_lds / 4);
-    D.lds_cap = (int)std::min<size_t>((dt_lds - 32) / 28 - 1, 8000);   // 16-bit handles: < 8191 points
+    D.lds_cap = (int)std::min<size_t>((dt_lds - 32) / 48 - 1, 8000);   // 16-bit handles: < 8191 points
     {
         Timed t(cx, "k_delaunay");
         if (big) {
             hipLaunchKernelGGL(k_delaunay<1024>, dim3(2 * g), dim3(1024), dt_lds, s, S, D);
         } else {
-            hipLaunchKernelGGL(k_delaunay<256>, dim3(2 * g), dim3(256), dt_lds, s, S, D);
+            if (dt_small_threads() == 512) hipLaunchKernelGGL(k_delaunay<512>, dim3(2 * g), dim3(512), dt_lds, s, S, D);
+            else hipLaunchKernelGGL(k_delaunay<256>, dim3(2 * g), dim3(256), dt_lds, s, S, D);
         }
     }
     {

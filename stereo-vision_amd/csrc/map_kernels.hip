@@ -28,6 +28,9 @@
 
 namespace svh {
 int fail(int code, const std::string& msg);   // elas_engine.cpp: sets svh_last_error()
+bool fi_armed();                                    // elas_engine.cpp: fault injection (svh_internal.h)
+bool fi_hit(const char* expr_text);
+void report_hip_failure(const char* entry);
 }
 
 namespace {
@@ -314,10 +317,16 @@ struct svh_map {
     }
 };
 
+static int map_hip_failed(const char* expr, bool injected, hipError_t e) {
+    const int rc = svh::fail(SVH_ERR_HIP, std::string(expr) + ": " + (injected ? "injected failure (SVH_TEST_FAIL_AT)" : hipGetErrorString(e)));
+    svh::report_hip_failure("map");
+    return rc;
+}
 #define MAP_TRY(expr)                                                                      \
     do {                                                                                   \
-        hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess) return svh::fail(SVH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        const bool inj_ = svh::fi_armed() && svh::fi_hit(#expr);   /* svh_internal.h: fault injection */ \
+        hipError_t e_ = inj_ ? hipErrorUnknown : (expr);                                   \
+        if (e_ != hipSuccess) return map_hip_failed(#expr, inj_, e_);                      \
     } while (0)
 
 static int32_t map_ensure(svh_map* m, int32_t w, int32_t h) {

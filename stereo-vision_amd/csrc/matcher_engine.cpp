@@ -27,6 +27,7 @@
 #include <condition_variable>
 #include <functional>
 #include <future>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <deque>
@@ -41,6 +42,9 @@
 namespace svh {
 
 int fail(int code, const std::string& msg);   // elas_engine.cpp: sets svh_last_error()
+bool fi_armed();                                    // elas_engine.cpp: fault injection (svh_internal.h)
+bool fi_hit(const char* expr_text);
+void report_hip_failure(const char* entry);
 static int mfail(int code, const std::string& msg) { return fail(code, msg); }
 
 // Threads that are inside a compute entry of the Matcher / visual odometry right now (svh_matcher_push_back,
@@ -157,15 +161,26 @@ void BatchRec::release() {
     flush_pending = false;
 }
 
-// the calling thread's recorder (its arena lives as long as the thread)
-BatchRec& batch_recorder() {
-    static thread_local BatchRec rec;
-    return rec;
+// The calling thread's recorder FOR A DEVICE (arena, side streams and events live on the device that was current
+// when they were created; they are kept for the thread's lifetime).  Round 5: one recorder per (thread, device) --
+// a thread that drove a lockstep batch on GPU 0 and then one on GPU 1 used to launch the second batch's kernels with
+// a job table in GPU 0's memory.
+namespace {
+BatchRec& recorder_of(std::map<int, std::unique_ptr<BatchRec>>& recs, int device) {
+    std::unique_ptr<BatchRec>& r = recs[device];
+    if (!r) r.reset(new BatchRec());
+    return *r;
+}
+}   // namespace
+BatchRec& batch_recorder(int device) {
+    static thread_local std::map<int, std::unique_ptr<BatchRec>> recs;
+    return recorder_of(recs, device);
 }
 // a second one for svh_matcher_prefetch_batch: its launches are still in flight when the thread records the next
 // phases of the frame before
-BatchRec& prefetch_recorder() {
-    static thread_local BatchRec rec;
+BatchRec& prefetch_recorder(int device) {
+    static thread_local std::map<int, std::unique_ptr<BatchRec>> recs;
+    BatchRec& rec = recorder_of(recs, device);
     rec.track = true;
     return rec;
 }
@@ -300,11 +315,18 @@ private:
 thread_local bool t_in_batch = false;   // inside a batch call: the outlier vote does not fork (the pool is the parallelism)
 }  // namespace
 
+// a failed HIP call: svh_last_error() names it, one line on stderr at the point of failure (the entries above it
+// only pass the code on), SVH_ERR_HIP
+static int hip_failed(const char* expr, bool injected, hipError_t e) {
+    const int rc = mfail(SVH_ERR_HIP, std::string(expr) + ": " + (injected ? "injected failure (SVH_TEST_FAIL_AT)" : hipGetErrorString(e)));
+    report_hip_failure("Matcher");
+    return rc;
+}
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
-        hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            return mfail(SVH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+        const bool inj_ = fi_armed() && fi_hit(#expr);   /* svh_internal.h: fault injection */ \
+        hipError_t e_ = inj_ ? hipErrorUnknown : (expr);                                     \
+        if (e_ != hipSuccess) return hip_failed(#expr, inj_, e_);                            \
     } while (0)
 
 template <typename T>
@@ -973,7 +995,7 @@ static int32_t push_prepare(svh_matcher* m, const uint8_t* I1, const uint8_t* I2
     if (w <= 0 || h <= 0 || pitch < w || I1 == 0) {
         // matcher.cpp:110-114
         fprintf(stderr, "ERROR: Image dimension mismatch!\n");
-        return SVH_ERR_BAD_ARG;
+        return SVH_ERR_BAD_DIMS;   // (its own code: callers that mimic the reference ignore THIS one only)
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1064,7 +1086,7 @@ static int32_t prefetch_body(const std::vector<svh_matcher*>& ms, const std::vec
     // one stream for the whole prefetch when the objects run in lockstep, else each object's second stream
     // The lockstep hand-over runs on a stream of the prefetch thread's own recorder: it outlives every Matcher, so the
     // recorder may wait for it before it reuses its arena whatever happened to the objects of the last hand-over.
-    BatchRec& pr = prefetch_recorder();
+    BatchRec& pr = prefetch_recorder(ms[0]->device);
     HIP_TRY(pr.ensure_side());
     HIP_TRY(pr.reuse());
     hipStream_t const pf_own = pr.side[0];
@@ -1224,9 +1246,13 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
     btick(1);
     const int ncam = (I2 && I2[0]) ? 2 : 1;
     std::vector<int> rcs((size_t)K * ncam, 0);
-    BatchRec& up = batch_recorder();
+    BatchRec& up = batch_recorder(ms[0]->device);
     HIP_TRY(up.ensure_side());
-    t_in_batch = true;
+    struct InBatch {     // (cleared on every exit, the error returns included)
+        InBatch() { t_in_batch = true; }
+        ~InBatch() { t_in_batch = false; }
+    };
+    InBatch in_batch_;
     BatchPool::get().parallel_for(K * ncam, [&](int j) {
         (void)hipSetDevice(ms[0]->device);
         svh_matcher* m = ms[j / ncam];
@@ -1241,11 +1267,10 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
         }
     });
     HIP_TRY(up.join_side(ms[0]->stream));
-    t_in_batch = false;
     for (int rc : rcs)
         if (rc) return rc;
     btick(2);
-    BatchRec& rec = batch_recorder();
+    BatchRec& rec = batch_recorder(ms[0]->device);
     rec.reset();
     t_rec = &rec;
     int rc = SVH_OK;
@@ -1401,14 +1426,20 @@ int32_t svh_matcher_match_features_batch(svh_matcher* const* ms, int32_t K, int3
     const int32_t ub = (int32_t)ceilf((float)part[0]->dims_c[0] / (float)p.match_binsize);
     const int32_t vb = (int32_t)ceilf((float)part[0]->dims_c[1] / (float)p.match_binsize);
     hipStream_t s = part[0]->stream;
-    BatchRec& rec = batch_recorder();
+    BatchRec& rec = batch_recorder(part[0]->device);
     std::vector<MatchPass> mp(n);
     std::vector<int> rcs(n, 0);
     double t_wait = 0, tm[5] = {0, 0, 0, 0, 0};
     auto mtick = [&](int i) { if (g_mtiming) tm[i] = mnow_ms(); };
     mtick(0); mtick(1); mtick(2);
     // record one device phase over all objects; on a sequence mismatch the objects run one by one instead
-    auto device_phase = [&](const std::function<int(int)>& body) -> int {
+    // (an error exit from a recording pass: ensure_bins has marked the bin indices of the recorded objects as built
+    // although no index kernel ran -- they are marked unbuilt again, the next matchFeatures rebuilds them)
+    auto unbuild = [&]() {
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 2; k++) part[i]->prev[k].nbins = part[i]->cur[k].nbins = 0;
+    };
+    auto device_phase_inner = [&](const std::function<int(int)>& body) -> int {
         rec.reset();
         t_rec = &rec;
         int rc = SVH_OK;
@@ -1437,6 +1468,15 @@ int32_t svh_matcher_match_features_batch(svh_matcher* const* ms, int32_t K, int3
         rec.synced();
         if (g_mtiming) t_wait += mnow_ms() - tw;
         return SVH_OK;
+    };
+    auto device_phase = [&](const std::function<int(int)>& body) -> int {
+        const int rc = device_phase_inner(body);
+        if (rc) {
+            t_rec = nullptr;
+            rec.reset();
+            unbuild();
+        }
+        return rc;
     };
     auto host_phase = [&](const std::function<int(int)>& body) -> int {
         t_in_batch = true;

@@ -29,6 +29,20 @@ Dims make_dims(const svh_elas_params& p, int32_t W, int32_t H);
 // CUs and launch gaps are paid once per group, not once per pair.
 constexpr int kMaxGroup = 32;
 
+// ---------------------------------------------------------------- fault injection (tests)
+// SVH_TEST_FAIL_AT=<kind>:<n>[:<count>] (environment, read once) or svh_test_fail_at("<kind>:<n>[:<count>]") at run
+// time: the n-th (1-based) HIP call of that kind in this process, counted from the moment the specification is set, is
+// NOT issued and reports an error instead, and so do the count-1 calls of the kind after it (count 0: every one from the
+// n-th on).  Kinds, as the engines' error macros see their calls:
+//   malloc  hipMalloc / hipHostMalloc              copy  hipMemcpy*Async / hipMemset*Async
+//   launch  the hipGetLastError() after a phase's launches      wait  stream / event waits (and queries in sleep-polls)
+// fi_filter() is what HIP_TRY / VO_TRY / MAP_TRY put in front of the call; when nothing is armed it costs one relaxed
+// load.  Boundary behaviour under a failure (tests/test_faults_gpu.py): the entry returns SVH_ERR_HIP, svh_last_error()
+// names the call, one line goes to stderr, the lane / object is usable for the next call, nothing leaks.
+bool fi_armed();
+bool fi_hit(const char* expr_text);
+void report_hip_failure(const char* entry);   // "svhip: <entry>: <last error>" on stderr, once per failing call
+
 // Per-pair header, uploaded with the support points and triangle lists after
 // the host stage.  Triangles of all pairs and both sides are packed in one
 // array; tri_end[] are running ends in (pair, side) order.
@@ -180,7 +194,7 @@ void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
 // (returns true: the checked maps are in *lr_out, launch_lr must be skipped); `write_raw` keeps
 // the raw maps in G.Draw as well (parity taps)
 bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
-                  const GroupDev& G, const DevMaps* lr_out, bool write_raw);
+                  const GroupDev& G, const DevMaps* lr_out, bool write_raw, const char** error);
 void launch_lr(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
                const GroupDev& G, const DevMaps& out);
 // post-processing of nside maps per pair, in place on `out`; scratch arrays are

@@ -21,13 +21,21 @@ using namespace svh;
 
 namespace svh {
 int fail(int code, const std::string& msg);   // elas_engine.cpp: records svh_last_error()
+bool fi_armed();                                    // elas_engine.cpp: fault injection (svh_internal.h)
+bool fi_hit(const char* expr_text);
+void report_hip_failure(const char* entry);
 }
 
+static int vo_hip_failed(const char* expr, bool injected, hipError_t e) {
+    const int rc = svh::fail(SVH_ERR_HIP, std::string(expr) + ": " + (injected ? "injected failure (SVH_TEST_FAIL_AT)" : hipGetErrorString(e)));
+    svh::report_hip_failure("VisualOdometry");
+    return rc;
+}
 #define VO_TRY(expr)                                                                             \
     do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return svh::fail(SVH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+        const bool inj_ = svh::fi_armed() && svh::fi_hit(#expr);   /* svh_internal.h: fault injection */ \
+        hipError_t e_ = inj_ ? hipErrorUnknown : (expr);                                         \
+        if (e_ != hipSuccess) return vo_hip_failed(#expr, inj_, e_);                             \
     } while (0)
 
 struct svh_vo {
@@ -301,7 +309,7 @@ int32_t svh_vo_process(svh_vo* v, const uint8_t* I1, const uint8_t* I2, const in
     svh::ActiveCaller active_;
     if (!v || !dims) return svh::fail(SVH_ERR_BAD_ARG, "null argument");
     const int32_t rc = svh_matcher_push_back(v->matcher, I1, I2, dims, replace);
-    if (rc < 0 && rc != SVH_ERR_BAD_ARG) return rc;   // bad dims: message printed, carry on like the reference
+    if (rc < 0 && rc != SVH_ERR_BAD_DIMS) return rc;   // (bad dimensions: message printed, frame ignored -- viso_stereo.cpp:41-68 goes on; a missing or pending prefetched frame IS an error)   // bad dims: message printed, carry on like the reference
     return process_after_push(v);
 }
 
@@ -334,7 +342,7 @@ static int32_t process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const*
         // K frames first -- which the hand-over of the next frame needs -- keeps the draw order)
         for (int i = 0; i < K; i++) {
             const int32_t rc = svh_matcher_push_back(ms[i], I1 ? I1[i] : nullptr, I2 ? I2[i] : nullptr, dims, replace);
-            if (rc < 0 && rc != SVH_ERR_BAD_ARG) return rc;
+            if (rc < 0 && rc != SVH_ERR_BAD_DIMS) return rc;   // (bad dimensions: message printed, frame ignored -- viso_stereo.cpp:41-68 goes on; a missing or pending prefetched frame IS an error)
         }
         if (N1) {
             const int32_t rc = svh_matcher_prefetch_batch(ms.data(), K, N1, N2, dims);
@@ -366,7 +374,7 @@ static int32_t process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const*
     std::vector<const double*> trs(K);
     for (int i = 0; i < K; i++) trs[i] = vs[i]->Tr;
     int32_t rc = svh_matcher_push_back_batch(ms.data(), K, I1, I2, dims, replace);
-    if (rc < 0 && rc != SVH_ERR_BAD_ARG) return rc;
+    if (rc < 0 && rc != SVH_ERR_BAD_DIMS) return rc;   // (bad dimensions: message printed, frame ignored -- viso_stereo.cpp:41-68 goes on; a missing or pending prefetched frame IS an error)
     if (N1) {   // the next frame goes out now: its packing, upload and features overlap everything below
         rc = svh_matcher_prefetch_batch(ms.data(), K, N1, N2, dims);
         if (rc < 0) return rc;
@@ -396,7 +404,7 @@ static int32_t process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const*
     for (int i = 0; i < K; i++)
         if (state[i] < 0) return state[i];
     if (timing) tt[3] = now();
-    BatchRec& rec = batch_recorder();
+    BatchRec& rec = batch_recorder(vs[0]->device);
     rec.reset();
     t_rec = &rec;
     for (int i = 0; i < K; i++)

@@ -66,6 +66,9 @@ hipError_t hipStreamQuery(hipStream_t s) {
 namespace svh {
 static thread_local std::string t_err;
 int fail(int code, const std::string& msg) { t_err = msg; return code; }
+bool fi_armed() { return false; }
+bool fi_hit(const char*) { return false; }
+void report_hip_failure(const char*) {}
 }  // namespace svh
 extern "C" const char* svh_last_error(void) { return svh::t_err.c_str(); }
 namespace svh {
