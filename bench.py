@@ -193,6 +193,23 @@ def matcher_bench(iters=40):
         rp, rm, rn = run(ref, 12)
         out["cpu_reference"] = {"pushBack_ms": rp, "matchFeatures_ms": rm, "frame_ms": rp + rm,
                                 "matches": rn, "cores": 1, "kind": "reference"}
+        # self-check of this leg (after the timing): the same three frames through a fresh object on each side,
+        # the match lists -- indices i1p, i2p, i1c, i2c and coordinates -- byte for byte
+        def lists(m):
+            seq = []
+            m.push_back(im[0], im[1])
+            for a, b in ((im[2], im[3]), (im[0], im[1])):
+                m.push_back(a, b)
+                m.match(2, staged=False)
+                seq.append(m.matches().tobytes())
+            return seq
+        d2 = Hh.ProductMatcher(prm)
+        d2.lib.svh_matcher_set_taps(C.c_void_p(d2.h), 0)
+        r2 = Hh.RefMatcher(prm)
+        r2.lib.ref_init(0)
+        out["matcher_matches_reference"] = lists(d2) == lists(r2)
+        out["self_check"] = "match lists of two quad matches (fresh objects, same frames) == the reference's Matcher " \
+                            "(oracle/_ref), byte for byte: indices and coordinates"
     return out
 
 
@@ -231,7 +248,29 @@ def vo_bench(iters=40):
     if Hh.have_ref_viso():
         rf, re_, rok, rnm, rni = run(Hh.RefVo(prm), 10)
         out["cpu_reference"] = {"frame_ms": rf, "estimateMotion_ms": re_, "frames_ok": rok, "matches": rnm,
-                                "inliers": rni, "cores": 1, "kind": "reference"}
+                                "inliers": rni, "cores": 1, "kind": "reference",
+                                "note": "timed over 10 frames (the device leg over %d): the counts above are those of "
+                                        "each side's LAST frame at a different position of the libc rand() stream; the "
+                                        "like-for-like comparison is vo_matches_reference" % iters}
+        # Self-check of this leg (after the timing): the SAME six frames through a fresh object on each side.  Both
+        # constructors call srand(0) (viso.cpp:36), so bucketing and RANSAC draw the same numbers: bucketed matches
+        # byte for byte, inlier indices identical, return values equal, motion within 1e-9.
+        def seq(cls):
+            vo = cls(prm)
+            res = []
+            for i in range(6):
+                a, b = (im[0], im[1]) if i % 2 == 0 else (im[2], im[3])
+                ok = vo.process(a, b)
+                res.append((ok, vo.matches().tobytes(), vo.inliers().tolist(), vo.motion().copy()))
+            return res
+        sd, sr = seq(Hh.ProductVo), seq(Hh.RefVo)
+        same = all(x[0] == y[0] and x[1] == y[1] and x[2] == y[2] and float(np.abs(x[3] - y[3]).max()) < 1e-9
+                   for x, y in zip(sd, sr))
+        out["vo_matches_reference"] = bool(same)
+        out["self_check"] = {"frames": 6, "inliers_last_frame": len(sd[-1][2]), "inliers_last_frame_reference": len(sr[-1][2]),
+                             "what": "return value, bucketed matches (bytes), inlier indices and Tr (1e-9) of six frames, "
+                                     "fresh objects on both sides (srand(0) in both constructors), == the reference's "
+                                     "VisualOdometryStereo (oracle/_ref)"}
     return out
 
 
@@ -411,6 +450,63 @@ def map_bench(iters=30):
     out["cpu_port"] = {"frame_ms": cms, "cores": 1, "kind": "port",
                        "note": "oracle/map_oracle.cpp, 5 frames (the device leg runs %d; parity is tests/test_map.py)" % iters}
     return out
+
+
+def settings_bench(S, torch, dev, batch=1536, steps=3):
+    """pairs/s for the parameter sets the APPLICATION uses, next to the headline's plain ROBOTICS preset:
+    stereomapper/stereothread.cpp:76-114 (ROBOTICS + support_texture = 30, postprocess_only_left, adaptive mean),
+    the same with the GUI's subsampling checkbox (maindialog.cpp:473 -> param.subsampling), and the MIDDLEBURY
+    preset (libelas/src/main.cpp, elas.h:118-146) on the reference's `cones` pair.  Device-resident batches through
+    the same entry as the headline; the first maps of each leg are compared with the reference's own output
+    (tests/golden where a golden exists, oracle/_ref otherwise)."""
+    import helpers as Hh
+    legs = []
+    u1, u2 = urban_inputs()
+    cl, cr = Hh.golden_pair("cones_640x480")
+    cones = (cl[None].repeat(4, 0), cr[None].repeat(4, 0))
+    for name, prm, (a1, a2), gold in (
+            ("stereomapper (ROBOTICS, support_texture 30)", Hh.robotics(support_texture=30), (u1, u2), (1, "urban2_stereomapper")),
+            ("stereomapper + subsampling", Hh.robotics(support_texture=30, subsampling=1), (u1, u2), None),
+            ("MIDDLEBURY on cones 640x480", Hh.middlebury(), cones, (0, "cones_middlebury"))):
+        h, w = a1.shape[1:]
+        dh, dw = (h // 2, w // 2) if prm.subsampling else (h, w)
+        idx = torch.arange(batch, device=dev) % len(a1)
+        dI1 = torch.from_numpy(np.ascontiguousarray(a1)).to(dev)[idx].contiguous()
+        dI2 = torch.from_numpy(np.ascontiguousarray(a2)).to(dev)[idx].contiguous()
+        dD1 = torch.empty((batch, dh, dw), dtype=torch.float32, device=dev)
+        dD2 = torch.empty((batch, dh, dw), dtype=torch.float32, device=dev)
+        e = S.Elas(prm)
+
+        def step():
+            st = e.process_batch_device(batch, dI1.data_ptr(), dI2.data_ptr(), w * h, dD1.data_ptr(), dD2.data_ptr(),
+                                        dw * dh * 4, w, h, w)
+            assert all(x == 0 for x in st), [x for x in st if x][:4]
+        step()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        # outputs against the reference
+        if gold is not None:
+            k, npz = gold
+            z = np.load(os.path.join(Hh.GOLDEN, npz + ".npz"))
+            same = bool(np.array_equal(dD1[k].cpu().numpy().ravel(), z["d1"]) and
+                        np.array_equal(dD2[k].cpu().numpy().ravel()[: z["d2"].size], z["d2"]))
+            how = "tests/golden/%s.npz" % npz
+        elif Hh.have_ref_elas():
+            R1, R2 = Hh.ref_elas_process(prm, a1[1], a2[1])
+            same = bool(np.array_equal(dD1[1].cpu().numpy(), R1) and np.array_equal(dD2[1].cpu().numpy(), R2))
+            how = "oracle/_ref Elas::process on the same pair"
+        else:
+            same, how = None, "no checker on this box"
+        legs.append({"setting": name, "image": "%dx%d" % (w, h), "pairs_per_s": steps * batch / dt,
+                     "pixels_per_s": steps * batch * w * h / dt, "pairs_per_step": batch,
+                     "outputs_match_reference": same, "checked_against": how,
+                     "d1_valid_fraction": round(float((dD1[:16] >= 0).float().mean().item()), 4)})
+        del dI1, dI2, dD1, dD2, e
+    return legs
 
 
 def _cpu_quota():
@@ -1169,6 +1265,8 @@ def main():
             out["visual_odometry"]["replicas"] = vo_replicas_bench()
             out["visual_odometry"]["replicas"]["as_processes"] = vo_replicas_processes()
             out["visual_odometry"]["lockstep"] = vo_lockstep_bench()
+            if args.workload == "kitti":
+                out["application_settings"] = settings_bench(S, torch, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(I1, I2, params, what, budget_s=args.cpu_budget,
                                                workers=int(avail) if args.workload == "kitti" else 0)

@@ -861,11 +861,30 @@ __device__ __forceinline__ void d_refine(svh_p_match* __restrict__ m,
 // __global__ form (one object: arguments by value) and a BATCHED form (K objects in lockstep, batch_rec.h:
 // arguments of job blockIdx.z read from a job table in device memory, grid = the largest job's).
 // ---------------------------------------------------------------------------
+// Pointers that arrive through a job table in memory have lost their address space: hipcc then reads and writes
+// through FLAT instructions (round 4: 913 of them in the lockstep kernels, 514 in k_refine_parabolic_b alone).  Every
+// buffer of a job is device (or device-mapped pinned host) memory: a round trip through address space 1 tells the
+// compiler so and the kernels use global_load / global_store like their single-object forms.
+template <class T>
+__device__ __forceinline__ T* gptr(T* p) {
+    return (T*)(__attribute__((address_space(1))) T*)p;
+}
+__device__ __forceinline__ FeatView gview(const FeatView& v) {
+    FeatView o;
+    o.rec = gptr(v.rec); o.count = gptr(v.count); o.off = gptr(v.off); o.ids = gptr(v.ids);
+    return o;
+}
+__device__ __forceinline__ SobelView gview(const SobelView& v) {
+    SobelView o = v;
+    o.du = gptr(v.du); o.dv = gptr(v.dv);
+    return o;
+}
+
 struct HalfJob { const uint8_t* I; int bpl; uint8_t* out; int hw, hh, hbpl; };
 __global__ __launch_bounds__(256) void k_half(HalfJob a) { d_half(a.I, a.bpl, a.out, a.hw, a.hh, a.hbpl, blockIdx.x, blockIdx.y); }
 __global__ __launch_bounds__(256) void k_half_b(const HalfJob* J) {
-    const HalfJob a = J[blockIdx.z];
-    d_half(a.I, a.bpl, a.out, a.hw, a.hh, a.hbpl, blockIdx.x, blockIdx.y);
+    const HalfJob a = gptr(J)[blockIdx.z];
+    d_half(gptr(a.I), a.bpl, gptr(a.out), a.hw, a.hh, a.hbpl, blockIdx.x, blockIdx.y);
 }
 
 struct FiltersJob { const uint8_t* I; int w, h, bpl; uint8_t *du, *dv; int16_t *f1, *f2; };
@@ -875,8 +894,8 @@ __global__ __launch_bounds__(256) void k_filters(FiltersJob a) {
 }
 template <bool kFeatures>
 __global__ __launch_bounds__(256) void k_filters_b(const FiltersJob* J) {
-    const FiltersJob a = J[blockIdx.z];
-    d_filters<kFeatures>(a.I, a.w, a.h, a.bpl, a.du, a.dv, a.f1, a.f2, blockIdx.x, blockIdx.y);
+    const FiltersJob a = gptr(J)[blockIdx.z];
+    d_filters<kFeatures>(gptr(a.I), a.w, a.h, a.bpl, gptr(a.du), gptr(a.dv), gptr(a.f1), gptr(a.f2), blockIdx.x, blockIdx.y);
 }
 
 struct NmsJob { const int16_t *f1, *f2; int w, h, bpl, n, tau, margin, ni, nj; int4* slots; int32_t* flags; };
@@ -886,15 +905,15 @@ __global__ __launch_bounds__(256) void k_nms(NmsJob a) {
 }
 template <int kG>
 __global__ __launch_bounds__(256) void k_nms_b(const NmsJob* J) {
-    const NmsJob a = J[blockIdx.z];
-    d_nms<kG>(a.f1, a.f2, a.w, a.h, a.bpl, a.n, a.tau, a.margin, a.ni, a.nj, a.slots, a.flags, blockIdx.x);
+    const NmsJob a = gptr(J)[blockIdx.z];
+    d_nms<kG>(gptr(a.f1), gptr(a.f2), a.w, a.h, a.bpl, a.n, a.tau, a.margin, a.ni, a.nj, gptr(a.slots), gptr(a.flags), blockIdx.x);
 }
 
 struct CompactSlotsJob { const int32_t* flags; int nslots; int32_t *order, *count; };
 __global__ __launch_bounds__(1024) void k_compact_slots(CompactSlotsJob a) { d_compact_slots(a.flags, a.nslots, a.order, a.count, 0u); }
 __global__ __launch_bounds__(1024) void k_compact_slots_b(const CompactSlotsJob* J) {
-    const CompactSlotsJob a = J[blockIdx.z];
-    d_compact_slots(a.flags, a.nslots, a.order, a.count, 0u);
+    const CompactSlotsJob a = gptr(J)[blockIdx.z];
+    d_compact_slots(gptr(a.flags), a.nslots, gptr(a.order), gptr(a.count), 0u);
 }
 
 struct FeatureRecordsJob { const int4* slots; const int32_t *order, *count; const uint8_t *du, *dv; int bpl, scale; int32_t* table; };
@@ -902,8 +921,8 @@ __global__ __launch_bounds__(256) void k_feature_records(FeatureRecordsJob a) {
     d_feature_records(a.slots, a.order, a.count, a.du, a.dv, a.bpl, a.scale, a.table, blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_feature_records_b(const FeatureRecordsJob* J) {
-    const FeatureRecordsJob a = J[blockIdx.z];
-    d_feature_records(a.slots, a.order, a.count, a.du, a.dv, a.bpl, a.scale, a.table, blockIdx.x);
+    const FeatureRecordsJob a = gptr(J)[blockIdx.z];
+    d_feature_records(gptr(a.slots), gptr(a.order), gptr(a.count), gptr(a.du), gptr(a.dv), a.bpl, a.scale, gptr(a.table), blockIdx.x);
 }
 
 struct BinIndexJob { BinJobs J; int njobs, ub, vb, binsize; };
@@ -926,22 +945,23 @@ __global__ __launch_bounds__(128) void k_match(MatchJob a) {
     d_match(a.P, a.m1p, a.m2p, a.m1c, a.m2c, a.ranges, a.use_prior, a.out, a.flags, a.pixel_owner, blockIdx.x);
 }
 __global__ __launch_bounds__(128) void k_match_b(const MatchJob* J) {
-    const MatchJob& a = J[blockIdx.z];
-    d_match(a.P, a.m1p, a.m2p, a.m1c, a.m2c, a.ranges, a.use_prior, a.out, a.flags, a.pixel_owner, blockIdx.x);
+    const MatchJob& a = gptr(J)[blockIdx.z];
+    d_match(a.P, gview(a.m1p), gview(a.m2p), gview(a.m1c), gview(a.m2c), gptr(a.ranges), a.use_prior, gptr(a.out), gptr(a.flags),
+            gptr(a.pixel_owner), blockIdx.x);
 }
 
 struct DedupeJob { const int32_t* n; int width; const svh_p_match* m; int32_t* flags; const int32_t* pixel_owner; };
 __global__ __launch_bounds__(256) void k_match_dedupe(DedupeJob a) { d_match_dedupe(a.n, a.width, a.m, a.flags, a.pixel_owner, blockIdx.x); }
 __global__ __launch_bounds__(256) void k_match_dedupe_b(const DedupeJob* J) {
-    const DedupeJob a = J[blockIdx.z];
-    d_match_dedupe(a.n, a.width, a.m, a.flags, a.pixel_owner, blockIdx.x);
+    const DedupeJob a = gptr(J)[blockIdx.z];
+    d_match_dedupe(gptr(a.n), a.width, gptr(a.m), gptr(a.flags), gptr(a.pixel_owner), blockIdx.x);
 }
 
 struct CompactMatchesJob { const svh_p_match* in; const int32_t *flags, *nslots; svh_p_match* out; int32_t* count; };
 __global__ __launch_bounds__(1024) void k_compact_matches(CompactMatchesJob a) { d_compact_matches(a.in, a.flags, a.nslots, a.out, a.count, 0u); }
 __global__ __launch_bounds__(1024) void k_compact_matches_b(const CompactMatchesJob* J) {
-    const CompactMatchesJob a = J[blockIdx.z];
-    d_compact_matches(a.in, a.flags, a.nslots, a.out, a.count, 0u);
+    const CompactMatchesJob a = gptr(J)[blockIdx.z];
+    d_compact_matches(gptr(a.in), gptr(a.flags), gptr(a.nslots), gptr(a.out), gptr(a.count), 0u);
 }
 
 struct RefineJob { svh_p_match* m; const int32_t* count; int method, margin; SobelView s1p, s2p, s1c, s2c; int32_t* flags; };
@@ -949,15 +969,16 @@ __global__ __launch_bounds__(256) void k_refine_group(RefineJob a) {
     d_refine_group(a.m, a.count, a.method, a.margin, a.s1p, a.s2p, a.s1c, a.s2c, blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_refine_group_b(const RefineJob* J) {
-    const RefineJob& a = J[blockIdx.z];
-    d_refine_group(a.m, a.count, a.method, a.margin, a.s1p, a.s2p, a.s1c, a.s2c, blockIdx.x);
+    const RefineJob& a = gptr(J)[blockIdx.z];
+    d_refine_group(gptr(a.m), gptr(a.count), a.method, a.margin, gview(a.s1p), gview(a.s2p), gview(a.s1c), gview(a.s2c), blockIdx.x);
 }
 __global__ __launch_bounds__(128) void k_refine_parabolic(RefineJob a) {
     d_refine<true>(a.m, a.count, a.method, a.margin, a.s1p, a.s2p, a.s1c, a.s2c, a.flags, blockIdx.x);
 }
 __global__ __launch_bounds__(128) void k_refine_parabolic_b(const RefineJob* J) {
-    const RefineJob& a = J[blockIdx.z];
-    d_refine<true>(a.m, a.count, a.method, a.margin, a.s1p, a.s2p, a.s1c, a.s2c, a.flags, blockIdx.x);
+    const RefineJob& a = gptr(J)[blockIdx.z];
+    d_refine<true>(gptr(a.m), gptr(a.count), a.method, a.margin, gview(a.s1p), gview(a.s2p), gview(a.s1c), gview(a.s2c), gptr(a.flags),
+                   blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -973,22 +994,25 @@ __global__ __launch_bounds__(256) void k_upload(UploadJob a) {
     if (i < a.n16) a.dev[i] = a.host[i];
 }
 __global__ __launch_bounds__(256) void k_upload_b(const UploadJob* J) {
-    const UploadJob a = J[blockIdx.z];
+    const UploadJob a = gptr(J)[blockIdx.z];
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < a.n16) a.dev[i] = a.host[i];
+    if (i < a.n16) gptr(a.dev)[i] = gptr(a.host)[i];
 }
 struct Copy4Job { uint32_t* dst; const uint32_t* src; size_t n4; };
 __global__ __launch_bounds__(256) void k_copy4(Copy4Job a) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) a.dst[i] = a.src[i];
 }
 __global__ __launch_bounds__(256) void k_copy4_b(const Copy4Job* J) {
-    const Copy4Job a = J[blockIdx.z];
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) a.dst[i] = a.src[i];
+    const Copy4Job a = gptr(J)[blockIdx.z];
+    uint32_t* const dst = gptr(a.dst);
+    const uint32_t* const src = gptr(a.src);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 struct Fill4Job { uint32_t* dst; uint32_t value; size_t n4; };
 __global__ __launch_bounds__(256) void k_fill4_b(const Fill4Job* J) {
-    const Fill4Job a = J[blockIdx.z];
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) a.dst[i] = a.value;
+    const Fill4Job a = gptr(J)[blockIdx.z];
+    uint32_t* const dst = gptr(a.dst);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) dst[i] = a.value;
 }
 
 // batched launch entries (BatchLaunchFn): jobs = device copy of the table, grid (gx, gy, njobs)
