@@ -61,6 +61,20 @@ ALG_BYTES_PER_PIXEL = {
 }
 
 
+# Compulsory HBM bytes per pixel of the kernels AS DESIGNED since round 4 (descriptors assembled on the fly from
+# the two Sobel planes: nothing ever stores the 16-byte descriptors): what a launch must move even with perfect
+# caching.  `roofline.achieved / frac` are quoted on THESE bytes -- a kernel cannot move more than it has to -- and the
+# SURVEY 8(d) staged-model figure (bytes a stage-by-stage pipeline with stored descriptors would move) keeps its own
+# key, `staged_model_8d`.
+#   k_match       4 N  du + dv planes of both images (each row is fetched by the blocks of 5 + 3 neighbouring image
+#                      rows: L2 traffic, not compulsory) + 8 N owner words of both maps + 8 N D1 + D2 after the fused
+#                      L/R check + 0.6 N candidate records and triangle planes
+#   k_support     4 N  the planes; the 37 KB lattice out is noise
+#   k_descriptor  6 N  (k_sobel_planes) 2 N image bytes in, 4 N plane bytes out
+#   the post-filters move what the staged model says (their inputs and outputs are the maps themselves)
+ALG_BYTES_DESIGN_PER_PIXEL = dict(ALG_BYTES_PER_PIXEL, k_match=20.6, k_support=4.0, k_descriptor=6.0)
+
+
 def make_inputs(batch, seed0=1000):
     import helpers as Hh
     I1 = np.empty((batch, H, W), np.uint8)
@@ -564,8 +578,8 @@ def load_pmc(build):
     """the committed rocprofv3 --pmc summaries, only if they were taken on the library that is
     loaded now (tools/pmc_*.py stamp them with svh_version(), which carries the source hash)"""
     import glob
-    out = {"traffic": None, "issue": None, "notes": []}
-    for key, pat in (("traffic", "*_pmc_traffic.json"), ("issue", "*_pmc_issue.json")):
+    out = {"traffic": None, "issue": None, "devcount": None, "notes": []}
+    for key, pat in (("traffic", "*_pmc_traffic.json"), ("issue", "*_pmc_issue.json"), ("devcount", "*_devcount.json")):
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
         if not files:
             continue
@@ -706,6 +720,18 @@ def main():
         raise SystemExit("bench.py: %d ranks but %d GPU(s): RCCL needs one GPU per rank "
                          "(--dist-backend gloo lets ranks share a GPU)" % (world, ndev))
     device_index = local_rank % ndev
+    # preflight (SCALE readiness): who shares a device, and how many hardware queues the ranks on it ask for.  The
+    # ROCm runtime gives every process GPU_MAX_HW_QUEUES queues on a device; ranks that share one (gloo dry runs on a
+    # 1-GPU box) multiply that.  RCCL with two ranks on one device is refused above.
+    ranks_on_my_device = len([r for r in range(world) if r % ndev == device_index]) if world > 1 else 1
+    hwq = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    preflight = {"ranks": world, "gpus_visible": ndev, "ranks_on_this_device": ranks_on_my_device,
+                 "hw_queues_per_rank": hwq, "hw_queues_requested_on_this_device": hwq * ranks_on_my_device}
+    if rank == 0 and world > 1:
+        print("bench.py preflight: %d ranks on %d visible GPU(s), backend %s: rank 0 -> device %d shared by %d rank(s); "
+              "GPU_MAX_HW_QUEUES=%d per rank = %d hardware queues requested on that device"
+              % (world, ndev, args.dist_backend, device_index, ranks_on_my_device, hwq, hwq * ranks_on_my_device),
+              file=sys.stderr, flush=True)
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where collectives run
@@ -954,7 +980,8 @@ def main():
             ms, cnt = prof[dom]
             avg_s = ms / cnt / 1e3
             gl = min(group, B)                       # pairs one launch covers
-            abytes = ALG_BYTES_PER_PIXEL.get(dom, 8.0) * N_PIX * gl
+            sbytes = ALG_BYTES_PER_PIXEL.get(dom, 8.0) * N_PIX * gl              # SURVEY 8(d) staged model
+            abytes = ALG_BYTES_DESIGN_PER_PIXEL.get(dom, 8.0) * N_PIX * gl       # compulsory bytes of the design
             in_run = abytes / avg_s / 1e9
             # isolated probe: ONE group on ONE worker -> the kernels of the group run one after the other
             S.set_lanes(1)
@@ -980,11 +1007,18 @@ def main():
             norm = region_bytes / (share * elapsed_local) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "definition": "algorithmic bytes of one launch (SURVEY 8d: %.1f B/pixel x %d pixels x %d pairs) / "
-                                      "duration of that launch alone on the device, HIP events on its stream, "
-                                      "average of %d launches in a probe after the timed region"
-                                      % (ALG_BYTES_PER_PIXEL.get(dom, 8.0), N_PIX, gl, probe_reps),
-                        "avg_launch_us": 1e6 * iso_s, "alg_bytes_per_launch": abytes, "pairs_per_launch": gl,
+                        "definition": "compulsory HBM bytes of one launch AS THE KERNEL IS DESIGNED (descriptors on the "
+                                      "fly: %.1f B/pixel x %d pixels x %d pairs, bench.py ALG_BYTES_DESIGN_PER_PIXEL) / "
+                                      "duration of that launch alone on the device, HIP events on its stream, average "
+                                      "of %d launches in a probe after the timed region.  The SURVEY 8(d) staged-model "
+                                      "figure is under staged_model_8d, counter bytes under traffic"
+                                      % (ALG_BYTES_DESIGN_PER_PIXEL.get(dom, 8.0), N_PIX, gl, probe_reps),
+                        "avg_launch_us": 1e6 * iso_s, "alg_bytes_per_launch": abytes, "alg_bytes_design": abytes,
+                        "pairs_per_launch": gl,
+                        "staged_model_8d": {"alg_bytes_per_launch": sbytes, "bytes_per_pixel": ALG_BYTES_PER_PIXEL.get(dom, 8.0),
+                                            "achieved": sbytes / iso_s / 1e9, "frac": sbytes / iso_s / 1e9 / HBM_PEAK_GBS,
+                                            "note": "round 4's headline definition (72 B/pixel for the dense matcher: stored "
+                                                    "descriptors read per map); the kernel no longer moves these bytes"},
                         "isolated_kernels_us": {k: round(v, 2) for k, v in sorted(iso_us.items())},
                         "isolated_sum_us": round(sum(iso_us.values()), 1),
                         "in_run": {"achieved": in_run, "frac": in_run / HBM_PEAK_GBS, "avg_launch_us": 1e6 * avg_s,
@@ -995,13 +1029,20 @@ def main():
                                            % (tot_ms / 1e3 / max(elapsed_local / args.steps, 1e-9))},
                         "modelled_share_normalised": {
                             "achieved": norm, "frac": norm / HBM_PEAK_GBS, "machine_share": round(share, 4),
-                            "definition": "MODEL (round 3's headline, kept for continuity): algorithmic bytes of all "
+                            "definition": "MODEL (round 3's headline, kept for continuity): staged-model bytes of all "
                                           "launches in the timed region / (kernel's share of summed kernel time x wall)"},
                         "kernels_us_probe_step": {k: round(1e3 * v[0] / v[1], 2)
                                                   for k, v in sorted(prof_all.items())}}
             if pmc["notes"]:
                 roofline["pmc_notes"] = pmc["notes"]
             tr, iss = pmc["traffic"], pmc["issue"]
+            if pmc["devcount"] and args.workload == "kitti":
+                # counters of the pipelined steady state itself (nothing serialised): what binds UNDER OVERLAP
+                dcd = pmc["devcount"]["derived"]
+                roofline["overlapped_counters"] = dict(dcd, source="profiles/%s: rocprofiler-sdk device counting service over "
+                                                                   "the timed region of this same command (tools/devcount.cpp, "
+                                                                   "bench.py --devcount), build-stamped" % pmc["devcount_file"],
+                                                       pairs_per_s_of_that_run=round(pmc["devcount"]["runs"][0]["pairs_per_s"]))
             alias_back = {"k_support": "k_support_lds", "k_match": "k_match_list", "k_descriptor": "k_descriptor_stream"}
             alias = {v: k for k, v in alias_back.items()}
             alias["k_match_keyed"] = "k_match"
@@ -1088,6 +1129,19 @@ def main():
                                                       "v_sad_u8 / min / max / VOP3 / DPP / compares 4.2-4.5 cycles, "
                                                       "add / and / or / xor / fp32 fma 2.4-2.6) -- a model, not a "
                                                       "busy counter" % pmc["issue_file"]}
+                    if roofline.get("overlapped_counters"):
+                        oc = roofline["overlapped_counters"]
+                        roofline["valu_issue"]["measured_overlapped"] = {
+                            "valu_active": oc.get("valu_active"), "valu_per_pair": oc.get("valu_per_pair"),
+                            "waves_per_simd": oc.get("waves_per_simd"), "parked": oc.get("parked"),
+                            "lds_busy": oc.get("lds_busy"), "hbm_frac_of_8TBps": oc.get("hbm_frac_of_8TBps"),
+                            "note": "busy counters of the steady state (SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles): the vector "
+                                    "ALUs are the busiest resource of the pipeline; what is left is wave time parked on "
+                                    "memory / LDS / barriers that the resident waves do not cover"}
+                        roofline["bound"] = "valu_issue"
+                        roofline["bound_evidence"] = dict(roofline.get("bound_evidence") or {},
+                                                          overlapped_valu_active=oc.get("valu_active"),
+                                                          overlapped_hbm_frac=oc.get("hbm_frac_of_8TBps"))
                 roofline["isolated_kernels_hbm"] = {"source": "profiles/%s + %s (rocprofv3 --pmc, kernels "
                                                               "serialised, KITTI workload)"
                                                               % (pmc["traffic_file"], pmc["issue_file"]),
@@ -1178,7 +1232,7 @@ def main():
                        "dist_backend": args.dist_backend if world > 1 else None,
                        "gpus_visible": ndev, "build": build, "stage": args.stage, "api": api,
                        "stream_depth_pairs": depth if api == "stream" else None,
-                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "preflight": preflight,
                        "stage_groups_device_handed_back": list(S.stage_stats()),
                        "d1_valid_fraction": round(valid, 4)},
             "ranks": ranks,

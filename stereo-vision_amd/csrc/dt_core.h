@@ -465,245 +465,6 @@ DT_FN void dt_merge(const M& m, unsigned* farleft_io, unsigned innerleft, unsign
     *farright_io = farright;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The same merge on a PAIR of lanes.  A wave64 instruction costs its four cycles whether one lane or all of them
-// are active, and a single wave issues one instruction per four cycles whatever it is: a merge on one lane is
-// bound by its instruction count (~270 per seam step).  Most of a step is the same code for the left and for the
-// right hull with next / prev and org / dest exchanged -- fetching the triangle behind the candidate edge, the
-// "is this hull done" orientation test, the in-circle test of the flip loop, the flips themselves -- and the two
-// hulls are disjoint record ranges.  So lane 0 of a pair takes the LEFT hull and lane 1 the RIGHT hull: the
-// mirrored code runs once for both, the flips of the two sides run side by side, and only the choice of the new
-// seam edge and the edge itself are one lane's work; the other lane hears of the new base handle and the new lower
-// vertex through a lane swap.  Everything outside the seam walk (rotations of the extreme handles, lower tangent,
-// the two bounding triangles) is executed by both lanes identically (same reads, the same values stored twice).
-//
-// One source for the kernel and for the CPU check.  PX supplies the pair:
-//   Var<T>         one value per side (device: this lane's register; host: both);
-//   par(f)         f(side) on each side (device: this lane's side; host: side 0, then side 1);
-//   other(x, s)    the other side's x.  Phases never read other(x) of an x they write: the host's sequential
-//                  order then equals the lock step of the device;
-//   both(a)        a on both sides (the pair's common branch condition).
-struct HostPair {
-    template <class T> struct Var {
-        T v[2];
-        T& operator[](int s) { return v[s]; }
-        const T& operator[](int s) const { return v[s]; }
-    };
-    template <class F> static void par(F f) { f(0); f(1); }
-    template <class T> static T other(const Var<T>& x, int s) { return x.v[1 - s]; }
-    static bool both(const Var<bool>& a) { return a.v[0] && a.v[1]; }
-    // the pair's state as the code after the walk needs it (device: this lane's values and the swapped ones)
-    static void fold(const Var<unsigned>& cand, const Var<unsigned>&, const Var<Vtx>& lo_own, const Var<Vtx>&,
-                     const Var<unsigned>& base, unsigned* lcand, unsigned* rcand, Vtx* lowerleft, Vtx* lowerright,
-                     unsigned* basef) {
-        *lcand = cand.v[0]; *rcand = cand.v[1];
-        *lowerleft = lo_own.v[0]; *lowerright = lo_own.v[1];
-        *basef = base.v[0];
-    }
-};
-
-// mirrored handle steps: side 0 (left hull) walks with next, side 1 (right hull) with prev
-DT_FN unsigned hfwd(unsigned h, int s) { return s ? hprev(h) : hnext(h); }
-DT_FN unsigned hbwd(unsigned h, int s) { return s ? hnext(h) : hprev(h); }
-template <class M> DT_FN void set_a(const M& m, unsigned h, int s, const Vtx& v) { m.set_corner(h & ~3u, s ? p2(h & 3) : p1(h & 3), v); }   // org (left) / dest (right)
-template <class M> DT_FN void set_b(const M& m, unsigned h, int s, const Vtx& v) { m.set_corner(h & ~3u, s ? p1(h & 3) : p2(h & 3), v); }   // dest (left) / org (right)
-
-template <bool kShort, class PX, class M>
-DT_FN void dt_merge2(const M& m, unsigned* farleft_io, unsigned innerleft, unsigned innerright, unsigned* farright_io,
-                     int axis, int ctr) {
-    // ---- up to the first seam edge: as dt_merge, by both lanes
-    unsigned farleft = *farleft_io, farright = *farright_io;
-    Rec RIL = m.load(innerleft), RIR = m.load(innerright);
-    Rec RFL = m.load(farleft), RFR = m.load(farright);
-    Vtx il_dest = r_dest(RIL, innerleft), il_apex = r_apex(RIL, innerleft);
-    Vtx ir_org = r_org(RIR, innerright), ir_apex = r_apex(RIR, innerright);
-    if (axis == 1) {
-        Vtx fl_pt = r_org(RFL, farleft), fl_apex = r_apex(RFL, farleft);
-        Vtx fr_pt = r_dest(RFR, farright);
-        unsigned chkB = r_sym(RIL, innerleft), chkD = r_sym(RFR, farright);
-        Rec RB = m.load(chkB), RD = m.load(chkD);
-        Vtx cvB = r_apex(RB, chkB), cvD = r_apex(RD, chkD);
-        for (;;) {
-            const bool gA = vy(fl_apex) < vy(fl_pt);
-            const bool gB = vy(cvB) > vy(il_dest);
-            const bool gC = vy(ir_apex) < vy(ir_org);
-            const bool gD = vy(cvD) > vy(fr_pt);
-            if (!(gA | gB | gC | gD)) break;
-            const unsigned hA = gA ? rnbr(RFL, p1(farleft & 3)) : farleft;
-            const unsigned nilB = gB ? hnext(chkB) : innerleft;
-            const unsigned hB = gB ? rnbr(RB, nilB & 3) : chkB;
-            const unsigned hC = gC ? rnbr(RIR, p1(innerright & 3)) : innerright;
-            const unsigned nfrD = gD ? hnext(chkD) : farright;
-            const unsigned hD = gD ? rnbr(RD, nfrD & 3) : chkD;
-            const Rec nA = m.load(hA), nB = m.load(hB), nC = m.load(hC), nD = m.load(hD);
-            if (gA) { farleft = hA; fl_pt = fl_apex; RFL = nA; fl_apex = r_apex(RFL, farleft); }
-            if (gB) { innerleft = nilB; RIL = RB; il_apex = il_dest; il_dest = cvB; chkB = hB; RB = nB; cvB = r_apex(RB, chkB); }
-            if (gC) { innerright = hC; ir_org = ir_apex; RIR = nC; ir_apex = r_apex(RIR, innerright); }
-            if (gD) { farright = nfrD; RFR = RD; fr_pt = cvD; chkD = hD; RD = nD; cvD = r_apex(RD, chkD); }
-        }
-    }
-    for (;;) {
-        const bool gL = ccw(il_dest, il_apex, ir_org) > 0;
-        const Vtx nd = gL ? il_apex : il_dest;
-        const bool gR = ccw(ir_apex, ir_org, nd) > 0;
-        if (!(gL | gR)) break;
-        const unsigned hL = gL ? rnbr(RIL, p2(innerleft & 3)) : innerleft;
-        const unsigned hR = gR ? rnbr(RIR, p1(innerright & 3)) : innerright;
-        const Rec nL = m.load(hL), nR = m.load(hR);
-        if (gL) { innerleft = hL; il_dest = il_apex; RIL = nL; il_apex = r_apex(RIL, innerleft); }
-        if (gR) { innerright = hR; ir_org = ir_apex; RIR = nR; ir_apex = r_apex(RIR, innerright); }
-    }
-    const unsigned lcand0 = r_sym(RIL, innerleft), rcand0 = r_sym(RIR, innerright);
-    unsigned base0 = m.make_rec(ctr);
-    m.bond(base0, innerleft);
-    base0 = hnext(base0);
-    m.bond(base0, innerright);
-    base0 = hnext(base0);
-    set_org(m, base0, ir_org);
-    set_dest(m, base0, il_dest);
-    if (il_dest.id == r_org(RFL, farleft).id) farleft = hnext(base0);
-    if (ir_org.id == r_dest(RFR, farright).id) farright = hprev(base0);
-    const Rec RL0 = m.load(lcand0), RR0 = m.load(rcand0);
-
-    // ---- the seam walk, one hull per side
-    typename PX::template Var<unsigned> cand, nx, base;
-    typename PX::template Var<Rec> R, N;
-    typename PX::template Var<Vtx> upper, nap, lo_own, lo_oth, upper_o;
-    typename PX::template Var<bool> have, r_ok, done, done_o, mine;
-    PX::par([&](int s) {
-        cand[s] = s ? rcand0 : lcand0;
-        R[s] = s ? RR0 : RL0;
-        upper[s] = r_apex(R[s], cand[s]);
-        lo_own[s] = s ? ir_org : il_dest;        // lowerleft on the left side, lowerright on the right side
-        lo_oth[s] = s ? il_dest : ir_org;
-        base[s] = base0;
-        nx[s] = 0;
-        nap[s] = ghost();
-        have[s] = false;
-        r_ok[s] = true;
-    });
-    for (;;) {
-        PX::par([&](int s) {
-            if (!have[s]) nx[s] = rnbr(R[s], s ? p1(cand[s] & 3) : p2(cand[s] & 3));   // sym(hbwd(cand))
-            N[s] = m.load(nx[s]);
-            if (!have[s]) nap[s] = r_apex(N[s], nx[s]);
-            have[s] = true;
-            const Vtx ll = s ? lo_oth[s] : lo_own[s], lr = s ? lo_own[s] : lo_oth[s];
-            done[s] = ccw(upper[s], ll, lr) <= 0;
-        });
-        PX::par([&](int s) { done_o[s] = PX::other(done, s); });
-        {
-            typename PX::template Var<bool> fin;
-            PX::par([&](int s) { fin[s] = done[s] && done_o[s]; });
-            if (PX::both(fin)) break;
-        }
-        PX::par([&](int s) {
-            if (done[s] || nap[s].id < 0) return;
-            const Vtx ll = s ? lo_oth[s] : lo_own[s], lr = s ? lo_own[s] : lo_oth[s];
-            bool bad = incircle(ll, lr, upper[s], nap[s]) > 0;
-            while (bad) {
-                r_ok[s] = false;
-                unsigned q = hfwd(nx[s], s);
-                const unsigned topc = r_sym(N[s], q);
-                q = hfwd(q, s);
-                const unsigned sidec = r_sym(N[s], q);
-                m.bond(q, topc);
-                m.bond(cand[s], sidec);
-                cand[s] = hfwd(cand[s], s);
-                const unsigned outerc = m.sym(cand[s]);
-                Rec NS = m.load(sidec);
-                q = hbwd(q, s);
-                m.bond(q, outerc);
-                set_a(m, cand[s], s, lo_own[s]);      // org <- lowerleft / dest <- lowerright
-                set_b(m, cand[s], s, ghost());
-                set_apex(m, cand[s], nap[s]);
-                set_a(m, q, s, ghost());
-                set_b(m, q, s, upper[s]);
-                set_apex(m, q, nap[s]);
-                if (same_rec(sidec, outerc) || same_rec(sidec, cand[s]) || same_rec(sidec, q)) NS = m.load(sidec);
-                upper[s] = nap[s];
-                nx[s] = sidec;
-                N[s] = NS;
-                nap[s] = r_apex(N[s], nx[s]);
-                bad = nap[s].id >= 0 && incircle(ll, lr, upper[s], nap[s]) > 0;
-            }
-        });
-        PX::par([&](int s) { upper_o[s] = PX::other(upper, s); });
-        PX::par([&](int s) {
-            const Vtx ll = s ? lo_oth[s] : lo_own[s], lr = s ? lo_own[s] : lo_oth[s];
-            const Vtx ul = s ? upper_o[s] : upper[s], ur = s ? upper[s] : upper_o[s];
-            const bool leftdone = s ? done_o[s] : done[s], rightdone = s ? done[s] : done_o[s];
-            const bool go_right = leftdone || (!rightdone && incircle(ul, ll, lr, ur) > 0);
-            mine[s] = go_right == (s == 1);
-            if (!mine[s]) return;
-            // new seam edge on this side: lowerleft -> upperright (right) / upperleft -> lowerright (left)
-            m.bond(base[s], cand[s]);
-            const unsigned nb = hfwd(cand[s], s);
-            set_a(m, nb, s, lo_oth[s]);              // right: dest <- lowerleft; left: org <- lowerright
-            lo_own[s] = upper[s];
-            unsigned nc;
-            if (kShort && r_ok[s] && !same_rec(base[s], cand[s])) {
-                nc = rnbr(R[s], nb & 3);
-                DT_CHECK_SHORTCUT(nc == m.sym(nb));
-            } else {
-                nc = m.sym(nb);
-            }
-            base[s] = nb;
-            cand[s] = nc;
-            R[s] = m.load(nc);
-            r_ok[s] = true;
-            upper[s] = r_apex(R[s], nc);
-            have[s] = false;
-        });
-        {
-            typename PX::template Var<unsigned> base_o;
-            typename PX::template Var<Vtx> low_o;
-            PX::par([&](int s) { base_o[s] = PX::other(base, s); low_o[s] = PX::other(lo_own, s); });
-            PX::par([&](int s) {
-                if (!mine[s]) {
-                    base[s] = base_o[s];
-                    lo_oth[s] = low_o[s];
-                }
-            });
-        }
-    }
-    // ---- both hulls are done: the top bounding triangle, by both lanes
-    typename PX::template Var<unsigned> cand_o;
-    PX::par([&](int s) { cand_o[s] = PX::other(cand, s); });
-    unsigned lcand, rcand, basef;
-    Vtx lowerleft, lowerright;
-    PX::fold(cand, cand_o, lo_own, lo_oth, base, &lcand, &rcand, &lowerleft, &lowerright, &basef);
-    unsigned top = m.make_rec(ctr + 1);
-    set_org(m, top, lowerleft);
-    set_dest(m, top, lowerright);
-    m.bond(top, basef);
-    top = hnext(top);
-    m.bond(top, rcand);
-    top = hnext(top);
-    m.bond(top, lcand);
-    if (axis == 1) {
-        Rec RF = m.load(farleft), RG = m.load(farright);
-        Vtx fl_pt = r_org(RF, farleft);
-        Vtx fr_pt = r_dest(RG, farright), fr_apex = r_apex(RG, farright);
-        unsigned chk = r_sym(RF, farleft);
-        Rec RC = m.load(chk);
-        Vtx cv = r_apex(RC, chk);
-        for (;;) {
-            const bool gE = vx(cv) < vx(fl_pt);
-            const bool gF = vx(fr_apex) > vx(fr_pt);
-            if (!(gE | gF)) break;
-            const unsigned nfl = gE ? hprev(chk) : farleft;
-            const unsigned hE = gE ? rnbr(RC, nfl & 3) : chk;
-            const unsigned hF = gF ? rnbr(RG, p2(farright & 3)) : farright;
-            const Rec nE = m.load(hE), nF = m.load(hF);
-            if (gE) { farleft = nfl; RF = RC; fl_pt = cv; chk = hE; RC = nE; cv = r_apex(RC, chk); }
-            if (gF) { farright = hF; fr_pt = fr_apex; RG = nF; fr_apex = r_apex(RG, farright); }
-        }
-    }
-    *farleft_io = farleft;
-    *farright_io = farright;
-}
-
 // node (s, n) reached from the root (0, m) along the top `depth` bits of `path` (MSB first);
 // returns false when a leaf is met before `depth`.  base = first record of the node.
 DT_FN bool dt_descend(int m, int depth, unsigned path, int* s, int* n, int* base) {
@@ -748,25 +509,6 @@ DT_FN void dt_node(const M& mesh, int m, int d, unsigned j, const int* order, co
         a = cfl[s];
         b = cfr[s + h];
         dt_merge<kShort>(mesh, &a, cfr[s], cfl[s + h], &b, d & 1, base + 2 * n - 4);
-    }
-    fl[s] = a;
-    fr[s] = b;
-}
-
-// the same on a pair of lanes (both call it with the same arguments; device: PX = the lane pair)
-template <bool kShort, class PX, class M>
-DT_FN void dt_node2(const M& mesh, int m, int d, unsigned j, const int* order, const int* oxy, const unsigned* cfl,
-                    const unsigned* cfr, unsigned* fl, unsigned* fr) {
-    int s, n, base;
-    if (!dt_descend(m, d, j, &s, &n, &base)) return;
-    unsigned a, b;
-    if (n <= 3) {
-        dt_leaf(mesh, order, oxy, s, n, base, &a, &b);
-    } else {
-        const int h = n >> 1;
-        a = cfl[s];
-        b = cfr[s + h];
-        dt_merge2<kShort, PX>(mesh, &a, cfr[s], cfl[s + h], &b, d & 1, base + 2 * n - 4);
     }
     fl[s] = a;
     fr[s] = b;

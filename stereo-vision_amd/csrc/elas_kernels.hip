@@ -1303,12 +1303,24 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P, 
     const int v = y * mul;
     int line = v < P.H - 3 ? v : P.H - 3;
     line = line > 2 ? line : 2;
-    {
+    // the image-2 row is stored REVERSED: a left-map candidate u - d is then slot (W-1-u) + d, a
+    // right-map candidate u + d slot u + d of the image-1 row -- position + disparity on both
+    // sides, one v_lshl_add per address
+    if (G.desc_fly) {
+        // round 5: the two rows assembled from the Sobel planes (as k_match_list does), so that subsampling and
+        // disp_max > 255 run without the 32 N bytes of descriptor maps too; tasks alternate between the images
+        const int nq = (P.W + 3) >> 2;
+        for (int task = (int)threadIdx.x; task < 2 * nq; task += (int)blockDim.x) {
+            const int im = task & 1, x = 4 * (task >> 1);
+            uint4 o[4];
+            fly_desc4(G.desc + (size_t)(2 * pair + im) * N * 16, P.W, P.H, x, line, o);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (x + i < P.W) s_rows[im ? 2 * P.W - 1 - (x + i) : x + i] = o[i];
+        }
+    } else {
         const uint4* l1 = reinterpret_cast<const uint4*>(G.desc + (size_t)(2 * pair) * N * 16) + (size_t)line * P.W;
         const uint4* l2 = l1 + N;
-        // the image-2 row is stored REVERSED: a left-map candidate u - d is then slot (W-1-u) + d, a
-        // right-map candidate u + d slot u + d of the image-1 row -- position + disparity on both
-        // sides, one v_lshl_add per address
         stage_slots<5>(s_rows, 2 * P.W, (int)threadIdx.x, (int)blockDim.x,
                        [&](int i) { return i < P.W ? l1[i] : l2[2 * P.W - 1 - i]; });
     }
@@ -2469,30 +2481,17 @@ static bool match_list_usable(const svh_elas_params& p, const Dims& d, int32_t p
     return ok;
 }
 
-bool descriptors_on_the_fly(const svh_elas_params& p, const Dims& d, int32_t prior_absmax, int32_t plane_radius,
-                            bool have_lists) {
-    static const bool off = getenv("SVH_DESC_FLY") && atoi(getenv("SVH_DESC_FLY")) == 0;
-    return !off && !p.subsampling && d.W >= 8 && support_strip(p, d, nullptr) != 0 &&
-           match_list_usable(p, d, prior_absmax, plane_radius, have_lists, nullptr, nullptr);
-}
-
-// returns false with *error set when the group cannot be matched (a HIP refusal between the descriptor stage and
-// here: the caller reports SVH_ERR_HIP for the group)
-bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
-                  const GroupDev& G, const DevMaps* lr_out, bool write_raw, const char** error) {
-    if (error) *error = nullptr;
-    MatchParams P;
-    P.W = d.W; P.H = d.H; P.DW = d.DW; P.DH = d.DH; P.gw = d.gw; P.gh = d.gh; P.gwords = d.gwords;
-    P.grid_size = p.grid_size; P.sub = p.subsampling; P.disp_max = p.disp_max;
-    P.match_texture = p.match_texture; P.plane_radius = G.plane_radius;
-    P.grid_magic = (uint32_t)(0x100000000ull / (uint64_t)p.grid_size) + 1u;
-    P.npairs = g;
-    const size_t lds = (size_t)d.W * sizeof(uint4);
-    // the keyed kernel packs cost and scan rank into one int32 (see k_match_keyed)
+// Does the dense matcher take its keyed form (k_match_keyed: subsampling, disp_max > 255, no candidate records) when
+// the list form is not usable?  with_lr: the raw rows of the fused L/R check count against the LDS (the pipeline's
+// form; the decision before E1 asks for it).  *lds2_out: dynamic LDS of the launch.
+static bool match_keyed_usable(const svh_elas_params& p, const Dims& d, int32_t prior_absmax, int32_t plane_radius,
+                               bool with_lr, size_t* lds2_out) {
     static const bool ordered = getenv("SVH_MATCH_ORDERED") != nullptr;
-    const bool keyed_ok = !ordered && G.prior_absmax < (1 << 19) && p.disp_max < 512 &&
-                          G.plane_radius <= 15 && d.W < 65536 && p.grid_size > 1;
-    const size_t lds2 = 2 * lds + (lr_out ? (size_t)2 * d.DW * sizeof(float) : 0);
+    const bool keyed_ok = !ordered && prior_absmax < (1 << 19) && p.disp_max < 512 && plane_radius <= 15 &&
+                          d.W < 65536 && p.grid_size > 1;
+    const size_t lds = (size_t)d.W * sizeof(uint4);
+    const size_t lds2 = 2 * lds + (with_lr ? (size_t)2 * d.DW * sizeof(float) : 0);
+    if (lds2_out) *lds2_out = lds2;
     // rows up to 1920 px (77 KB with the raw-disparity rows) still take the keyed kernel: two blocks
     // per CU, measured 2-5 % ahead of the ordered fallback on 1920x1080 since the kernel got leaner
     constexpr size_t keyed_lds_max = 96 * 1024;
@@ -2507,6 +2506,36 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
                                         (int)keyed_lds_max) == hipSuccess;
         if (!use_keyed) (void)hipGetLastError();
     }
+    return use_keyed;
+}
+
+// E1 writes only the Sobel planes when BOTH matchers assemble their descriptor rows themselves: the LDS support
+// kernel, and the list form or (round 5: subsampling, disp_max > 255) the keyed form of the dense matcher.
+bool descriptors_on_the_fly(const svh_elas_params& p, const Dims& d, int32_t prior_absmax, int32_t plane_radius,
+                            bool have_lists) {
+    static const bool off = getenv("SVH_DESC_FLY") && atoi(getenv("SVH_DESC_FLY")) == 0;
+    static const bool keyed_fly = !(getenv("SVH_DESC_FLY_KEYED") && atoi(getenv("SVH_DESC_FLY_KEYED")) == 0);
+    if (off || d.W < 8 || support_strip(p, d, nullptr) == 0) return false;
+    if (match_list_usable(p, d, prior_absmax, plane_radius, have_lists, nullptr, nullptr)) return true;
+    return keyed_fly && match_keyed_usable(p, d, prior_absmax, plane_radius, true, nullptr);
+}
+
+// returns false with *error set when the group cannot be matched (a HIP refusal between the descriptor stage and
+// here: the caller reports SVH_ERR_HIP for the group)
+bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
+                  const GroupDev& G, const DevMaps* lr_out, bool write_raw, const char** error) {
+    if (error) *error = nullptr;
+    MatchParams P;
+    P.W = d.W; P.H = d.H; P.DW = d.DW; P.DH = d.DH; P.gw = d.gw; P.gh = d.gh; P.gwords = d.gwords;
+    P.grid_size = p.grid_size; P.sub = p.subsampling; P.disp_max = p.disp_max;
+    P.match_texture = p.match_texture; P.plane_radius = G.plane_radius;
+    P.grid_magic = (uint32_t)(0x100000000ull / (uint64_t)p.grid_size) + 1u;
+    P.npairs = g;
+    const size_t lds = (size_t)d.W * sizeof(uint4);
+    constexpr size_t kStaticLds = 64 * sizeof(int);   // s_P of both match kernels counts against the limit
+    // the keyed kernel packs cost and scan rank into one int32 (see k_match_keyed)
+    size_t lds2 = 0;
+    const bool use_keyed = match_keyed_usable(p, d, G.prior_absmax, G.plane_radius, lr_out != nullptr, &lds2);
     // round 4: the list form of the keyed kernel (per-cell candidate records, v_sad_hi_u8 keys, LDS-DMA staging)
     {
         MatchList Q;
@@ -2514,11 +2543,11 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
         const bool ok = match_list_usable(p, d, G.prior_absmax, G.plane_radius, G.lists != nullptr, &Q, &ldsl);
         const int iters = (d.DW + 255) / 256;
         const int half = std::min(256, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
-        if (!ok && G.desc_fly) {
-            // descriptors_on_the_fly() and this selection are the same function of the same arguments; what can
+        if (!ok && !use_keyed && G.desc_fly) {
+            // descriptors_on_the_fly() and this selection are the same functions of the same arguments; what can
             // differ between the two calls is the driver's answer to the LDS opt-in.  The descriptor maps of this
             // group do not exist, so it cannot fall back: the group fails, the next one decides again.
-            if (error) *error = "the list matcher was refused after the descriptor stage had left only the Sobel planes";
+            if (error) *error = "both row matchers were refused after the descriptor stage had left only the Sobel planes";
             return false;
         }
         if (ok) {

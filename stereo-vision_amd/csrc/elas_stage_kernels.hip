@@ -405,41 +405,6 @@ __global__ __launch_bounds__(512) void k_lattice(StageDev S, LatticeParams P) {
 // tests/cxx/dt_core_check.cpp).  Round 5: records are fetched whole, their corners carry the coordinates.
 using namespace dt;
 
-// the lane pair of dt_merge2: lanes 2k (left hull) and 2k+1 (right hull) of a wave; values cross with one DPP move
-// (quad_perm [1,0,3,2]).  Both lanes of a pair are active wherever a swap is issued.
-struct LanePair {
-    template <class T> struct Var {
-        T v;
-        __device__ __forceinline__ T& operator[](int) { return v; }
-        __device__ __forceinline__ const T& operator[](int) const { return v; }
-    };
-    template <class F> static __device__ __forceinline__ void par(F f) { f((int)(threadIdx.x & 1)); }
-    static __device__ __forceinline__ int swap(int x) {
-        int r = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
-        asm volatile("" : "+v"(r));     // (kept a plain v_mov_b32_dpp: see lane_prev in elas_kernels.hip)
-        return r;
-    }
-    static __device__ __forceinline__ unsigned other(const Var<unsigned>& x, int) { return (unsigned)swap((int)x.v); }
-    static __device__ __forceinline__ bool other(const Var<bool>& x, int) { return swap(x.v ? 1 : 0) != 0; }
-    static __device__ __forceinline__ Vtx other(const Var<Vtx>& x, int) {
-        Vtx r;
-        r.id = swap(x.v.id);
-        r.xy = swap(x.v.xy);
-        return r;
-    }
-    static __device__ __forceinline__ bool both(const Var<bool>& a) { return a.v; }   // (equal on both lanes by construction)
-    static __device__ __forceinline__ void fold(const Var<unsigned>& cand, const Var<unsigned>& cand_o, const Var<Vtx>& lo_own,
-                                                const Var<Vtx>& lo_oth, const Var<unsigned>& base, unsigned* lcand,
-                                                unsigned* rcand, Vtx* lowerleft, Vtx* lowerright, unsigned* basef) {
-        const bool right = (threadIdx.x & 1) != 0;
-        *lcand = right ? cand_o.v : cand.v;
-        *rcand = right ? cand.v : cand_o.v;
-        *lowerleft = right ? lo_oth.v : lo_own.v;
-        *lowerright = right ? lo_own.v : lo_oth.v;
-        *basef = base.v;
-    }
-};
-
 struct DtParams {
     int lds_ints;                 // ints of dynamic LDS of a k_delaunay block
     int lds_cap;                  // points whose records fit the block's LDS (48 bytes per point)
@@ -447,7 +412,6 @@ struct DtParams {
     int W, H, sup_cap, rec_cap;   // W: columns the points may use (image width + disp_max: the two
                                   // right-image corner points of addCornerSupportPoints lie at W-1+d)
     int spread;                   // depths with at most this many nodes give consecutive nodes to different waves
-    int pairs;                    // depths with at most this many nodes run every merge on a lane pair (dt_merge2)
 };
 
 // The recursion of the divide and conquer, bottom-up: all nodes of one depth are independent (one
@@ -455,8 +419,7 @@ struct DtParams {
 // of the nodes of a depth, by first vertex, two depths alternating.
 template <int kT, class M>
 __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const int* order, const int* oxy,
-                                         unsigned* FL, unsigned* FR, int sup_cap, int64_t* dbg, bool stamp, int spread,
-                                         int pairs) {
+                                         unsigned* FL, unsigned* FR, int sup_cap, int64_t* dbg, bool stamp, int spread) {
     const int tid = threadIdx.x;
     if (tid == 0) mesh.make_rec(0);   // record 0 = outer space
     __syncthreads();
@@ -476,14 +439,7 @@ __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const 
         constexpr unsigned kWaves = kT / 64;
         const bool spr = spread < 0 || tasks <= (unsigned)spread;
         const unsigned j0 = spr ? (unsigned)(tid & 63) * kWaves + (unsigned)(tid >> 6) : (unsigned)tid;
-        if (tasks <= (unsigned)pairs) {
-            // near the root a merge takes a lane PAIR (left hull / right hull, see dt_merge2): pair p of wave w
-            const unsigned pr = (unsigned)(tid & 63) >> 1;
-            const unsigned p0 = spr ? pr * kWaves + (unsigned)(tid >> 6) : (unsigned)(tid >> 6) * 32u + pr;
-            for (unsigned j = p0; j < tasks; j += kT / 2) dt_node2<true, LanePair>(mesh, m, d, j, order, oxy, cfl, cfr, fl, fr);
-        } else {
-            for (unsigned j = j0; j < tasks; j += kT) dt_node<true>(mesh, m, d, j, order, oxy, cfl, cfr, fl, fr);
-        }
+        for (unsigned j = j0; j < tasks; j += kT) dt_node<true>(mesh, m, d, j, order, oxy, cfl, cfr, fl, fr);
         __syncthreads();
         if (stamp && tid == 0 && 11 + (depth - d) < 30) dbg[11 + (depth - d)] = wall_clock64();
     }
@@ -499,7 +455,11 @@ __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const 
 // kT = 256 for KITTI-size lattices; 1024 for large ones (1920x1080: 6-12 k points per side), where
 // the chunked loops of the first two phases are 4x shorter per thread.
 // ---------------------------------------------------------------------------
-template <int kT>
+// kPhase 0: the whole triangulation in one launch.  Large point sets (1920x1080: 6-12 k points per side, records in
+// L2) run it as TWO launches since round 5: kPhase 1 = ranks + cut order (the part that wants the CU's whole LDS,
+// ~230 us) and kPhase 2 = the bottom-up build (~1.3 ms of pointer walking that needs no LDS at all) -- as one kernel
+// a triangulation held 159 KB of LDS, i.e. a whole CU, for its entire duration.
+template <int kT, int kPhase>
 __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
     extern __shared__ int s_hist[];   // [W + 1] column starts, [H + 1] row starts, then two cursors copies
     __shared__ int s_scan[kT / 64 + 1];
@@ -507,6 +467,7 @@ __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
     const int slot = blockIdx.x, pair = slot >> 1, side = slot & 1, tid = threadIdx.x;
     int m = S.counts->nsup[pair];
     const int m_all = m;              // k_stage_pack walks the records of m_all points
+    if (kPhase == 1 && tid == 0) S.counts->dt_m[slot] = 0;     // (every early exit below: nothing to build)
     if (m < 3 || (S.counts->flags[pair] & STG_OVERFLOW)) {
         if (tid == 0) S.counts->ntri[slot] = 0;
         return;
@@ -531,6 +492,15 @@ __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
     int* cury = curx + P.W;                  // H
     const int nh = 2 * (P.W + P.H) + 2;
 #define STAMP(k) do { if (slot == 0 && tid == 0) S.counts->dbg[k] = wall_clock64(); } while (0)
+    int depth = 0;
+    if (kPhase == 2) {
+        // the ordering launch left order / oxy / pxy / dmap in memory and these three numbers
+        m = S.counts->dt_m[slot];
+        if (m < 3) return;             // (it has set ntri and the records of a slot without triangles)
+        const int dd = S.counts->dt_depth[slot];
+        depth = dd & 0xffff;
+        remap = (dd & 0x10000) != 0;
+    } else {
     STAMP(8);
     // ---- ranks in (x,y) and (y,x) order.  Second trip only when coincident points were found and dropped.
     for (;;) {
@@ -706,7 +676,6 @@ __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
         lx = l0; ly = l0 + m; tmp = l0 + 2 * m; Pc = l0 + 3 * m;
         __syncthreads();
     }
-    int depth = 0;
     for (;; depth++) {
         const int axis = depth & 1;
         unsigned* src = axis == 0 ? ly : lx;
@@ -758,6 +727,14 @@ __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
         order[i] = p;
         oxy[i] = pxy[p];
     }
+    if (kPhase == 1) {
+        if (tid == 0) {
+            S.counts->dt_m[slot] = m;
+            S.counts->dt_depth[slot] = depth | (remap ? 0x10000 : 0);
+        }
+        return;
+    }
+    }   // (kPhase != 2)
     // ---- divide and conquer, bottom-up by depth (`depth` is where every node is a leaf), in LDS
     // when the records of this triangulation fit the block's allocation
     MeshG mg;
@@ -770,7 +747,7 @@ __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
     if (m <= P.lds_cap) {
         MeshL ml;
         ml.base = reinterpret_cast<unsigned char*>(s_hist);      // 24 bytes per record, 2m + 2 records
-        dt_build<kT>(ml, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0, P.spread, P.pairs);
+        dt_build<kT>(ml, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0, P.spread);
         // corner indices out for k_stage_pack (records 1 .. 2m-2)
         // (after coincident points were dropped the triangulation's point p is support point dmap[p])
         auto sid = [&](int a) { return a < 0 ? -1 : (remap ? dmap[a] : a); };
@@ -780,7 +757,7 @@ __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
         }
         __syncthreads();
     } else {
-        dt_build<kT>(mg, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0, P.spread, P.pairs);
+        dt_build<kT>(mg, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0, P.spread);
         if (remap) {
             for (int t = 1 + tid; t < 2 * m - 1; t += kT) {
                 int4 v = *reinterpret_cast<const int4*>(mg.ids + 4 * (size_t)t);
@@ -904,6 +881,11 @@ static bool dt_large(const Dims& d) { return (size_t)d.Wc * d.Hc / 8 * 16 > 63 *
 // More than 64 KB of dynamic LDS needs an opt-in per kernel and device: asked once per device; a refusal (a part
 // with 64 KB of LDS per workgroup) sends large lattices through the 256-thread / 63 KB form and keeps the small
 // form at 63 KB (records of larger point sets then live in L2).
+// large point sets: ordering and build as two launches (SVH_DT_SPLIT=0: one launch, round 4's form)
+static bool dt_split() {
+    static const bool on = !(getenv("SVH_DT_SPLIT") && atoi(getenv("SVH_DT_SPLIT")) == 0);
+    return on;
+}
 static int dt_small_threads() {
     static const int t = getenv("SVH_DT_THREADS") ? atoi(getenv("SVH_DT_THREADS")) : 512;
     return t == 512 || t == 1024 ? t : 256;
@@ -916,8 +898,8 @@ static bool dt_lds_optin(bool big, size_t bytes) {
     std::lock_guard<std::mutex> lk(mu);
     if (state[big][dev] == 0) {
         const int t = big ? 1024 : dt_small_threads();
-        const void* fn = t == 1024 ? (const void*)k_delaunay<1024>
-                                   : (t == 512 ? (const void*)k_delaunay<512> : (const void*)k_delaunay<256>);
+        const void* fn = t == 1024 ? (big && dt_split() ? (const void*)k_delaunay<1024, 1> : (const void*)k_delaunay<1024, 0>)
+                                   : (t == 512 ? (const void*)k_delaunay<512, 0> : (const void*)k_delaunay<256, 0>);
         // (the small form on 1024 threads shares the kernel with the large one: the larger request stands)
         const bool ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)(t == 1024 ? 159 * 1024 : bytes)) == hipSuccess;
@@ -989,19 +971,23 @@ void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Di
     const bool big = dt_large(d) && dt_lds_optin(true, 159 * 1024);
     static const int dt_spread = getenv("SVH_DT_SPREAD") ? atoi(getenv("SVH_DT_SPREAD")) : 64;
     D.spread = big ? -1 : dt_spread;      // (large sets: every depth spread)
-    static const int dt_pairs = getenv("SVH_DT_PAIRS") ? atoi(getenv("SVH_DT_PAIRS")) : 0;
-    D.pairs = dt_pairs;
     const size_t dt_lds = dt_lds_bytes(p, d, big);
     D.lds_ints = (int)(dt_lds / 4);
     D.lds_cap = (int)std::min<size_t>((dt_lds - 32) / 48 - 1, 8000);   // 16-bit handles: < 8191 points
     {
         Timed t(cx, "k_delaunay");
-        if (big) {
-            hipLaunchKernelGGL(k_delaunay<1024>, dim3(2 * g), dim3(1024), dt_lds, s, S, D);
+        if (big && dt_split()) {
+            hipLaunchKernelGGL((k_delaunay<1024, 1>), dim3(2 * g), dim3(1024), dt_lds, s, S, D);
+            DtParams B = D;
+            B.lds_ints = 0;
+            B.lds_cap = 0;            // records in L2: the build launch takes no dynamic LDS
+            hipLaunchKernelGGL((k_delaunay<1024, 2>), dim3(2 * g), dim3(1024), 0, s, S, B);
+        } else if (big) {
+            hipLaunchKernelGGL((k_delaunay<1024, 0>), dim3(2 * g), dim3(1024), dt_lds, s, S, D);
         } else {
-            if (dt_small_threads() == 1024) hipLaunchKernelGGL(k_delaunay<1024>, dim3(2 * g), dim3(1024), dt_lds, s, S, D);
-            else if (dt_small_threads() == 512) hipLaunchKernelGGL(k_delaunay<512>, dim3(2 * g), dim3(512), dt_lds, s, S, D);
-            else hipLaunchKernelGGL(k_delaunay<256>, dim3(2 * g), dim3(256), dt_lds, s, S, D);
+            if (dt_small_threads() == 1024) hipLaunchKernelGGL((k_delaunay<1024, 0>), dim3(2 * g), dim3(1024), dt_lds, s, S, D);
+            else if (dt_small_threads() == 512) hipLaunchKernelGGL((k_delaunay<512, 0>), dim3(2 * g), dim3(512), dt_lds, s, S, D);
+            else hipLaunchKernelGGL((k_delaunay<256, 0>), dim3(2 * g), dim3(256), dt_lds, s, S, D);
         }
     }
     {

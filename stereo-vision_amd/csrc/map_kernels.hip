@@ -487,6 +487,11 @@ int32_t svh_disparity_colormap(const float* D, int32_t d_on_device, int64_t n, f
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
         return svh::fail(SVH_ERR_NO_DEVICE, "no HIP device visible: libsvhip has no CPU fallback");
     float *dD = nullptr, *dC = nullptr;
+    struct FreeBoth {       // (the error returns below must not leak the two temporaries)
+        float*& a;
+        float*& b;
+        ~FreeBoth() { (void)hipFree(a); (void)hipFree(b); }
+    } free_both_{dD, dC};
     MAP_TRY(hipMalloc(&dC, (size_t)n * 12));
     const float* src = D;
     if (!d_on_device) {
@@ -496,8 +501,6 @@ int32_t svh_disparity_colormap(const float* D, int32_t d_on_device, int64_t n, f
     }
     hipLaunchKernelGGL(k_disp_color, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, src, (long long)n, dC);
     const hipError_t e = hipMemcpy(rgb, dC, (size_t)n * 12, hipMemcpyDeviceToHost);
-    (void)hipFree(dD);
-    (void)hipFree(dC);
     if (e != hipSuccess) return svh::fail(SVH_ERR_HIP, std::string("colormap: ") + hipGetErrorString(e));
     return SVH_OK;
 }

@@ -91,12 +91,18 @@ hipError_t BatchRec::flush(hipStream_t s) {
         if (h_arena) (void)hipHostFree(h_arena);
         if (d_arena) (void)hipFree(d_arena);
         h_arena = d_arena = nullptr;
-        cap = std::max<size_t>(2 * (used + need), 256 * 1024);
-        e = hipHostMalloc((void**)&h_arena, cap);
-        if (e != hipSuccess) return e;
-        e = hipMalloc((void**)&d_arena, cap);
-        if (e != hipSuccess) return e;
+        const size_t want = std::max<size_t>(2 * (used + need), 256 * 1024);
+        cap = 0;      // (a failed allocation leaves an arena of size 0: the next flush allocates again)
         used = 0;
+        e = hipHostMalloc((void**)&h_arena, want);
+        if (e != hipSuccess) return e;
+        e = hipMalloc((void**)&d_arena, want);
+        if (e != hipSuccess) {
+            (void)hipHostFree(h_arena);
+            h_arena = nullptr;
+            return e;
+        }
+        cap = want;
     }
     size_t off = used;
     std::vector<size_t> at;
@@ -333,6 +339,22 @@ template <typename T>
 static hipError_t dalloc(T** p, size_t count) {
     return hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T));
 }
+// Growing a buffer: the old one is freed and its pointer CLEARED before the new allocation is tried, and the callers
+// set the capacity they track to 0 first and to the new size only after every allocation of the set succeeded -- a
+// failure in the middle (found by the sanitizer run with injected failures, tools/sanitize_viso.cpp) then leaves
+// "nothing allocated", which the next call repairs, instead of a stale pointer behind a capacity that says "fits".
+template <typename T>
+static hipError_t drealloc(T** p, size_t count) {
+    (void)hipFree(*p);
+    *p = nullptr;
+    return dalloc(p, count);
+}
+template <typename T>
+static hipError_t hrealloc(T** p, size_t bytes) {
+    (void)hipHostFree(*p);
+    *p = nullptr;
+    return hipHostMalloc((void**)p, bytes);
+}
 
 // device-resident data of one camera image of one frame
 struct DevView {
@@ -418,6 +440,7 @@ struct svh_matcher {
     bool taps = false;                          // keep every intermediate stage (parity tests)
     // results
     std::vector<svh_p_match> m1, m2;
+    std::vector<svh_p_match> m2_kept;   // the match list of the last good matchFeatures while a new one is being built
     std::vector<float> ranges;    // [bins][16]
     std::vector<svh_p_match> stage[SVH_M_STAGE_COUNT];
     // SVH_MATCHER_TIMING=1: host wall-clock per step, printed by svh_matcher_destroy
@@ -448,10 +471,16 @@ static BatchTiming g_btime;
 
 namespace svh {
 
+static int size_view(svh_matcher* m, DevView& V, int32_t w, int32_t h, int32_t bpl);
 static int ensure_view(svh_matcher* m, DevView& V, int32_t w, int32_t h, int32_t bpl) {
-    const svh_matcher_params& p = m->p;
-    if (V.w == w && V.h == h && V.bpl == bpl && V.half == p.half_resolution) return SVH_OK;
+    if (V.w == w && V.h == h && V.bpl == bpl && V.half == m->p.half_resolution) return SVH_OK;
     V.release();
+    const int rc = size_view(m, V, w, h, bpl);
+    if (rc) V.release();     // (a half-sized view must not look like one of the right geometry to the next call)
+    return rc;
+}
+static int size_view(svh_matcher* m, DevView& V, int32_t w, int32_t h, int32_t bpl) {
+    const svh_matcher_params& p = m->p;
     V.w = w; V.h = h; V.bpl = bpl;
     V.half = p.half_resolution;
     if (p.half_resolution) {
@@ -494,11 +523,11 @@ static int ensure_view(svh_matcher* m, DevView& V, int32_t w, int32_t h, int32_t
 // two functions, so that neither side reads the other's bookkeeping
 static int ensure_feature_scratch(svh_matcher* m, int32_t slot_need) {
     if (slot_need > m->slot_cap) {
+        m->slot_cap = 0;
         for (int c = 0; c < 2; c++) {
-            (void)hipFree(m->slots[c]); (void)hipFree(m->flags[c]); (void)hipFree(m->order[c]);
-            HIP_TRY(dalloc(&m->slots[c], (size_t)slot_need));
-            HIP_TRY(dalloc(&m->flags[c], (size_t)slot_need + 4));
-            HIP_TRY(dalloc(&m->order[c], (size_t)slot_need));
+            HIP_TRY(drealloc(&m->slots[c], (size_t)slot_need));
+            HIP_TRY(drealloc(&m->flags[c], (size_t)slot_need + 4));
+            HIP_TRY(drealloc(&m->order[c], (size_t)slot_need));
         }
         m->slot_cap = slot_need;
     }
@@ -507,16 +536,16 @@ static int ensure_feature_scratch(svh_matcher* m, int32_t slot_need) {
 
 static int ensure_match_scratch(svh_matcher* m, int32_t pm_need, size_t owner_need) {
     if (pm_need > m->pm_cap) {
-        (void)hipFree(m->pm_slots); (void)hipFree(m->pm_out); (void)hipFree(m->pm_flags);
-        HIP_TRY(dalloc(&m->pm_slots, (size_t)pm_need));
-        HIP_TRY(dalloc(&m->pm_out, (size_t)pm_need));
-        HIP_TRY(dalloc(&m->pm_flags, (size_t)pm_need));
+        m->pm_cap = 0;
+        HIP_TRY(drealloc(&m->pm_slots, (size_t)pm_need));
+        HIP_TRY(drealloc(&m->pm_out, (size_t)pm_need));
+        HIP_TRY(drealloc(&m->pm_flags, (size_t)pm_need));
         m->pm_cap = pm_need;
     }
     if (!m->pm_count) HIP_TRY(dalloc(&m->pm_count, 2));
     if (owner_need > m->owner_cap) {
-        (void)hipFree(m->pixel_owner);
-        HIP_TRY(dalloc(&m->pixel_owner, owner_need));
+        m->owner_cap = 0;
+        HIP_TRY(drealloc(&m->pixel_owner, owner_need));
         m->owner_cap = owner_need;
     }
     return SVH_OK;
@@ -602,10 +631,8 @@ static int ensure_bins(svh_matcher* m, DevView* const* views, int nviews, int32_
         DevView& V = *views[v];
         if (!V.valid || V.nbins == nb) continue;
         if (nb > V.off_cap) {   // (re)allocate only when the bin grid grows: hipFree synchronises the device
-            for (int k = 0; k < 2; k++) {
-                (void)hipFree(V.off[k]);
-                HIP_TRY(dalloc(&V.off[k], (size_t)nb + 1));
-            }
+            V.off_cap = 0;
+            for (int k = 0; k < 2; k++) HIP_TRY(drealloc(&V.off[k], (size_t)nb + 1));
             V.off_cap = nb;
         }
         for (int k = 0; k < 2; k++) {
@@ -620,8 +647,8 @@ static int ensure_bins(svh_matcher* m, DevView* const* views, int nviews, int32_
     }
     if (!nj) return SVH_OK;
     if (nb > m->cursor_cap) {
-        (void)hipFree(m->cursor);
-        HIP_TRY(dalloc(&m->cursor, (size_t)nb));
+        m->cursor_cap = 0;
+        HIP_TRY(drealloc(&m->cursor, (size_t)nb));
         m->cursor_cap = nb;
     }
     mlaunch_bin_index(m->stream, J, nj, nmax, ub, vb, m->p.match_binsize, m->cursor);
@@ -773,8 +800,8 @@ static int match_enqueue(svh_matcher* m, int dense, int32_t method, bool use_pri
                   view_of(m->cur[1], dense), nq, m->ranges_dev, use_prior ? 1 : 0, m->pm_slots, m->pm_flags,
                   m->pixel_owner, m->pm_out, m->pm_count);
     if (nq > m->h_pm_cap || !m->h_cnt) {
-        (void)hipHostFree(m->h_pm);
-        HIP_TRY(hipHostMalloc((void**)&m->h_pm, (size_t)std::max(nq, 1) * sizeof(svh_p_match)));
+        m->h_pm_cap = 0;
+        HIP_TRY(hrealloc(&m->h_pm, (size_t)std::max(nq, 1) * sizeof(svh_p_match)));
         if (!m->h_cnt) HIP_TRY(hipHostMalloc((void**)&m->h_cnt, sizeof(int32_t)));
         m->h_pm_cap = std::max(nq, 1);
     }
@@ -1326,6 +1353,22 @@ static bool match_inputs_present(const svh_matcher* m, int32_t method) {
     return true;
 }
 
+// A matchFeatures that fails (a HIP error half-way) leaves the object's match list as the last good call made it
+// (getMatches / getGain / bucketFeatures of the caller keep working on a consistent list): the list is set aside for
+// the duration of the call and put back unless the call commits.  Two vectors swapped: no copy, capacities kept.
+struct KeepMatches {
+    std::vector<svh_matcher*> ms;
+    bool committed = false;
+    explicit KeepMatches(const std::vector<svh_matcher*>& list) : ms(list) {
+        for (svh_matcher* m : ms) m->m2.swap(m->m2_kept);
+    }
+    void commit() { committed = true; }
+    ~KeepMatches() {
+        if (!committed)
+            for (svh_matcher* m : ms) m->m2.swap(m->m2_kept);
+    }
+};
+
 // result vectors cleared, bin indices of changed tables rebuilt, prior-range buffer sized
 static int32_t match_prepare(svh_matcher* m, int32_t ub, int32_t vb) {
     for (int s = 0; s < SVH_M_STAGE_COUNT; s++) m->stage[s].clear();
@@ -1335,8 +1378,8 @@ static int32_t match_prepare(svh_matcher* m, int32_t ub, int32_t vb) {
     const int rc = ensure_bins(m, views, 4, ub, vb);
     if (rc) return rc;
     if (ub * vb > m->ranges_cap) {
-        (void)hipFree(m->ranges_dev);
-        HIP_TRY(dalloc(&m->ranges_dev, (size_t)16 * ub * vb));
+        m->ranges_cap = 0;
+        HIP_TRY(drealloc(&m->ranges_dev, (size_t)16 * ub * vb));
         m->ranges_cap = ub * vb;
     }
     return SVH_OK;
@@ -1348,6 +1391,7 @@ int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double*
     const svh_matcher_params& p = m->p;
     if (!match_inputs_present(m, method)) return SVH_OK;
     if (method > 2) method = 2;
+    KeepMatches keep_({m});
     HIP_TRY(hipSetDevice(m->device));
     const int32_t ub = (int32_t)ceilf((float)m->dims_c[0] / (float)p.match_binsize);
     const int32_t vb = (int32_t)ceilf((float)m->dims_c[1] / (float)p.match_binsize);
@@ -1384,6 +1428,7 @@ int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double*
         m->tcalls[1]++;
     }
     if (m->taps) m->stage[SVH_M_DENSE] = m->m2;
+    keep_.commit();
     return SVH_OK;
 }
 
@@ -1420,6 +1465,7 @@ int32_t svh_matcher_match_features_batch(svh_matcher* const* ms, int32_t K, int3
     }
     if (!lockstep || part.size() < 2) return serial(part, trs);
     if (method > 2) method = 2;
+    KeepMatches keep_(part);
     const int n = (int)part.size();
     const svh_matcher_params& p = part[0]->p;
     HIP_TRY(hipSetDevice(part[0]->device));
@@ -1510,9 +1556,8 @@ int32_t svh_matcher_match_features_batch(svh_matcher* const* ms, int32_t K, int3
             svh_matcher* m = part[i];
             match_collect(m, mp[i], m->m1);
             if (nr > m->h_ranges_cap) {
-                (void)hipHostFree(m->h_ranges);
-                m->h_ranges = nullptr;
-                HIP_TRY(hipHostMalloc((void**)&m->h_ranges, nr * sizeof(float)));
+                m->h_ranges_cap = 0;
+                HIP_TRY(hrealloc(&m->h_ranges, nr * sizeof(float)));
                 m->h_ranges_cap = nr;
             }
         }
@@ -1552,6 +1597,7 @@ int32_t svh_matcher_match_features_batch(svh_matcher* const* ms, int32_t K, int3
         g_btime.t[10] += tm[4] - tm[3];
         g_btime.calls[1]++;
     }
+    if (rc == SVH_OK) keep_.commit();
     return rc;
 }
 

@@ -305,13 +305,15 @@ __device__ __forceinline__ void d_feature_records(const int4* __restrict__ slots
 // ---------------------------------------------------------------------------
 // LDS build: histogram, scan, scatter and the per-bin ascending sort all stay on chip;
 // used when 2*nb + 1 + n ints fit the LDS budget (launcher), else k_bin_index below.
-__device__ __forceinline__ void d_bin_index_lds(BinJobs J, int ub, int vb, int binsize, unsigned bx) {
+// (table / count / off / ids: the four pointers of the workgroup's table.  The callers pick them out of their BinJobs
+// -- a kernel argument in the single-object form, a row of the job table in the batched form -- so that the 32
+// pointers are never copied: round 4's batched form indexed a by-value copy and spilled 264 bytes of scratch)
+__device__ __forceinline__ void d_bin_index_lds(const int32_t* __restrict__ table, const int32_t* __restrict__ count,
+                                                int32_t* __restrict__ off, int32_t* __restrict__ ids, int ub, int vb,
+                                                int binsize) {
     extern __shared__ int s_bin[];
-    // one workgroup per table (bx): the four tables of a stereo frame build concurrently
-    const int32_t* __restrict__ table = J.table[bx];
-    int32_t* __restrict__ off = J.off[bx];
-    int32_t* __restrict__ ids = J.ids[bx];
-    const int n = *J.count[bx], nb = 4 * ub * vb, t = threadIdx.x;
+    // one workgroup per table: the four tables of a stereo frame build concurrently
+    const int n = *count, nb = 4 * ub * vb, t = threadIdx.x;
     int* s_off = s_bin;            // nb + 1
     int* s_cur = s_bin + nb + 1;   // nb
     int* s_ids = s_cur + nb;       // n
@@ -867,7 +869,11 @@ __device__ __forceinline__ void d_refine(svh_p_match* __restrict__ m,
 // compiler so and the kernels use global_load / global_store like their single-object forms.
 template <class T>
 __device__ __forceinline__ T* gptr(T* p) {
-    return (T*)(__attribute__((address_space(1))) T*)p;
+    // (the empty asm keeps the address-space-1 value opaque: a plain generic -> global -> generic cast pair is folded
+    // away before the compiler's address-space inference sees it; held in a vector register pair)
+    __attribute__((address_space(1))) T* q = (__attribute__((address_space(1))) T*)p;
+    asm volatile("" : "+v"(q));
+    return (T*)q;
 }
 __device__ __forceinline__ FeatView gview(const FeatView& v) {
     FeatView o;
@@ -883,7 +889,7 @@ __device__ __forceinline__ SobelView gview(const SobelView& v) {
 struct HalfJob { const uint8_t* I; int bpl; uint8_t* out; int hw, hh, hbpl; };
 __global__ __launch_bounds__(256) void k_half(HalfJob a) { d_half(a.I, a.bpl, a.out, a.hw, a.hh, a.hbpl, blockIdx.x, blockIdx.y); }
 __global__ __launch_bounds__(256) void k_half_b(const HalfJob* J) {
-    const HalfJob a = gptr(J)[blockIdx.z];
+    const HalfJob a = J[blockIdx.z];
     d_half(gptr(a.I), a.bpl, gptr(a.out), a.hw, a.hh, a.hbpl, blockIdx.x, blockIdx.y);
 }
 
@@ -894,7 +900,7 @@ __global__ __launch_bounds__(256) void k_filters(FiltersJob a) {
 }
 template <bool kFeatures>
 __global__ __launch_bounds__(256) void k_filters_b(const FiltersJob* J) {
-    const FiltersJob a = gptr(J)[blockIdx.z];
+    const FiltersJob a = J[blockIdx.z];
     d_filters<kFeatures>(gptr(a.I), a.w, a.h, a.bpl, gptr(a.du), gptr(a.dv), gptr(a.f1), gptr(a.f2), blockIdx.x, blockIdx.y);
 }
 
@@ -905,14 +911,14 @@ __global__ __launch_bounds__(256) void k_nms(NmsJob a) {
 }
 template <int kG>
 __global__ __launch_bounds__(256) void k_nms_b(const NmsJob* J) {
-    const NmsJob a = gptr(J)[blockIdx.z];
+    const NmsJob a = J[blockIdx.z];
     d_nms<kG>(gptr(a.f1), gptr(a.f2), a.w, a.h, a.bpl, a.n, a.tau, a.margin, a.ni, a.nj, gptr(a.slots), gptr(a.flags), blockIdx.x);
 }
 
 struct CompactSlotsJob { const int32_t* flags; int nslots; int32_t *order, *count; };
 __global__ __launch_bounds__(1024) void k_compact_slots(CompactSlotsJob a) { d_compact_slots(a.flags, a.nslots, a.order, a.count, 0u); }
 __global__ __launch_bounds__(1024) void k_compact_slots_b(const CompactSlotsJob* J) {
-    const CompactSlotsJob a = gptr(J)[blockIdx.z];
+    const CompactSlotsJob a = J[blockIdx.z];
     d_compact_slots(gptr(a.flags), a.nslots, gptr(a.order), gptr(a.count), 0u);
 }
 
@@ -921,16 +927,20 @@ __global__ __launch_bounds__(256) void k_feature_records(FeatureRecordsJob a) {
     d_feature_records(a.slots, a.order, a.count, a.du, a.dv, a.bpl, a.scale, a.table, blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_feature_records_b(const FeatureRecordsJob* J) {
-    const FeatureRecordsJob a = gptr(J)[blockIdx.z];
+    const FeatureRecordsJob a = J[blockIdx.z];
     d_feature_records(gptr(a.slots), gptr(a.order), gptr(a.count), gptr(a.du), gptr(a.dv), a.bpl, a.scale, gptr(a.table), blockIdx.x);
 }
 
 struct BinIndexJob { BinJobs J; int njobs, ub, vb, binsize; };
-__global__ __launch_bounds__(1024) void k_bin_index_lds(BinJobs J, int ub, int vb, int binsize) { d_bin_index_lds(J, ub, vb, binsize, blockIdx.x); }
+__global__ __launch_bounds__(1024) void k_bin_index_lds(BinJobs J, int ub, int vb, int binsize) {
+    const unsigned bx = blockIdx.x;
+    d_bin_index_lds(J.table[bx], J.count[bx], J.off[bx], J.ids[bx], ub, vb, binsize);
+}
 __global__ __launch_bounds__(1024) void k_bin_index_lds_b(const BinIndexJob* J) {
     const BinIndexJob& a = J[blockIdx.z];
-    if ((int)blockIdx.x >= a.njobs) return;
-    d_bin_index_lds(a.J, a.ub, a.vb, a.binsize, blockIdx.x);
+    const unsigned bx = blockIdx.x;
+    if ((int)bx >= a.njobs) return;
+    d_bin_index_lds(gptr(a.J.table[bx]), gptr(a.J.count[bx]), gptr(a.J.off[bx]), gptr(a.J.ids[bx]), a.ub, a.vb, a.binsize);
 }
 
 struct MatchJob {
@@ -945,7 +955,7 @@ __global__ __launch_bounds__(128) void k_match(MatchJob a) {
     d_match(a.P, a.m1p, a.m2p, a.m1c, a.m2c, a.ranges, a.use_prior, a.out, a.flags, a.pixel_owner, blockIdx.x);
 }
 __global__ __launch_bounds__(128) void k_match_b(const MatchJob* J) {
-    const MatchJob& a = gptr(J)[blockIdx.z];
+    const MatchJob& a = J[blockIdx.z];
     d_match(a.P, gview(a.m1p), gview(a.m2p), gview(a.m1c), gview(a.m2c), gptr(a.ranges), a.use_prior, gptr(a.out), gptr(a.flags),
             gptr(a.pixel_owner), blockIdx.x);
 }
@@ -953,14 +963,14 @@ __global__ __launch_bounds__(128) void k_match_b(const MatchJob* J) {
 struct DedupeJob { const int32_t* n; int width; const svh_p_match* m; int32_t* flags; const int32_t* pixel_owner; };
 __global__ __launch_bounds__(256) void k_match_dedupe(DedupeJob a) { d_match_dedupe(a.n, a.width, a.m, a.flags, a.pixel_owner, blockIdx.x); }
 __global__ __launch_bounds__(256) void k_match_dedupe_b(const DedupeJob* J) {
-    const DedupeJob a = gptr(J)[blockIdx.z];
+    const DedupeJob a = J[blockIdx.z];
     d_match_dedupe(gptr(a.n), a.width, gptr(a.m), gptr(a.flags), gptr(a.pixel_owner), blockIdx.x);
 }
 
 struct CompactMatchesJob { const svh_p_match* in; const int32_t *flags, *nslots; svh_p_match* out; int32_t* count; };
 __global__ __launch_bounds__(1024) void k_compact_matches(CompactMatchesJob a) { d_compact_matches(a.in, a.flags, a.nslots, a.out, a.count, 0u); }
 __global__ __launch_bounds__(1024) void k_compact_matches_b(const CompactMatchesJob* J) {
-    const CompactMatchesJob a = gptr(J)[blockIdx.z];
+    const CompactMatchesJob a = J[blockIdx.z];
     d_compact_matches(gptr(a.in), gptr(a.flags), gptr(a.nslots), gptr(a.out), gptr(a.count), 0u);
 }
 
@@ -969,14 +979,14 @@ __global__ __launch_bounds__(256) void k_refine_group(RefineJob a) {
     d_refine_group(a.m, a.count, a.method, a.margin, a.s1p, a.s2p, a.s1c, a.s2c, blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_refine_group_b(const RefineJob* J) {
-    const RefineJob& a = gptr(J)[blockIdx.z];
+    const RefineJob& a = J[blockIdx.z];
     d_refine_group(gptr(a.m), gptr(a.count), a.method, a.margin, gview(a.s1p), gview(a.s2p), gview(a.s1c), gview(a.s2c), blockIdx.x);
 }
 __global__ __launch_bounds__(128) void k_refine_parabolic(RefineJob a) {
     d_refine<true>(a.m, a.count, a.method, a.margin, a.s1p, a.s2p, a.s1c, a.s2c, a.flags, blockIdx.x);
 }
 __global__ __launch_bounds__(128) void k_refine_parabolic_b(const RefineJob* J) {
-    const RefineJob& a = gptr(J)[blockIdx.z];
+    const RefineJob& a = J[blockIdx.z];
     d_refine<true>(gptr(a.m), gptr(a.count), a.method, a.margin, gview(a.s1p), gview(a.s2p), gview(a.s1c), gview(a.s2c), gptr(a.flags),
                    blockIdx.x);
 }
@@ -994,7 +1004,7 @@ __global__ __launch_bounds__(256) void k_upload(UploadJob a) {
     if (i < a.n16) a.dev[i] = a.host[i];
 }
 __global__ __launch_bounds__(256) void k_upload_b(const UploadJob* J) {
-    const UploadJob a = gptr(J)[blockIdx.z];
+    const UploadJob a = J[blockIdx.z];
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < a.n16) gptr(a.dev)[i] = gptr(a.host)[i];
 }
@@ -1003,14 +1013,14 @@ __global__ __launch_bounds__(256) void k_copy4(Copy4Job a) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) a.dst[i] = a.src[i];
 }
 __global__ __launch_bounds__(256) void k_copy4_b(const Copy4Job* J) {
-    const Copy4Job a = gptr(J)[blockIdx.z];
+    const Copy4Job a = J[blockIdx.z];
     uint32_t* const dst = gptr(a.dst);
     const uint32_t* const src = gptr(a.src);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 struct Fill4Job { uint32_t* dst; uint32_t value; size_t n4; };
 __global__ __launch_bounds__(256) void k_fill4_b(const Fill4Job* J) {
-    const Fill4Job a = gptr(J)[blockIdx.z];
+    const Fill4Job a = J[blockIdx.z];
     uint32_t* const dst = gptr(a.dst);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * 256) dst[i] = a.value;
 }

@@ -100,6 +100,9 @@ struct StageCounts {
     int32_t ntri[2 * kMaxGroup];        // triangles per (pair, side)
     int32_t flags[kMaxGroup];           // STG_*
     int64_t dbg[32];                    // phase time stamps of slot 0 (wall_clock64, 10 ns ticks)
+    // k_delaunay in two launches (large point sets): what the ordering launch hands to the build launch, per slot
+    int32_t dt_m[2 * kMaxGroup];        // points of the triangulation after coincident ones were dropped; 0 = nothing to build
+    int32_t dt_depth[2 * kMaxGroup];    // depth at which every node is a leaf | 0x10000 when points were dropped (dmap)
 };
 enum { STG_DUP = 1,        // coincident points in a triangulation: the host path must decide
        STG_OVERFLOW = 2,   // more support points than the scratch holds / coordinates out of range

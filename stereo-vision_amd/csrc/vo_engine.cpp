@@ -83,37 +83,45 @@ int ensure(svh_vo* v, int32_t N, int32_t iters) {
             return svh::fail(SVH_ERR_NO_DEVICE, "no HIP device visible: libsvhip has no CPU fallback");
         VO_TRY(hipSetDevice(v->device));
         VO_TRY(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
-        VO_TRY(hipHostMalloc((void**)&v->h_out, sizeof(VoResult)));
     }
     VO_TRY(hipSetDevice(v->device));
+    if (!v->h_out) VO_TRY(hipHostMalloc((void**)&v->h_out, sizeof(VoResult)));   // (its own check: a failure here must not be hidden behind the stream's)
     const size_t in_bytes = (((size_t)N * sizeof(svh_p_match) + 15) & ~(size_t)15) +
                             (((size_t)iters * 3 * sizeof(int32_t) + 15) & ~(size_t)15);
+    // (every capacity goes to 0 BEFORE its buffer is freed and back up only when the new one exists: a failed
+    // allocation must not leave a freed pointer behind a capacity that says "fits" to a later, smaller request)
     if (in_bytes > v->h_in_cap) {
+        v->h_in_cap = 0;
         (void)hipHostFree(v->h_in);
         v->h_in = nullptr;
         VO_TRY(hipHostMalloc((void**)&v->h_in, in_bytes));
         v->h_in_cap = in_bytes;
     }
     if (in_bytes > v->d_in_cap) {
+        v->d_in_cap = 0;
         VO_TRY(grow(&v->d_in, in_bytes));
         v->d_in_cap = in_bytes;
     }
     if (N > v->inl_cap) {
+        v->inl_cap = 0;
         (void)hipHostFree(v->h_inl);
         v->h_inl = nullptr;
         VO_TRY(hipHostMalloc((void**)&v->h_inl, (size_t)N * sizeof(int32_t)));
         v->inl_cap = N;
     }
     if (iters > v->hyp_cap) {
+        v->hyp_cap = 0;
         VO_TRY(grow(&v->d_hyp_tr, (size_t)6 * iters));
         VO_TRY(grow(&v->d_hyp_count, (size_t)iters));
         v->hyp_cap = iters;
     }
     if ((size_t)iters * N > v->flags_cap) {
+        v->flags_cap = 0;
         VO_TRY(grow(&v->d_flags, (size_t)iters * N));
         v->flags_cap = (size_t)iters * N;
     }
     if (N > v->j_cap) {
+        v->j_cap = 0;
         VO_TRY(grow(&v->d_J, (size_t)24 * N));
         VO_TRY(grow(&v->d_res, (size_t)4 * N));
         v->j_cap = N;

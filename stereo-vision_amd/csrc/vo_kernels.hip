@@ -364,6 +364,14 @@ __device__ __forceinline__ void d_vo_refine(const svh_p_match* __restrict__ pm, 
 }
 
 // plain and batched forms (batch_rec.h: job blockIdx.z of a table in device memory)
+// (pointers read from the job table are told to be global memory: global_load instead of flat_load, see gptr in
+// matcher_kernels.hip)
+template <class T>
+__device__ __forceinline__ T* vgptr(T* p) {
+    __attribute__((address_space(1))) T* q = (__attribute__((address_space(1))) T*)p;
+    asm volatile("" : "+v"(q));
+    return (T*)q;
+}
 struct VoRansacJob { const svh_p_match* pm; int N; const int32_t* samples; VoCalib c; double* hyp_tr; int32_t* hyp_count; uint8_t* hyp_flags; int iters; };
 __global__ __launch_bounds__(64) void k_vo_ransac(VoRansacJob a) {
     d_vo_ransac(a.pm, a.N, a.samples, a.c, a.hyp_tr, a.hyp_count, a.hyp_flags, (int)blockIdx.x);
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(64) void k_vo_ransac(VoRansacJob a) {
 __global__ __launch_bounds__(64) void k_vo_ransac_b(const VoRansacJob* J) {
     const VoRansacJob& a = J[blockIdx.z];
     if ((int)blockIdx.x >= a.iters) return;
-    d_vo_ransac(a.pm, a.N, a.samples, a.c, a.hyp_tr, a.hyp_count, a.hyp_flags, (int)blockIdx.x);
+    d_vo_ransac(vgptr(a.pm), a.N, vgptr(a.samples), a.c, vgptr(a.hyp_tr), vgptr(a.hyp_count), vgptr(a.hyp_flags), (int)blockIdx.x);
 }
 struct VoRefineJob {
     const svh_p_match* pm; int N, iters; VoCalib c; const double* hyp_tr; const int32_t* hyp_count; const uint8_t* hyp_flags;
@@ -382,7 +390,8 @@ __global__ __launch_bounds__(256) void k_vo_refine(VoRefineJob a) {
 }
 __global__ __launch_bounds__(256) void k_vo_refine_b(const VoRefineJob* J) {
     const VoRefineJob& a = J[blockIdx.z];
-    d_vo_refine(a.pm, a.N, a.iters, a.c, a.hyp_tr, a.hyp_count, a.hyp_flags, a.Jg, a.resg, a.lds_rows, a.out, a.out_inliers);
+    d_vo_refine(vgptr(a.pm), a.N, a.iters, a.c, vgptr(a.hyp_tr), vgptr(a.hyp_count), vgptr(a.hyp_flags), vgptr(a.Jg), vgptr(a.resg),
+                a.lds_rows, vgptr(a.out), vgptr(a.out_inliers));
 }
 struct VoUploadJob { const uint4* host; uint4* dev; size_t n16; };
 __global__ __launch_bounds__(256) void k_vo_upload(VoUploadJob a) {
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(256) void k_vo_upload(VoUploadJob a) {
 __global__ __launch_bounds__(256) void k_vo_upload_b(const VoUploadJob* J) {
     const VoUploadJob a = J[blockIdx.z];
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < a.n16) a.dev[i] = a.host[i];
+    if (i < a.n16) vgptr(a.dev)[i] = vgptr(a.host)[i];
 }
 static void b_vo_ransac(const void* jobs, int njobs, unsigned gx, unsigned gy, size_t lds, hipStream_t s) {
     hipLaunchKernelGGL(k_vo_ransac_b, dim3(gx, gy, (unsigned)njobs), dim3(64), lds, s, reinterpret_cast<const VoRansacJob*>(jobs));

@@ -2,8 +2,7 @@
 // driven exactly as the kernel drives it (alternating-cut order, bottom-up by depth, record ranges known in advance).
 // The triangle lists must equal csrc/delaunay.cpp's (order included), which the oracle tests pin against the real
 // Triangle.  Both record storages (MeshG: 32-bit rows, MeshL: 24-byte records) and both forms of the seam step
-// (kShort on / off) are run, on one lane (dt_merge) and as a lane pair (dt_merge2, sides in sequence = lock step);
-// with kShort every shortcut is compared with the fresh read it replaces.
+// (kShort on / off) are run; with kShort every shortcut is compared with the fresh read it replaces.
 //   usage: dt_core_check [rounds] [seed]        exit 0 = identical everywhere
 #include <stdint.h>
 #include <stdio.h>
@@ -36,7 +35,7 @@ static void kd(Pt* a, int n, int axis) {
     kd(a + h, n - h, 1 - axis);
 }
 
-template <bool kShort, bool kPair, class M, class IdsOf>
+template <bool kShort, class M, class IdsOf>
 static std::vector<int32_t> run_mesh(const M& mesh, const std::vector<Pt>& P, IdsOf ids_of) {
     const int m = (int)P.size();
     std::vector<int> order(m), oxy(m);
@@ -54,10 +53,7 @@ static std::vector<int32_t> run_mesh(const M& mesh, const std::vector<Pt>& P, Id
         unsigned* fr = FR.data() + (size_t)(d & 1) * m;
         const unsigned* cfl = FL.data() + (size_t)((d + 1) & 1) * m;
         const unsigned* cfr = FR.data() + (size_t)((d + 1) & 1) * m;
-        for (unsigned j = 0; j < (1u << d); j++) {
-            if (kPair) dt_node2<kShort, HostPair>(mesh, m, d, j, order.data(), oxy.data(), cfl, cfr, fl, fr);
-            else dt_node<kShort>(mesh, m, d, j, order.data(), oxy.data(), cfl, cfr, fl, fr);
-        }
+        for (unsigned j = 0; j < (1u << d); j++) dt_node<kShort>(mesh, m, d, j, order.data(), oxy.data(), cfl, cfr, fl, fr);
     }
     std::vector<int32_t> out;
     for (int t = 1; t < 2 * m - 1; t++) {
@@ -112,17 +108,14 @@ int main(int argc, char** argv) {
         std::vector<Pt> Q = P;
         kd(Q.data(), m, 0);
         const size_t nrec = 2 * (size_t)m + 2;
-        for (int form = 0; form < 8; form++) {
+        for (int form = 0; form < 4; form++) {
             std::vector<int32_t> got;
-            const bool pairf = form >= 4;
-            const int f4 = form & 3;
-            if (f4 < 2) {
+            if (form < 2) {
                 std::vector<int> ids(4 * nrec, 0x5a5a5a5a), xys(4 * nrec, 0x5a5a5a5a);
                 std::vector<unsigned> nbr(4 * nrec, 0x5a5a5a5au);
                 MeshG g{ids.data(), xys.data(), nbr.data()};
                 auto ids_of = [&](int t, int v[3]) { v[0] = ids[4 * t]; v[1] = ids[4 * t + 1]; v[2] = ids[4 * t + 2]; };
-                got = pairf ? (f4 == 0 ? run_mesh<false, true>(g, Q, ids_of) : run_mesh<true, true>(g, Q, ids_of))
-                            : (f4 == 0 ? run_mesh<false, false>(g, Q, ids_of) : run_mesh<true, false>(g, Q, ids_of));
+                got = form == 0 ? run_mesh<false>(g, Q, ids_of) : run_mesh<true>(g, Q, ids_of);
             } else {
                 if (m > 8000) continue;
                 std::vector<uint64_t> mem(3 * nrec, 0x5a5a5a5a5a5a5a5aull);
@@ -131,8 +124,7 @@ int main(int argc, char** argv) {
                     const Rec rc = l.load((unsigned)t * 4u);
                     v[0] = rc.id0; v[1] = rc.id1; v[2] = rc.id2;
                 };
-                got = pairf ? (f4 == 2 ? run_mesh<false, true>(l, Q, ids_of) : run_mesh<true, true>(l, Q, ids_of))
-                            : (f4 == 2 ? run_mesh<false, false>(l, Q, ids_of) : run_mesh<true, false>(l, Q, ids_of));
+                got = form == 2 ? run_mesh<false>(l, Q, ids_of) : run_mesh<true>(l, Q, ids_of);
             }
             if (got != want) {
                 bad++;
@@ -144,7 +136,7 @@ int main(int argc, char** argv) {
         sets++;
         tris += nt;
     }
-    printf("dt_core_check: %ld point sets x 8 forms (one lane / a lane pair, two storages, shortcut on / off), %ld triangles, mismatches %ld, shortcuts taken %ld, shortcuts wrong %ld\n",
+    printf("dt_core_check: %ld point sets x 4 forms (two storages, shortcut on / off), %ld triangles, mismatches %ld, shortcuts taken %ld, shortcuts wrong %ld\n",
            sets, tris, bad, g_short_taken, g_short_bad);
     return bad || g_short_bad ? 1 : 0;
 }

@@ -298,7 +298,8 @@ def test_no_leak_over_100_failures(svhip, pair):
             pass
         arm(svhip, "")
 
-    for i in range(8):
+    # free device memory after 50 failures and after 100 more: no growth (lanes are trimmed before each reading)
+    for i in range(50):
         round_(i)
     svhip.trim()
     before = free_bytes()
@@ -306,7 +307,7 @@ def test_no_leak_over_100_failures(svhip, pair):
         round_(i)
     svhip.trim()
     after = free_bytes()
-    assert abs(before - after) <= 8 << 20, (before, after)
+    assert before - after <= 4 << 20, (before, after)
     st, D1, D2 = e.process_batch(I1, I2)
     assert all(s == 0 for s in st) and np.array_equal(D1[7], g1)
     svhip.set_group(16)

@@ -11,13 +11,16 @@ run() {  # name counters
 }
 run issue GRBM_GUI_ACTIVE,SQ_BUSY_CYCLES,SQ_WAVES,SQ_WAVE_CYCLES,SQ_INSTS_VALU,SQ_ACTIVE_INST_VALU,SQ_INSTS_LDS,SQ_ACTIVE_INST_LDS,SQ_WAIT_INST_LDS "$@"
 run wait GRBM_GUI_ACTIVE,SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_ANY,SQ_INSTS_SALU,SQ_INST_CYCLES_SALU,SQ_INSTS_VMEM_RD,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE "$@"
-run mem GRBM_GUI_ACTIVE,FETCH_SIZE,WRITE_SIZE "$@"
+run fetch FETCH_SIZE "$@"
+run write WRITE_SIZE "$@"
 python - <<PY
 import json
-for n in ("issue", "wait", "mem"):
+for n in ("issue", "wait", "fetch", "write"):
     try:
         d = json.loads(open("$O/devcount_%s$SUF.json" % n).read().strip().splitlines()[-1])
         print(n, round(d["value"]), json.dumps(d.get("devcount", {}).get("counters")))
     except Exception as e:
         print(n, "no line:", e)
 PY
+python tools/devcount_summary.py $O/devcount_issue$SUF.json $O/devcount_wait$SUF.json $O/devcount_fetch$SUF.json $O/devcount_write$SUF.json > $O/devcount$SUF.json
+python -c "import json; print(json.dumps(json.load(open('$O/devcount$SUF.json'))['derived']))"

@@ -66,8 +66,13 @@ hipError_t hipStreamQuery(hipStream_t s) {
 namespace svh {
 static thread_local std::string t_err;
 int fail(int code, const std::string& msg) { t_err = msg; return code; }
-bool fi_armed() { return false; }
-bool fi_hit(const char*) { return false; }
+// fault injection under the sanitizers: SVH_SAN_FAIL_EVERY=n makes every n-th HIP call the engines check fail
+// (any kind), so that their error paths -- early returns out of recording passes, helper-pool phases, the prefetch
+// hand-over -- run under TSan / ASan with 16 threads around them
+static const long g_fi_every = getenv("SVH_SAN_FAIL_EVERY") ? atol(getenv("SVH_SAN_FAIL_EVERY")) : 0;
+static std::atomic<long> g_fi_n{0};
+bool fi_armed() { return g_fi_every > 0; }
+bool fi_hit(const char*) { return g_fi_every > 0 && (g_fi_n.fetch_add(1) + 1) % g_fi_every == 0; }
 void report_hip_failure(const char*) {}
 }  // namespace svh
 extern "C" const char* svh_last_error(void) { return svh::t_err.c_str(); }
@@ -144,7 +149,15 @@ int main(int argc, char** argv) {
     const int K = argc > 1 ? atoi(argv[1]) : 16, frames = argc > 2 ? atoi(argv[2]) : 12;
     const int W = 640, H = 200;
     std::atomic<int> bad{0};
-    std::atomic<long> matches{0};
+    std::atomic<long> matches{0}, injected{0};
+    const bool inject = svh::fi_armed();
+    // a negative return is a failure of the run -- unless failures are being injected: then it must be SVH_ERR_HIP
+    // (or the bad-argument answer of an entry whose hand-over was lost with the failed call), and is counted
+    auto check = [&](int32_t rc) {
+        if (rc >= 0) return;
+        if (inject && (rc == SVH_ERR_HIP || rc == SVH_ERR_BAD_ARG)) injected++;
+        else bad++;
+    };
     auto sequence = [&](int id) {
         svh_vo_params p;
         svh_vo_params_default(&p);
@@ -158,8 +171,7 @@ int main(int argc, char** argv) {
                 I1[i] = (uint8_t)(svh::mix((uint32_t)(i + 977 * f + 31 * id)) >> 24);
                 I2[i] = (uint8_t)(svh::mix((uint32_t)(i + 977 * f + 31 * id + 5)) >> 24);
             }
-            const int32_t rc = svh_vo_process(vo, I1.data(), I2.data(), dims, 0);
-            if (rc < 0) bad++;
+            check(svh_vo_process(vo, I1.data(), I2.data(), dims, 0));
             matches += svh_vo_num_matches(vo);
         }
         svh_vo_destroy(vo);
@@ -175,8 +187,8 @@ int main(int argc, char** argv) {
             std::vector<uint8_t> I((size_t)W * H, (uint8_t)(r * 7));
             const int32_t dims[3] = {W, H, W};
             for (int f = 0; f < 2; f++) {
-                if (svh_matcher_push_back(m, I.data(), I.data(), dims, 0) < 0) bad++;
-                if (svh_matcher_match_features(m, 2, nullptr) < 0) bad++;
+                check(svh_matcher_push_back(m, I.data(), I.data(), dims, 0));
+                check(svh_matcher_match_features(m, 2, nullptr));
             }
             svh_matcher_destroy(m);
         }
@@ -211,12 +223,16 @@ int main(int argc, char** argv) {
             }
             // thread 1: images with the call; thread 2: the pipelined loop (frame f handed over one call earlier)
             if (id == 1) {
-                if (svh_vo_process_batch(vs.data(), n, p1.data(), p2.data(), dims, 0, ok.data()) < 0) bad++;
+                check(svh_vo_process_batch(vs.data(), n, p1.data(), p2.data(), dims, 0, ok.data()));
             } else {
                 if (f == 0) {
-                    if (svh_vo_prefetch_batch(vs.data(), n, p1.data(), p2.data(), dims) < 0) bad++;
-                } else if (svh_vo_process_next_batch(vs.data(), n, p1.data(), p2.data(), dims, 0, ok.data()) < 0) {
-                    bad++;   // (processes frame f - 1, hands over frame f)
+                    check(svh_vo_prefetch_batch(vs.data(), n, p1.data(), p2.data(), dims));
+                } else {
+                    // (processes frame f - 1, hands over frame f)
+                    const int32_t rc = svh_vo_process_next_batch(vs.data(), n, p1.data(), p2.data(), dims, 0, ok.data());
+                    check(rc);
+                    // a failed call may have lost the hand-over of frame f: hand it over again (refused when it is pending)
+                    if (rc < 0 && inject) (void)svh_vo_prefetch_batch(vs.data(), n, p1.data(), p2.data(), dims);
                 }
             }
             for (int i = 0; i < n; i++) matches += svh_vo_num_matches(vs[i]);
@@ -226,7 +242,7 @@ int main(int argc, char** argv) {
     th.emplace_back(lockstep, 1);
     th.emplace_back(lockstep, 2);
     for (std::thread& t : th) t.join();
-    printf("sanitize_viso: %d sequences x %d frames + 1 Matcher thread + 2 lockstep threads, %ld matches seen, %d failures\n",
-           K, frames, matches.load(), bad.load());
+    printf("sanitize_viso: %d sequences x %d frames + 1 Matcher thread + 2 lockstep threads, %ld matches seen, %d failures"
+           ", %ld injected HIP failures reported\n", K, frames, matches.load(), bad.load(), injected.load());
     return bad.load() ? 1 : 0;
 }
