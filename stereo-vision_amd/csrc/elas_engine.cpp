@@ -383,7 +383,9 @@ struct Pool {
 };
 
 static std::mutex g_mu;
-static std::map<int, Pool*> g_pools;
+// (the pools live as long as the process -- batch crew and stream workers may still be parked on them at exit -- and
+// stay reachable through this never-destroyed map, so that leak checkers do not report them)
+static std::map<int, Pool*>& g_pools = *new std::map<int, Pool*>();
 static std::atomic<int> g_lanes{8};
 static std::atomic<int> g_group{16};
 static std::atomic<bool> g_group_set{false};   // svh_elas_set_group was called: take the value as is
