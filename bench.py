@@ -619,7 +619,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0,
                     help="double-buffered pipeline workers per GPU (0 = auto: 1.5 per available core, <= 24)")
     ap.add_argument("--group", type=int, default=0,
-                    help="pairs per kernel launch, 1..32 (0 = 32 for kitti; hd1080: 8 for steps of 32 pairs "
+                    help="pairs per kernel launch, 1..32 (0 = 32 for kitti; hd1080: 16 for steps of 32 pairs "
                          "or more, else 1 on the host stage and 2 on the device stage)")
     ap.add_argument("--spinup", type=float, default=1.0,
                     help="seconds of untimed steps before the warmup (GPU clocks, lane buffers)")
@@ -694,7 +694,10 @@ def main():
         if args.workload != "hd1080":
             args.group = 32
         elif (args.batch >= 32 or args.api in ("auto", "stream")) and args.stage != "host":
-            args.group = 8            # a deep step / a stream: the library's automatic mode takes the device stage
+            # a deep step / a stream: the library's automatic mode takes the device stage.  16 pairs per launch
+            # (round 5 sweep on one box: 8 -> 6.55 k, 16 -> 7.14-7.28 k, 24 -> 7.27 k pairs/s; 32 with 6 workers
+            # collapses to 4.5 k: 12 lanes x 32 pairs x 2 MP of buffers no longer overlap anything)
+            args.group = 16
         else:
             args.group = 2 if args.stage == "device" else 1
 

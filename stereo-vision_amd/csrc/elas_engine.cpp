@@ -390,11 +390,12 @@ static std::atomic<int> g_lanes{8};
 static std::atomic<int> g_group{16};
 static std::atomic<bool> g_group_set{false};   // svh_elas_set_group was called: take the value as is
 // pairs per launch for an image of N pixels: the default (16) is meant for KITTI-size pairs, whose
-// group holds ~0.75 GB of lane buffers; larger images get proportionally smaller groups
+// group holds ~0.75 GB of lane buffers; much larger images get proportionally smaller groups (1920x1080 still
+// 16: round 5 measured 6.5 k pairs/s at 8 per launch, 7.1-7.3 k at 16; a lane then holds ~2 GB)
 static int group_for(size_t N) {
     const int g = std::max(1, std::min(g_group.load(), kMaxGroup));
     if (g_group_set.load()) return g;
-    return (int)std::max<size_t>(1, std::min<size_t>(g, (size_t)8 * 1024 * 1024 / std::max<size_t>(N, 1)));
+    return (int)std::max<size_t>(1, std::min<size_t>(g, (size_t)32 * 1024 * 1024 / std::max<size_t>(N, 1)));
 }
 
 static Pool* pool_for(int device) {

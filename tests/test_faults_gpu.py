@@ -279,41 +279,58 @@ def test_close_wakes_a_producer_blocked_on_a_full_stream(svhip, pair):
     assert out == [svhip.ERR_BAD_ARG], out      # "stream is closing"
 
 
-def test_no_leak_over_100_failures(svhip, pair):
-    prm, l, r, g1, g2 = pair
-    e = svhip.Elas(prm)
-    svhip.set_lanes(2)
-    svhip.set_group(4)
+def leak_trace():
+    """free device memory (bytes) before every tenth of 150 injected failures -- single calls and batches, every kind,
+    the lane pool trimmed before each reading -- and after the last one, then one good batch"""
+    import svhip as S
+    S.lib().svh_test_fail_at.argtypes = [C.c_char_p]
+    z = np.load(os.path.join(H.GOLDEN, "urban3_demo.npz"))
+    prm = H.ElasParams.from_buffer_copy(z["params"].tobytes())
+    l, r = H.golden_pair(str(z["crop"]))
+    e = S.Elas(prm)
+    S.set_lanes(2)
+    S.set_group(4)
     I1 = np.stack([l] * 8)
     I2 = np.stack([r] * 8)
-
-    def round_(i):
-        kind = KINDS[i % 4]
-        if kind == "malloc":
-            svhip.trim()
-        if not os.environ.get("SVH_TEST_NOINJECT"):
-            arm(svhip, "%s:%d" % (kind, 1 + i % 5))
-        try:
-            e.process_batch(I1, I2) if i % 2 else e.process(l, r)
-        except svhip.SvhError:
-            pass
-        arm(svhip, "")
-
-    # free device memory after 50 failures and after 100 more: no growth (lanes are trimmed before each reading)
+    failed = 0
     trace = []
     for i in range(150):
         if i % 10 == 0:
-            svhip.trim()
+            S.trim()
             trace.append(free_bytes())
-        round_(i)
-    svhip.trim()
+        kind = KINDS[i % 4]
+        if kind == "malloc":
+            S.trim()
+        arm(S, "%s:%d" % (kind, 1 + i % 5))
+        try:
+            e.process_batch(I1, I2) if i % 2 else e.process(l, r)
+        except S.SvhError:
+            failed += 1
+        arm(S, "")
+    S.trim()
     trace.append(free_bytes())
-    print("free device memory every 10 injected failures (MB):", [round((trace[0] - t) / 2**20, 1) for t in trace])
-    before, after = trace[5], trace[-1]
-    assert before - after <= 4 << 20, (before, after)
     st, D1, D2 = e.process_batch(I1, I2)
-    assert all(s == 0 for s in st) and np.array_equal(D1[7], g1)
-    svhip.set_group(16)
+    good = all(x == 0 for x in st) and bool(np.array_equal(D1[7].ravel(), z["d1"]))
+    return {"free_bytes": trace, "failed_calls": failed, "next_call_good": good}
+
+
+def test_no_leak_over_150_failures():
+    """in a process of its own: the HIP runtime the library is linked against, nothing else in the address space (in
+    the test process torch's bundled runtime is loaded as soon as pytest has collected test_multirank.py, and under
+    it plain hipMalloc / hipFree cycles of the lane pool -- with or without failures -- let the reported free memory
+    drift by ~1 MB per cycle)"""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "leak_trace"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    t = d["free_bytes"]
+    print("free device memory, MB below the first reading, every 10 failures:", [round((t[0] - x) / 2**20, 1) for x in t])
+    assert d["failed_calls"] >= 60 and d["next_call_good"], d      # (an injection aimed past the last call of its kind misses)
+    # the first ten calls load code objects and start the crew (a one-time step); from then on: flat
+    assert max(t[1] - x for x in t[1:]) <= 4 << 20, t
 
 
 # ---------------------------------------------------------------- Matcher / visual odometry
@@ -431,3 +448,11 @@ def test_vo_lockstep_pipelined_loop(svhip, kind):
         rc, ok = H.product_vo_process_next_batch(vos, frames[1], frames_r[1], shape)
         rc, ok = H.product_vo_process_next_batch(vos, None, None, shape)
         assert rc >= K // 2, (kind, n, rc, ok)
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(H.ROOT, "stereo-vision_amd"))
+    if sys.argv[1:] == ["leak_trace"]:
+        print(json.dumps(leak_trace()))

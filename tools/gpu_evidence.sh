@@ -10,18 +10,22 @@ ulimit -c 0
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/evidence
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 mkdir -p $O
 GRAFT_REPO_ROOT=$R timeout 600 bash $R/tools/gpu_pmc_all.sh > $O/pmc_summary.txt 2>&1
 cp $R/gpurun_out/pmc_issue.json $R/gpurun_out/pmc_traffic.json $O/
 cp $R/gpurun_out/pmc_issue.json $R/profiles/${ROUND}_pmc_issue.json
 cp $R/gpurun_out/pmc_traffic.json $R/profiles/${ROUND}_pmc_traffic.json
+# counters of the overlapped run (device-wide, nothing serialised): tools/devcount.cpp
+make -C $R/tools libdevcount.so > /dev/null 2>&1
+GRAFT_REPO_ROOT=$R timeout 900 bash $R/tools/gpu_devcount.sh > $O/devcount_summary.txt 2>&1
+cp $R/gpurun_out/devcount.json $O/devcount.json
+cp $R/gpurun_out/devcount.json $R/profiles/${ROUND}_devcount.json
 cd $R
 b() { name=$1; shift; timeout 600 python bench.py "$@" > $O/bench_line$name.json 2> $O/bench_line$name.err; }
 b "" --gpus 1 --steps 20 --warmup 5
 Q="--no-extras --no-cpu-baseline"
 b _kitti_stream $Q --steps 10 --warmup 3 --api stream
-b _keyed_matcher $Q --steps 10 --warmup 3
 b _sequence $Q --workload sequence --steps 30 --warmup 5
 b _sequence_batch_api $Q --workload sequence --steps 30 --warmup 5 --api batch
 b _hd1080 $Q --workload hd1080 --steps 20 --warmup 3
@@ -32,6 +36,10 @@ b _hd1080_x256 $Q --workload hd1080 --batch 256 --group 16 --lanes 6 --steps 8 -
 b _2ranks_gloo_1gpu $Q --gpus 2 --steps 10 --warmup 2 --dist-backend gloo
 b _1rank_nccl $Q --force-dist --dist-backend nccl --steps 10 --warmup 3
 b _soak60 $Q --steps 8 --warmup 2 --soak 60
+# SCALE readiness: eight ranks sharing the one GPU over gloo, two workers each, small steps (bookkeeping dry runs)
+b _8ranks_gloo_1gpu_kitti $Q --gpus 8 --dist-backend gloo --steps 4 --warmup 1 --batch 128 --lanes 2
+b _8ranks_gloo_1gpu_sequence $Q --gpus 8 --dist-backend gloo --steps 4 --warmup 1 --workload sequence --lanes 2
+b _8ranks_gloo_1gpu_hd1080 $Q --gpus 8 --dist-backend gloo --steps 4 --warmup 1 --workload hd1080 --lanes 2
 SVH_MATCH_LIST=0 timeout 300 python bench.py $Q --steps 10 --warmup 3 > $O/bench_line_keyed_matcher.json 2> /dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 cd /tmp
