@@ -39,7 +39,7 @@ b _soak60 $Q --steps 8 --warmup 2 --soak 60
 # SCALE readiness: eight ranks sharing the one GPU over gloo, two workers each, small steps (bookkeeping dry runs)
 b _8ranks_gloo_1gpu_kitti $Q --gpus 8 --dist-backend gloo --steps 4 --warmup 1 --batch 128 --lanes 2
 b _8ranks_gloo_1gpu_sequence $Q --gpus 8 --dist-backend gloo --steps 4 --warmup 1 --workload sequence --lanes 2
-b _8ranks_gloo_1gpu_hd1080 $Q --gpus 8 --dist-backend gloo --steps 4 --warmup 1 --workload hd1080 --lanes 2
+b _8ranks_gloo_1gpu_hd1080 $Q --gpus 8 --dist-backend gloo --steps 8 --warmup 2 --workload hd1080 --lanes 2 --group 8   # (16 pairs per launch: the 32 lanes of eight ranks spend these few steps allocating)
 SVH_MATCH_LIST=0 timeout 300 python bench.py $Q --steps 10 --warmup 3 > $O/bench_line_keyed_matcher.json 2> /dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 cd /tmp
