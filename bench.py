@@ -707,7 +707,9 @@ def main():
     # triangulation / pair) occupy their queue while using almost none of the machine: with 16 queues
     # every stream has its own (round 3: 28.2 k pairs/s at 8, 29.6 k at 16, 29.3-29.6 k at 24-32; round 2
     # measured 4 -> 8 at +4 %).  Must be set before the runtime starts; an explicit setting of the caller wins.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # (round 5: libsvhip sets 24 itself when it is loaded -- room for an RCCL communicator's streams -- and a C++
+    # caller gets the same; set here as well so that os.environ, which `hw_queues` below reports, shows it)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     devcount_so = os.path.join(ROOT, "tools", "libdevcount.so")
     if args.devcount:
         if not os.path.exists(devcount_so):

@@ -99,9 +99,13 @@ typedef struct svh_elas svh_elas;
  *                          dense matchers assemble the descriptor rows they stage (same results, 27 % less HBM traffic)
  *   SVH_MATCHER_COPY_KERNEL=0   small pinned transfers of the Matcher / visual odometry by hipMemcpyAsync instead of a
  *                          copy kernel in the stream's own queue
+ *   SVH_UPLOAD_BATCH=0     lockstep prefetch: one k_upload launch per image from the packing threads instead of one
+ *                          recorded launch per camera over the call's objects
  *   SVH_DT_THREADS=256|512|1024, SVH_DT_SPREAD=n, SVH_DT_LDS_KB=n, SVH_DT_SPLIT=0   shape of the device
  *                          triangulation (defaults 512, 64, 96, split on for large point sets)
  *   SVH_DESC_FLY_KEYED=0   subsampling / disp_max > 255 keep the stored descriptor maps
+ *   SVH_HW_QUEUES=n        loading the library sets GPU_MAX_HW_QUEUES=24 (a hardware queue per worker stream + spare)
+ *                          unless the process has set that variable itself; n: another count, 0: leave it alone
  *   SVH_TEST_FAIL_AT=kind:n[:count]   tests: fault injection (svh_test_fail_at below)
  * (the full list with defaults: INTEGRATION.md, "Environment switches")                                      */
 /* Elas::Elas(parameters) -- libelas/src/elas.h:151.  Cheap: callers build one
@@ -186,12 +190,12 @@ int32_t svh_elas_stream_pop_n(svh_elas_stream* s, int32_t n, int32_t* status, in
  * process -- and returns how many it released; the pool regrows on demand. */
 int64_t svh_elas_trim(void);
 
-/* number of batch workers the engine runs per device (each is double-buffered: two HIP streams
- * and buffer sets, the host stage of one group overlaps the device stages of the next) */
+/* number of batch workers the engine runs per device (default 6; each is double-buffered: two HIP
+ * streams and buffer sets, the host stage of one group overlaps the device stages of the next) */
 int32_t svh_elas_set_lanes(int32_t lanes);
-/* pairs a lane pushes through each kernel launch (1..32; default 16 for images up to ~0.5
- * Mpixel, proportionally fewer for larger ones until this is called): batches are cut into
- * groups of this many consecutive pairs */
+/* pairs a lane pushes through each kernel launch (1..32; default 32 for images up to ~1
+ * Mpixel, proportionally fewer for larger ones -- 16 at 1920x1080 -- until this is called):
+ * batches are cut into groups of this many consecutive pairs */
 int32_t svh_elas_set_group(int32_t pairs);
 
 /* where the stages between the two matching phases run (lattice filters elas.cpp:174-279, support

@@ -385,13 +385,30 @@ struct Pool {
 static std::mutex g_mu;
 // (the pools live as long as the process -- batch crew and stream workers may still be parked on them at exit -- and
 // stay reachable through this never-destroyed map, so that leak checkers do not report them)
+// The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and the kernels of one
+// queue run one after the other: a worker's stream then waits behind another worker's k_delaunay / k_lattice (one
+// workgroup per triangulation, ~1 ms, almost none of the machine).  With 16 queues each of the 12 worker streams has
+// its own (4 -> 8: +4 %, 8 -> 16: +5 % pairs/s); 24 leave room for the streams of others in the process -- an RCCL
+// communicator's take queues too (svh_shard with its communicator open: 31.8-32.0 k pairs/s at 16, 34.2 k at 24 and
+// 32; without one 34.1-34.3 k at 16).  The runtime reads the variable when it starts, so it is set when this
+// library is loaded -- unless the process has set it already (the caller's choice wins) or SVH_HW_QUEUES=0.
+__attribute__((constructor)) static void svh_default_hw_queues() {
+    const char* own = getenv("SVH_HW_QUEUES");
+    if (own && atoi(own) <= 0) return;
+    setenv("GPU_MAX_HW_QUEUES", own ? own : "24", /*overwrite=*/0);
+}
+
 static std::map<int, Pool*>& g_pools = *new std::map<int, Pool*>();
-static std::atomic<int> g_lanes{8};
-static std::atomic<int> g_group{16};
+// Defaults = the settings the headline number is measured with (bench.py used to set them itself; a C++ caller
+// of the batch entries got 27-31 k pairs/s instead of 33.6-33.9 k with round 4's 8 workers x 16 pairs and 4 queues):
+// six workers (each double-buffered; more only stretches every kernel's in-run duration), 32 pairs per launch
+// for KITTI-size images, 16 hardware queues (below).
+static std::atomic<int> g_lanes{6};
+static std::atomic<int> g_group{32};
 static std::atomic<bool> g_group_set{false};   // svh_elas_set_group was called: take the value as is
-// pairs per launch for an image of N pixels: the default (16) is meant for KITTI-size pairs, whose
-// group holds ~0.75 GB of lane buffers; much larger images get proportionally smaller groups (1920x1080 still
-// 16: round 5 measured 6.5 k pairs/s at 8 per launch, 7.1-7.3 k at 16; a lane then holds ~2 GB)
+// pairs per launch for an image of N pixels: the default (32) is meant for KITTI-size pairs, whose
+// group holds ~1.5 GB of lane buffers; much larger images get proportionally smaller groups (1920x1080:
+// 16 -- round 5 measured 6.5 k pairs/s at 8 per launch, 7.1-7.3 k at 16, a collapse to 4.5 k at 32)
 static int group_for(size_t N) {
     const int g = std::max(1, std::min(g_group.load(), kMaxGroup));
     if (g_group_set.load()) return g;

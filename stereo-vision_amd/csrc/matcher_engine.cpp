@@ -1118,13 +1118,18 @@ static int32_t prefetch_body(const std::vector<svh_matcher*>& ms, const std::vec
     HIP_TRY(pr.reuse());
     hipStream_t const pf_own = pr.side[0];
     std::vector<int> rcs((size_t)K * ncam, 0);
+    // Lockstep hand-over: the K * ncam image uploads are recorded with the features (one k_upload_b launch per camera
+    // over the K objects instead of one k_upload per image -- 32 launches a call at K = 16); the packing threads then
+    // launch nothing.  SVH_UPLOAD_BATCH=0: every packing thread launches its image's upload as soon as it is packed.
+    static const bool upload_batch = !(getenv("SVH_UPLOAD_BATCH") && atoi(getenv("SVH_UPLOAD_BATCH")) == 0);
+    const bool upload_recorded = lockstep && upload_batch;
     batch_parallel_for(K * ncam, [&](int j) {
         (void)hipSetDevice(ms[0]->device);
         svh_matcher* m = ms[j / ncam];
         const int cam = j % ncam;
         DevView& V = m->next[cam];
         rcs[j] = features_pack(m, V, cam, cam ? I2[j / ncam] : I1[j / ncam], pitch);
-        if (!rcs[j]) {
+        if (!rcs[j] && !upload_recorded) {
             // (all on the stream the features follow on: this work is hidden behind the frame before, so the
             // uploads need not overlap each other -- and the hand-over needs no events)
             mlaunch_upload(lockstep ? pf_own : m->stream2, V.stage, V.I, (size_t)V.bpl * V.h);
@@ -1140,13 +1145,19 @@ static int32_t prefetch_body(const std::vector<svh_matcher*>& ms, const std::vec
         for (int i = 0; i < K && !rc; i++) {
             pr.begin_object();
             for (int cam = 0; cam < ncam && !rc; cam++)
-                rc = features_enqueue(ms[i], ms[i]->next[cam], cam, nullptr, true, ms[i]->h_n + 4);
+                rc = features_enqueue(ms[i], ms[i]->next[cam], cam, nullptr, !upload_recorded, ms[i]->h_n + 4);
         }
         t_rec = nullptr;
         if (rc) return rc;
         if (pr.broken) {
             pr.reset();
             lockstep = false;   // (not reachable with equal parameters and sizes) issue them one by one below
+            if (upload_recorded)
+                for (int i = 0; i < K; i++)
+                    for (int cam = 0; cam < ncam; cam++) {
+                        DevView& V = ms[i]->next[cam];
+                        mlaunch_upload(ms[i]->stream2, V.stage, V.I, (size_t)V.bpl * V.h);
+                    }
             HIP_TRY(hipStreamSynchronize(pf));
         } else {
             HIP_TRY(pr.flush(pf));

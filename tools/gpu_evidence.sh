@@ -40,6 +40,10 @@ b _soak60 $Q --steps 8 --warmup 2 --soak 60
 b _8ranks_gloo_1gpu_kitti $Q --gpus 8 --dist-backend gloo --steps 4 --warmup 1 --batch 128 --lanes 2
 b _8ranks_gloo_1gpu_sequence $Q --gpus 8 --dist-backend gloo --steps 4 --warmup 1 --workload sequence --lanes 2
 b _8ranks_gloo_1gpu_hd1080 $Q --gpus 8 --dist-backend gloo --steps 8 --warmup 2 --workload hd1080 --lanes 2 --group 8   # (16 pairs per launch: the 32 lanes of eight ranks spend these few steps allocating)
+# the C++ driver above the C-ABI (apps/svh_shard.cpp): one rank with its RCCL communicator, four ranks sharing the GPU
+timeout 300 stereo-vision_amd/bin/svh_shard --ranks 1 --gather rccl --pairs-per-rank 6144 --steps 20 --warmup 5 2> /dev/null | grep '^{' > $O/shard_driver_1rank_rccl.json
+timeout 300 stereo-vision_amd/bin/svh_shard --ranks 4 --pairs-per-rank 1536 --steps 20 --warmup 5 2> /dev/null | grep '^{' > $O/shard_driver_4ranks_pipes_1gpu.json
+timeout 300 stereo-vision_amd/bin/svh_shard --ranks 8 --total 430 --steps 20 --warmup 5 --lanes 2 2> /dev/null | grep '^{' > $O/shard_driver_8ranks_sequence_strong.json
 SVH_MATCH_LIST=0 timeout 300 python bench.py $Q --steps 10 --warmup 3 > $O/bench_line_keyed_matcher.json 2> /dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 cd /tmp
