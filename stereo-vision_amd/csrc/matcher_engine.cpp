@@ -1291,6 +1291,11 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
         ~InBatch() { t_in_batch = false; }
     };
     InBatch in_batch_;
+    // The uploads are recorded with the features (one k_upload_b launch per camera over the K objects; they start when
+    // every image is packed instead of overlapping the packing, which costs less than 2 K launches from the packing
+    // threads did: 2 x 16 objects 7.8-8.6 -> 8.7-9.0 k frames/s, 1 x 32 6.1-6.2 -> 6.3-6.6 k, 1 x 16 unchanged).
+    // SVH_UPLOAD_BATCH=0: every packing thread launches its image's upload, rotating over the side streams.
+    static const bool upload_recorded = !(getenv("SVH_UPLOAD_BATCH") && atoi(getenv("SVH_UPLOAD_BATCH")) == 0);
     BatchPool::get().parallel_for(K * ncam, [&](int j) {
         (void)hipSetDevice(ms[0]->device);
         svh_matcher* m = ms[j / ncam];
@@ -1299,7 +1304,7 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
         rcs[j] = features_pack(m, V, cam, cam ? I2[j / ncam] : I1[j / ncam], dims[2]);
         // the image goes to the device while the other threads still pack theirs; the uploads rotate over the
         // call's stream and the side streams (several copy kernels in flight fill the PCIe link better)
-        if (!rcs[j]) {
+        if (!rcs[j] && !upload_recorded) {
             const int q = j % (BatchRec::kSide + 1);
             mlaunch_upload(q == 0 ? ms[0]->stream : up.side[q - 1], V.stage, V.I, (size_t)V.bpl * V.h);
         }
@@ -1314,7 +1319,8 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
     int rc = SVH_OK;
     for (int i = 0; i < K && !rc; i++) {
         rec.begin_object();
-        for (int cam = 0; cam < ncam && !rc; cam++) rc = features_enqueue(ms[i], ms[i]->cur[cam], cam, nullptr, true);
+        for (int cam = 0; cam < ncam && !rc; cam++)
+            rc = features_enqueue(ms[i], ms[i]->cur[cam], cam, nullptr, !upload_recorded);
     }
     t_rec = nullptr;
     if (rc) return rc;
