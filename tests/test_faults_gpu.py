@@ -330,7 +330,9 @@ def test_no_leak_over_150_failures():
     print("free device memory, MB below the first reading, every 10 failures:", [round((t[0] - x) / 2**20, 1) for x in t])
     assert d["failed_calls"] >= 60 and d["next_call_good"], d      # (an injection aimed past the last call of its kind misses)
     # the first ten calls load code objects and start the crew (a one-time step); from then on: flat
-    assert max(t[1] - x for x in t[1:]) <= 4 << 20, t
+    # (free memory is a device-wide reading: under pytest-xdist the other workers' allocations move it)
+    if "PYTEST_XDIST_WORKER" not in os.environ:
+        assert max(t[1] - x for x in t[1:]) <= 4 << 20, t
 
 
 # ---------------------------------------------------------------- Matcher / visual odometry
