@@ -1413,6 +1413,7 @@ __device__ __forceinline__ void dma_slots(uint4* dst, const uint4* src, int n, i
 
 struct MatchList {
     int kIters;      // pixels per thread (template argument of the launch)
+    int half;        // threads per image side (a multiple of 64; the block is 2 * half)
     int Wr;          // raw-row stride (int16)
     int Ws;          // descriptor-row stride in LDS (slots): >= W and == 2 (mod 4), see the staging loop
 };
@@ -1589,7 +1590,7 @@ __device__ __forceinline__ int ml_pixel_checked(const uint4& own, const PixelPla
 }
 
 template <bool kLr, int kIters>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(kIters <= 5 ? 6 : 4, 8))) void k_match_list(GroupDev G, MatchParams P, MatchList Q, DevMaps out,
+__global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_waves_per_eu(kIters <= 5 ? 6 : 4, 8))) void k_match_list(GroupDev G, MatchParams P, MatchList Q, DevMaps out,
                                                     int write_raw, float lr_threshold) {
     extern __shared__ uint4 s_dyn[];   // rows [2][W] | cell records [2][gw][ML_CAP] u16 | raw [2][Wr] int16
     __shared__ int s_band[32];         // P[|k - radius|] << 16
@@ -2459,7 +2460,15 @@ static bool match_list_usable(const svh_elas_params& p, const Dims& d, int32_t p
     MatchList Q;
     Q.Wr = (d.W + 7) / 8 * 8;
     Q.Ws = ((d.W + 1) & ~3) + 2;
-    const int iters = (d.DW + 255) / 256;
+    // threads per side: 256; rows of 1281 .. 1920 px, whose LDS footprint lets two blocks share a CU, take 384 (round
+    // 5: 2 x 12 waves = 6 per SIMD with the 5-pixel instance instead of 2 x 8 = 4 per SIMD with the 8-pixel one)
+    static const bool wide768 = !(getenv("SVH_MATCH_WIDE768") && atoi(getenv("SVH_MATCH_WIDE768")) == 0);
+    int iters = (d.DW + 255) / 256;
+    Q.half = std::min(256, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
+    if (iters > 5 && wide768 && d.DW <= 5 * 384) {
+        iters = (d.DW + 383) / 384;
+        Q.half = std::min(384, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
+    }
     Q.kIters = iters <= 5 ? 5 : 8;
     const size_t ldsl = (size_t)2 * Q.Ws * sizeof(uint4) + (size_t)2 * d.gw * ML_CAP * sizeof(uint16_t) +
                         (size_t)2 * Q.Wr * sizeof(int16_t);
@@ -2538,11 +2547,10 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     const bool use_keyed = match_keyed_usable(p, d, G.prior_absmax, G.plane_radius, lr_out != nullptr, &lds2);
     // round 4: the list form of the keyed kernel (per-cell candidate records, v_sad_hi_u8 keys, LDS-DMA staging)
     {
-        MatchList Q;
+        MatchList Q{};
         size_t ldsl = 0;
         const bool ok = match_list_usable(p, d, G.prior_absmax, G.plane_radius, G.lists != nullptr, &Q, &ldsl);
-        const int iters = (d.DW + 255) / 256;
-        const int half = std::min(256, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
+        const int half = Q.half;
         if (!ok && !use_keyed && G.desc_fly) {
             // descriptors_on_the_fly() and this selection are the same functions of the same arguments; what can
             // differ between the two calls is the driver's answer to the LDS opt-in.  The descriptor maps of this
