@@ -466,7 +466,7 @@ def map_bench(iters=30):
     return out
 
 
-def settings_bench(S, torch, dev, batch=1536, steps=3):
+def settings_bench(S, torch, dev, batch=1536, steps=3, only=None):
     """pairs/s for the parameter sets the APPLICATION uses, next to the headline's plain ROBOTICS preset:
     stereomapper/stereothread.cpp:76-114 (ROBOTICS + support_texture = 30, postprocess_only_left, adaptive mean),
     the same with the GUI's subsampling checkbox (maindialog.cpp:473 -> param.subsampling), and the MIDDLEBURY
@@ -482,6 +482,8 @@ def settings_bench(S, torch, dev, batch=1536, steps=3):
             ("stereomapper (ROBOTICS, support_texture 30)", Hh.robotics(support_texture=30), (u1, u2), (1, "urban2_stereomapper")),
             ("stereomapper + subsampling", Hh.robotics(support_texture=30, subsampling=1), (u1, u2), None),
             ("MIDDLEBURY on cones 640x480", Hh.middlebury(), cones, (0, "cones_middlebury"))):
+        if only is not None and only.lower() not in name.lower():
+            continue
         h, w = a1.shape[1:]
         dh, dw = (h // 2, w // 2) if prm.subsampling else (h, w)
         idx = torch.arange(batch, device=dev) % len(a1)

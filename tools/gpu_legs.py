@@ -1,6 +1,6 @@
 """The secondary legs of bench.py on their own (Matcher, visual odometry, map fusion), so that a
 rocprofv3 kernel trace of this script shows their kernels only:
-    rocprofv3 --kernel-trace --stats -- python tools/gpu_legs.py [matcher|vo|map|replicas[K]|lockstep[TxK]]"""
+    rocprofv3 --kernel-trace --stats -- python tools/gpu_legs.py [matcher|vo|map|replicas[K]|lockstep[TxK]|settings[:name]]"""
 import json
 import os
 import sys
@@ -29,4 +29,8 @@ if which.startswith("lockstep"):   # lockstep, lockstep16, ...
     out["vo_lockstep"] = bench.vo_lockstep_bench(frames=60, private_rand=os.environ.get("LOCKSTEP_LIBC_RAND") is None,
                                                  pipelined=(False, True) if pl is None else (pl == "1",),
                                                  **({"shapes": shapes} if shapes else {}))
+if which.startswith("settings"):   # settings, settings:middlebury, settings:subsampling, settings:texture   (one application_settings leg)
+    import svhip as S
+    out["application_settings"] = bench.settings_bench(S, torch, torch.device("cuda:0"), steps=int(os.environ.get("SETTINGS_STEPS", "3")),
+                                                       only=which.split(":", 1)[1] if ":" in which else None)
 print(json.dumps(out))
