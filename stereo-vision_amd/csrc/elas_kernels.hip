@@ -2189,6 +2189,159 @@ __global__ void k_gap_lines(GroupDev G, DevMaps m, int nside, int DW, int DH, in
     }
 }
 
+// Parallel forms of the general version (round 5; MIDDLEBURY: ipol_gap_width 5000 + add_corners, where the
+// one-thread-per-line walk above was 21 % of the kernel time: a thread walking along a ROW reads 4 bytes per 64-byte
+// line, a thread walking down a COLUMN waits for one dependent load after the other).  A run of invalid pixels is
+// filled from the two valid pixels that bound it, and those are ORIGINAL values (the reference's scan never writes a
+// valid pixel and reads only the pixel before a run and the one that ends it, elas.cpp:1352-1399 / 1446-1491), so
+// every pixel can look up its bounds independently: L = nearest valid index before it, R = nearest valid index after
+// it, fill iff both exist and R - L - 1 <= gap.  The extrapolation (add_corners, :1401-1436 / :1493-1528) concerns
+// only the pixels before the first / after the last valid pixel of the line, which the interior fill never touches.
+//
+// rows: one wave per row.  The row is staged in LDS in chunks of 64; the valid mask of a chunk is a ballot, L / R
+// inside the chunk are bit scans of that mask, across chunks two short uniform loops (last valid index before /
+// first valid index after each chunk).
+constexpr int kGapChunks = 64;   // rows up to 4096 px
+__global__ __launch_bounds__(256) void k_gap_rows_scan(GroupDev G, DevMaps m, int nside, int DW, int DH, int gap,
+                                                       int add_corners) {
+    extern __shared__ float s_gapline[];                 // [4][nch * 64]
+    __shared__ unsigned long long s_mask[4][kGapChunks];
+    __shared__ int s_prev[4][kGapChunks], s_next[4][kGapChunks];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= DH) return;                               // (wave-uniform; the kernel has no block barrier)
+    int pair;
+    float* D = post_map(m, blockIdx.y, nside, &pair);
+    if (!G.hdr->active[pair]) return;
+    float* base = D + (size_t)row * DW;
+    const int nch = (DW + 63) >> 6;
+    float* line = s_gapline + wave * (nch * 64);
+    constexpr int kNone = 1 << 30;
+    int run = -1;
+    for (int k = 0; k < nch; k++) {
+        const int p = 64 * k + lane;
+        const float v = p < DW ? base[p] : -1.f;
+        line[p] = v;
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(v >= 0);
+        s_mask[wave][k] = mk;                            // (every lane stores the same value)
+        s_prev[wave][k] = run;
+        if (mk) run = 64 * k + 63 - __builtin_clzll(mk);
+    }
+    const int pl = run;                                  // last valid pixel of the row, -1 = none
+    int runn = kNone;
+    for (int k = nch - 1; k >= 0; k--) {
+        const unsigned long long mk = s_mask[wave][k];
+        s_next[wave][k] = runn;
+        if (mk) runn = 64 * k + __builtin_ctzll(mk);
+    }
+    const int pf = runn;                                 // first valid pixel, kNone = none
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < nch; k++) {
+        const int p = 64 * k + lane;
+        const float v = line[p];
+        if (p >= DW || v >= 0) continue;
+        const unsigned long long mk = s_mask[wave][k];
+        const unsigned long long lower = mk & ((1ull << lane) - 1ull), upper = mk >> lane;
+        const int L = lower ? 64 * k + 63 - __builtin_clzll(lower) : s_prev[wave][k];
+        const int R = upper ? p + __builtin_ctzll(upper) : s_next[wave][k];
+        float o = v;
+        if (L >= 0 && R != kNone) {
+            if (R - L - 1 <= gap) o = gap_value(line[L], line[R]);
+        } else if (add_corners) {
+            if (L < 0 && R != kNone && p >= pf - gap) o = line[pf];
+            if (L >= 0 && R == kNone && p <= pl + gap) o = line[pl];
+        }
+        if (o >= 0) base[p] = o;
+    }
+}
+
+// columns: 64 columns x kGapSeg row segments per block.  Every thread summarises its segment (first / last valid
+// pixel), the summaries meet in LDS, and each thread then fills its own segment: runs that end inside it from the
+// valid pixel that ends them, the run that reaches the end of the segment from the next segment's first valid pixel.
+constexpr int kGapSeg = 8;
+__global__ __launch_bounds__(64 * kGapSeg) void k_gap_cols_seg(GroupDev G, DevMaps m, int nside, int DW, int DH,
+                                                              int gap, int add_corners) {
+    __shared__ int s_first[kGapSeg][64], s_last[kGapSeg][64];
+    __shared__ float s_fval[kGapSeg][64], s_lval[kGapSeg][64];
+    const int tx = threadIdx.x, seg = threadIdx.y;
+    const int col = blockIdx.x * 64 + tx;
+    int pair;
+    float* D = post_map(m, blockIdx.y, nside, &pair);
+    if (!G.hdr->active[pair]) return;                    // (block-uniform)
+    const bool on = col < DW;
+    const int seg_len = (DH + kGapSeg - 1) / kGapSeg;
+    const int r0 = seg * seg_len, r1 = DH < r0 + seg_len ? DH : r0 + seg_len;
+    float* base = D + (on ? col : 0);
+    constexpr int kB = 8;                                // loads in flight per thread
+    int fi = -1, li = -1;
+    float fv = 0.f, lv = 0.f;
+    if (on) {
+        for (int p0 = r0; p0 < r1; p0 += kB) {
+            float v[kB];
+#pragma unroll
+            for (int j = 0; j < kB; j++) v[j] = p0 + j < r1 ? base[(size_t)(p0 + j) * DW] : -1.f;
+#pragma unroll
+            for (int j = 0; j < kB; j++)
+                if (v[j] >= 0) {
+                    if (fi < 0) { fi = p0 + j; fv = v[j]; }
+                    li = p0 + j;
+                    lv = v[j];
+                }
+        }
+    }
+    s_first[seg][tx] = fi; s_fval[seg][tx] = fv;
+    s_last[seg][tx] = li;  s_lval[seg][tx] = lv;
+    __syncthreads();
+    if (!on) return;
+    int Li = -1, Ri = -1, pf = -1, pl = -1;
+    float Lv = 0.f, Rv = 0.f, pfv = 0.f, plv = 0.f;
+    for (int s2 = 0; s2 < kGapSeg; s2++) {
+        const int f2 = s_first[s2][tx], l2 = s_last[s2][tx];
+        if (f2 < 0) continue;
+        if (pf < 0) { pf = f2; pfv = s_fval[s2][tx]; }
+        pl = l2; plv = s_lval[s2][tx];
+        if (s2 < seg) { Li = l2; Lv = s_lval[s2][tx]; }
+        if (s2 > seg && Ri < 0) { Ri = f2; Rv = s_fval[s2][tx]; }
+    }
+    int last = Li;
+    float lastv = Lv;
+    if (fi >= 0) {
+        for (int p0 = r0; p0 < r1; p0 += kB) {
+            float v[kB];
+#pragma unroll
+            for (int j = 0; j < kB; j++) v[j] = p0 + j < r1 ? base[(size_t)(p0 + j) * DW] : -1.f;
+#pragma unroll
+            for (int j = 0; j < kB; j++) {
+                const int p = p0 + j;
+                if (v[j] >= 0) {
+                    const int count = p - last - 1;
+                    if (last >= 0 && count >= 1 && count <= gap) {
+                        const float di = gap_value(lastv, v[j]);
+                        for (int q = last + 1 > r0 ? last + 1 : r0; q < p; q++) base[(size_t)q * DW] = di;
+                    }
+                    last = p;
+                    lastv = v[j];
+                }
+            }
+        }
+    }
+    // the run that reaches the end of the segment (the whole segment when it holds no valid pixel)
+    if (last < r1 - 1 && last >= 0 && Ri >= 0 && Ri - last - 1 <= gap) {
+        const float di = gap_value(lastv, Rv);
+        for (int q = last + 1 > r0 ? last + 1 : r0; q < r1; q++) base[(size_t)q * DW] = di;
+    }
+    if (add_corners && pf >= 0) {
+        int q0 = pf - gap > 0 ? pf - gap : 0, q1 = pf;                     // [q0, q1): the first valid value upwards
+        q0 = q0 > r0 ? q0 : r0;
+        q1 = q1 < r1 ? q1 : r1;
+        for (int q = q0; q < q1; q++) base[(size_t)q * DW] = pfv;
+        int e0 = pl + 1, e1 = (pl + gap < DH - 1 ? pl + gap : DH - 1) + 1; // [e0, e1): the last valid value downwards
+        e0 = e0 > r0 ? e0 : r0;
+        e1 = e1 < r1 ? e1 : r1;
+        for (int q = e0; q < e1; q++) base[(size_t)q * DW] = plv;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // E15  Elas::adaptiveMean   libelas/src/elas.cpp:1535-1754
 // weight = max(0, 4 - float_from_bits(bits(val - centre) & 0x4F000000)): the
@@ -2652,6 +2805,18 @@ void launch_gap(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, in
         LAUNCH("k_gap_cols", k_gap_local<true>, grid2d(d.DW, d.DH, z), dim3(64, 4), G, out, S, nside,
                d.DW, d.DH, gap);
     } else {
+        static const bool seq = getenv("SVH_GAP_SEQ") && atoi(getenv("SVH_GAP_SEQ")) != 0;   // (A/B: the one-thread-per-line form)
+        const int nch = (d.DW + 63) / 64;
+        if (!seq && nch <= kGapChunks) {
+            {
+                Timed timed_(cx, "k_gap_rows_scan");
+                hipLaunchKernelGGL(k_gap_rows_scan, dim3((d.DH + 3) / 4, z), dim3(256), (size_t)4 * nch * 64 * sizeof(float),
+                                   (hipStream_t)cx.stream, G, out, nside, d.DW, d.DH, gap, (int)p.add_corners);
+            }
+            LAUNCH("k_gap_cols_seg", k_gap_cols_seg, dim3((d.DW + 63) / 64, z), dim3(64, kGapSeg), G, out,
+                   nside, d.DW, d.DH, gap, p.add_corners);
+            return;
+        }
         LAUNCH("k_gap_rows_seq", k_gap_lines<false>, dim3((d.DH + 63) / 64, z), dim3(64), G, out,
                nside, d.DW, d.DH, gap, p.add_corners);
         LAUNCH("k_gap_cols_seq", k_gap_lines<true>, dim3((d.DW + 63) / 64, z), dim3(64), G, out,

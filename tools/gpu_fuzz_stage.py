@@ -1,6 +1,6 @@
 """One-off extended fuzz of the device stage (not part of the test suite): seeded random points of
 Elas::parameters x image shapes, product (svh_elas_set_stage(1), all stage taps) vs the oracle with
-the real Triangle.  python tools/gpu_fuzz_stage.py [first_seed] [count] [dup]
+the real Triangle.  python tools/gpu_fuzz_stage.py [first_seed] [count] [dup|gap]
 "dup": candidate_stepsize 2-3 with lr_threshold 3-4 and noisy pairs, so that coincident right-image
 support points occur (k_delaunay's replay of Triangle's quicksort decides which one survives)."""
 import os
@@ -16,6 +16,7 @@ from test_elas_gpu import product_run  # noqa: E402
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 dup_mode = len(sys.argv) > 3 and sys.argv[3] == "dup"
+gap_mode = len(sys.argv) > 3 and sys.argv[3] == "gap"   # wide interpolation gaps (MIDDLEBURY's 5000), with / without add_corners
 ndup = 0
 shapes = [(320, 200), (401, 177), (512, 160), (288, 240), (640, 480), (1242, 375), (97, 61), (1000, 120)]
 S.set_stage(int(os.environ.get("SVH_FUZZ_STAGE", "1")))   # 1 = device stage (default), 0 = host stage
@@ -31,6 +32,8 @@ for seed in range(first, first + count):
         w, h = [(240, 120), (320, 200), (401, 177), (512, 160)][seed % 4]
         l, r = H.synth_pair(w, h, seed, dmax=30, noise=6)
     else:
+        if gap_mode:
+            prm = prm.copy(ipol_gap_width=[17, 40, 300, 5000][seed % 4], add_corners=(seed // 4) % 2)
         l, r = H.synth_pair(w, h, seed, dmax=min(48, prm.disp_max - 8, w // 4))
     got = product_run(S, prm, l, r)
     want = H.oracle_elas_run(prm, l, r)
