@@ -65,6 +65,8 @@ kt vo python $R/tools/gpu_legs.py vo
 LOCKSTEP_PIPELINED=0 kt vo_lockstep16 python $R/tools/gpu_legs.py lockstep1x16
 LOCKSTEP_PIPELINED=1 kt vo_lockstep16_pipelined python $R/tools/gpu_legs.py lockstep1x16
 kt vo_replicas16 python $R/tools/gpu_legs.py replicas16
+SETTINGS_STEPS=6 kt settings_middlebury python $R/tools/gpu_legs.py settings:middlebury
+SETTINGS_STEPS=6 kt settings_subsampling python $R/tools/gpu_legs.py settings:subsampling
 LOCKSTEP_PIPELINED=0 SVH_MATCHER_TIMING=1 timeout 300 python $R/tools/gpu_legs.py lockstep1x16 2>&1 | python $R/tools/show_lockstep.py > $O/lockstep_phases.txt
 LOCKSTEP_PIPELINED=1 SVH_MATCHER_TIMING=1 timeout 300 python $R/tools/gpu_legs.py lockstep1x16 2>&1 | python $R/tools/show_lockstep.py > $O/lockstep_phases_pipelined.txt
 LOCKSTEP_LIBC_RAND=1 timeout 300 python $R/tools/gpu_legs.py lockstep 2>&1 | python $R/tools/show_lockstep.py > $O/lockstep_libc_rand.txt
