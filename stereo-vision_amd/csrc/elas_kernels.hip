@@ -2201,7 +2201,7 @@ __global__ void k_gap_lines(GroupDev G, DevMaps m, int nside, int DW, int DH, in
 // rows: one wave per row.  The row is staged in LDS in chunks of 64; the valid mask of a chunk is a ballot, L / R
 // inside the chunk are bit scans of that mask, across chunks two short uniform loops (last valid index before /
 // first valid index after each chunk).
-constexpr int kGapChunks = 64;   // rows up to 4096 px
+constexpr int kGapChunks = 48;   // rows up to 3072 px (4 rows x 12 KB + the tables below stay under the 64 KB a launch gets without opting in); wider rows take k_gap_lines
 __global__ __launch_bounds__(256) void k_gap_rows_scan(GroupDev G, DevMaps m, int nside, int DW, int DH, int gap,
                                                        int add_corners) {
     extern __shared__ float s_gapline[];                 // [4][nch * 64]
@@ -2448,15 +2448,13 @@ __global__ __launch_bounds__(256) void k_median(GroupDev G, DevMaps m, PostScrat
             float v[7];
 #pragma unroll
             for (int k = 0; k < 7; k++) v[k] = in[i + (k - 3) * stride];
-            for (int a = 1; a < 7; a++) {
-                float key = v[a];
-                int b = a - 1;
-                while (b >= 0 && v[b] > key) {
-                    v[b + 1] = v[b];
-                    b--;
-                }
-                v[b + 1] = key;
-            }
+            // the reference insertion-sorts the window and takes element 3 (elas.cpp:1790-1800, 1818-1828): the
+            // fourth smallest VALUE, which a 13-exchange selection network yields without data-dependent loops
+            // (disparity maps hold no NaN and no -0: equal values are interchangeable)
+#define SVH_CX(a, b) { const float lo_ = fminf(v[a], v[b]), hi_ = fmaxf(v[a], v[b]); v[a] = lo_; v[b] = hi_; }
+            SVH_CX(0, 5) SVH_CX(0, 3) SVH_CX(1, 6) SVH_CX(2, 4) SVH_CX(0, 1) SVH_CX(3, 5) SVH_CX(2, 6)
+            SVH_CX(2, 3) SVH_CX(3, 6) SVH_CX(4, 5) SVH_CX(1, 4) SVH_CX(1, 3) SVH_CX(3, 4)
+#undef SVH_CX
             res = v[3];
         } else {
             res = gate;

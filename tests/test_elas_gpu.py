@@ -289,6 +289,21 @@ def test_param_fuzz_matches_oracle(seed, svhip, oracle_lib):
     if got.status == 0:
         assert_same(want, got)
 
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
+@pytest.mark.parametrize("gap,corners,w,h", [(17, 0, 320, 200), (40, 1, 401, 177), (5000, 1, 641, 120), (5000, 0, 288, 240),
+                                             (300, 1, 1000, 67), (5000, 1, 97, 61), (5000, 1, 3100, 40)])
+def test_wide_gap_interpolation_matches_oracle(gap, corners, w, h, svhip, oracle_lib):
+    """ipol_gap_width beyond the local kernels' reach (MIDDLEBURY: 5000) with and without the corner extrapolation:
+    the per-row ballot scan and the segmented column pass (k_gap_rows_scan, k_gap_cols_seg) against the oracle's
+    sequential walk (elas.cpp:1330-1530), rows that are not a multiple of 64, columns shorter than 8 segments' worth; rows beyond 3072 px take the one-thread-per-line
+    form (k_gap_lines)"""
+    prm = H.robotics(ipol_gap_width=gap, add_corners=corners, speckle_size=60, lr_threshold=1)
+    l, r = H.synth_pair(w, h, 900 + gap % 97 + w, dmax=40, noise=4)
+    got = product_run(svhip, prm, l, r)
+    want = H.oracle_elas_run(prm, l, r)
+    assert got.status == want.status == 0
+    assert_same(want, got)
+
 @pytest.mark.parametrize("group,workers", [(1, 1), (2, 3), (4, 2), (8, 8)])
 def test_batch_with_failing_pairs(group, workers, svhip, capfd):
     """a batch mixing good pairs with flat ones (< 3 support points): statuses per pair, failed
