@@ -466,7 +466,7 @@ def map_bench(iters=30):
     return out
 
 
-def settings_bench(S, torch, dev, batch=1536, steps=3, only=None):
+def settings_bench(S, torch, dev, batch=1536, steps=8, only=None):
     """pairs/s for the parameter sets the APPLICATION uses, next to the headline's plain ROBOTICS preset:
     stereomapper/stereothread.cpp:76-114 (ROBOTICS + support_texture = 30, postprocess_only_left, adaptive mean),
     the same with the GUI's subsampling checkbox (maindialog.cpp:473 -> param.subsampling), and the MIDDLEBURY
