@@ -106,6 +106,9 @@ typedef struct svh_elas svh_elas;
  *   SVH_DESC_FLY_KEYED=0   subsampling / disp_max > 255 keep the stored descriptor maps
  *   SVH_HW_QUEUES=n        loading the library sets GPU_MAX_HW_QUEUES=24 (a hardware queue per worker stream + spare)
  *                          unless the process has set that variable itself; n: another count, 0: leave it alone
+ *   SVH_MATCH_WIDE768=0    rows of 1281-1920 px: 512-thread blocks (8 pixels per thread) in k_match_list instead of 768
+ *   SVH_GAP_SEQ=1          wide interpolation gaps / add_corners: one thread per line (k_gap_lines) instead of the
+ *                          per-row scan and the segmented column pass
  *   SVH_TEST_FAIL_AT=kind:n[:count]   tests: fault injection (svh_test_fail_at below)
  * (the full list with defaults: INTEGRATION.md, "Environment switches")                                      */
 /* Elas::Elas(parameters) -- libelas/src/elas.h:151.  Cheap: callers build one

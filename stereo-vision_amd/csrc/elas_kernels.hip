@@ -1414,6 +1414,7 @@ __device__ __forceinline__ void dma_slots(uint4* dst, const uint4* src, int n, i
 struct MatchList {
     int kIters;      // pixels per thread (template argument of the launch)
     int half;        // threads per image side (a multiple of 64; the block is 2 * half)
+    int xcd;         // 1: blockIdx -> row in eight contiguous runs, one per XCD
     int Wr;          // raw-row stride (int16)
     int Ws;          // descriptor-row stride in LDS (slots): >= W and == 2 (mod 4), see the staging loop
 };
@@ -1597,7 +1598,16 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
     __shared__ int s_neg;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
-    const int row_id = blockIdx.x;
+    // XCD-aware row order (Q.xcd): workgroups go to the 8 XCDs round-robin by id, and the blocks of neighbouring image
+    // rows read the same Sobel lines (4 of 5), the same cell records (20 rows per cell row) and neighbouring owner
+    // rows.  XCD k therefore takes the k-th eighth of the launch's rows, in order: what neighbours share is served by
+    // that XCD's L2.
+    int row_id = blockIdx.x;
+    if (Q.xcd) {
+        const int total = P.DH * P.npairs, chunk = (total + 7) >> 3;
+        row_id = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+        if (row_id >= total) return;
+    }
     const int pair = row_id / P.DH, v = row_id - pair * P.DH;
     if (!G.hdr->active[pair]) return;
     const size_t N = (size_t)P.W * P.H;
@@ -2621,6 +2631,8 @@ static bool match_list_usable(const svh_elas_params& p, const Dims& d, int32_t p
         Q.half = std::min(384, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
     }
     Q.kIters = iters <= 5 ? 5 : 8;
+    static const bool xcd_rows = !(getenv("SVH_MATCH_XCD") && atoi(getenv("SVH_MATCH_XCD")) == 0);
+    Q.xcd = xcd_rows ? 1 : 0;
     const size_t ldsl = (size_t)2 * Q.Ws * sizeof(uint4) + (size_t)2 * d.gw * ML_CAP * sizeof(uint16_t) +
                         (size_t)2 * Q.Wr * sizeof(int16_t);
     constexpr size_t kListStatic = 256;   // s_band, s_neg
@@ -2711,7 +2723,7 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
         }
         if (ok) {
             Timed timed_(cx, "k_match");
-            const dim3 grid((unsigned)(d.DH * g)), block(2 * half);
+            const dim3 grid((unsigned)(Q.xcd ? (d.DH * g + 7) / 8 * 8 : d.DH * g)), block(2 * half);
             hipStream_t s = (hipStream_t)cx.stream;
             DevMaps none{};
             const DevMaps& o = lr_out ? *lr_out : none;
