@@ -988,7 +988,10 @@ template <bool kFix>
 __global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri_arg, int W, int H, int sub, int fix_all) {
     const int total_tri = total_tri_arg >= 0 ? total_tri_arg : G.hdr->total_tri;   // see k_prior
     const int lane = threadIdx.x & 63;
-    for (int T = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6)); T < total_tri;
+    // (launched with a multiple of 8 workgroups: XCD k takes the k-th eighth of the triangles, which Triangle emits
+    // in an order that keeps neighbours close -- the partial lines two neighbouring triangles write meet in one L2)
+    const int bid = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    for (int T = __builtin_amdgcn_readfirstlane((int)((bid * 256 + threadIdx.x) >> 6)); T < total_tri;
          T += gridDim.x * 4) {
     const TriRaster tr = G.raster[T];
     const int slot = tr.slot, first = tr.first;
@@ -1890,18 +1893,46 @@ __device__ __forceinline__ void lds_union(int* L, int a, int b) {
     }
 }
 
+// XCD-aware tile order of the tile kernels (k_seg_tile, k_gap_tile, k_mean_tile).  Workgroups go to the 8 XCDs
+// round-robin by id, and neighbouring tiles read each other's halo (and share 128-byte lines along their common
+// border): launched as a 1-D grid of xcd_blocks(tiles) workgroups, XCD k takes the k-th eighth of the tiles in
+// row-major order -- whole maps when the launch has 8 or more -- so the halo is served by that XCD's L2.
+// nz == 0: the plain 3-D launch (blockIdx = tile x, tile y, map).
+struct TileIdx {
+    int x, y, z, gx, gy;
+};
+__device__ __forceinline__ bool tile_index(int tw, int th, int DW, int DH, int nz, TileIdx* t) {
+    t->gx = (DW + tw - 1) / tw;
+    t->gy = (DH + th - 1) / th;
+    if (nz == 0) {
+        t->x = blockIdx.x; t->y = blockIdx.y; t->z = blockIdx.z;
+        return true;
+    }
+    const int per = t->gx * t->gy, total = per * nz, chunk = (total + 7) >> 3;
+    const int lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (lin >= total) return false;
+    t->z = lin / per;
+    const int r = lin - t->z * per;
+    t->y = r / t->gx;
+    t->x = r - t->y * t->gx;
+    return true;
+}
+inline unsigned xcd_blocks(int total) { return (unsigned)(((total + 7) >> 3) << 3); }
+
 __global__ __launch_bounds__(256) void k_seg_tile(GroupDev G, DevMaps m, PostScratch S, int nside,
-                                                  int DW, int DH, float thr) {
+                                                  int DW, int DH, float thr, int nz) {
     __shared__ float sD[CY][CX];
     __shared__ int sL[CX * CY];
     __shared__ int sC[CX * CY];
     __shared__ int s_nr;           // tile-local roots listed so far
+    TileIdx tb;
+    if (!tile_index(CX, CY, DW, DH, nz, &tb)) return;   // (block-uniform, before any barrier)
     int pair;
-    const float* D = post_map(m, blockIdx.z, nside, &pair);
+    const float* D = post_map(m, tb.z, nside, &pair);
     if (!G.hdr->active[pair]) return;
     if (threadIdx.y == 0 && threadIdx.x == 0) s_nr = 0;   // (three barriers before its first use)
-    const size_t zo = (size_t)blockIdx.z * DW * DH;
-    const int x0 = blockIdx.x * CX, y0 = blockIdx.y * CY;
+    const size_t zo = (size_t)tb.z * DW * DH;
+    const int x0 = tb.x * CX, y0 = tb.y * CY;
     const int tx = threadIdx.x;   // lane: a wave owns whole tile rows ty = threadIdx.y + 4k
     // step 1: horizontal runs per row with one ballot; label = first pixel of the run
     int len[CY / 4];
@@ -1997,7 +2028,7 @@ __global__ __launch_bounds__(256) void k_seg_tile(GroupDev G, DevMaps m, PostScr
     }
     __syncthreads();
     if (threadIdx.y == 0 && tx == 0)
-        S.nroots[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s_nr;
+        S.nroots[((size_t)tb.z * tb.gy + tb.y) * tb.gx + tb.x] = s_nr;
 }
 
 // unions across tile borders: one thread per pixel of a tile's first row / column
@@ -2600,9 +2631,10 @@ void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     // margin is gone, so such geometries (not 1920x1080 at disp_max 255: 2.6e6) take the exhaustive pass.
     const bool wide = (double)d.H * ((double)d.W + 2.0 * p.disp_max) > 4194304.0;
     const int fix_all = getenv("SVH_OWNER_FIX_ALL") ? atoi(getenv("SVH_OWNER_FIX_ALL")) : (wide ? 1 : 0);   // read per launch: tests toggle it
-    LAUNCH("k_owner", k_owner<false>, dim3((nt + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
+    const dim3 go(xcd_blocks((nt + 3) / 4));   // (a multiple of 8: see the kernel's block order)
+    LAUNCH("k_owner", k_owner<false>, go, dim3(256), G, total_tri, d.W, d.H,
            p.subsampling, 0);
-    LAUNCH("k_owner_fix", k_owner<true>, dim3((nt + 3) / 4), dim3(256), G, total_tri, d.W, d.H,
+    LAUNCH("k_owner_fix", k_owner<true>, go, dim3(256), G, total_tri, d.W, d.H,
            p.subsampling, fix_all);
 }
 
@@ -2793,8 +2825,13 @@ void launch_segments_label(const LaunchCtx& cx, const svh_elas_params& p, const 
     if (p.subsampling) min_size = (int)(sqrtf((float)p.speckle_size) * 2);  // elas.cpp:1218
     const dim3 lin((n + 255) / 256, z), b256(256);
     const dim3 tiles((d.DW + CX - 1) / CX, (d.DH + CY - 1) / CY, z);
-    LAUNCH("k_seg_tile", k_seg_tile, tiles, dim3(CX, 4), G, in, S, nside, d.DW, d.DH,
-           p.speckle_sim_threshold);
+    static const bool tile_xcd = !(getenv("SVH_TILE_XCD") && atoi(getenv("SVH_TILE_XCD")) == 0);
+    if (tile_xcd)
+        LAUNCH("k_seg_tile", k_seg_tile, dim3(xcd_blocks((int)(tiles.x * tiles.y * tiles.z))), dim3(CX, 4), G, in, S, nside,
+               d.DW, d.DH, p.speckle_sim_threshold, z);
+    else
+        LAUNCH("k_seg_tile", k_seg_tile, tiles, dim3(CX, 4), G, in, S, nside, d.DW, d.DH,
+               p.speckle_sim_threshold, 0);
     const int nhor = ((d.DH - 1) / CY) * d.DW;              // pixels on interior horizontal borders
     const int nver = ((d.DW - 1) / CX) * d.DH;              // ... and vertical ones
     if (nhor + nver > 0)
@@ -2865,15 +2902,17 @@ __device__ __forceinline__ float gap_pick(float val, const float* line, int stri
 // min_size > 0: the speckle verdict (E13, k_seg_mask) is applied while the tile is loaded --
 // a pixel of a component below min_size reads as -10 -- so the masked map never goes to memory
 __global__ __launch_bounds__(256) void k_gap_tile(GroupDev G, DevMaps m, PostScratch S, int nside, int DW,
-                                                  int DH, int gap, int min_size) {
+                                                  int DH, int gap, int min_size, int nz) {
     constexpr int HG = 4;
     __shared__ float sA[QY + 2 * HG][QX + 2 * HG];   // D with halo
     __shared__ float sB[QY + 2 * HG][QX];            // row-pass result, rows with halo
+    TileIdx tb;
+    if (!tile_index(QX, QY, DW, DH, nz, &tb)) return;   // (block-uniform, before any barrier)
     int pair;
-    const float* D = post_map(m, blockIdx.z, nside, &pair);
+    const float* D = post_map(m, tb.z, nside, &pair);
     if (!G.hdr->active[pair]) return;
-    float* out = S.tmp + (size_t)blockIdx.z * DW * DH;
-    const int x0 = blockIdx.x * QX, y0 = blockIdx.y * QY;
+    float* out = S.tmp + (size_t)tb.z * DW * DH;
+    const int x0 = tb.x * QX, y0 = tb.y * QY;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     {
         // Rows wave, wave + 4, ... of the tile: 64 columns by the lanes, the 2 HG columns beyond them
@@ -2882,8 +2921,8 @@ __global__ __launch_bounds__(256) void k_gap_tile(GroupDev G, DevMaps m, PostScr
         // of a thread's entries before the next one starts.
         constexpr int AW = QX + 2 * HG, AH = QY + 2 * HG, NR = AH / 4, NE = NR + (AH * 8 + 255) / 256;
         static_assert(AH % 4 == 0 && AW - 64 == 8, "tile shape");
-        const int32_t* L = S.labels + (size_t)blockIdx.z * DW * DH;
-        const int32_t* Cn = S.counts + (size_t)blockIdx.z * DW * DH;
+        const int32_t* L = S.labels + (size_t)tb.z * DW * DH;
+        const int32_t* Cn = S.counts + (size_t)tb.z * DW * DH;
         const int lane = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
         float val[NE];
         int lab[NE];
@@ -3046,18 +3085,20 @@ __device__ __forceinline__ void mean_col_pass(const float* sB, float* D, const f
 
 template <int kTaps>
 __global__ __launch_bounds__(256) void k_mean_tile(GroupDev G, DevMaps m, PostScratch S, int nside, int DW,
-                                                   int DH) {
+                                                   int DH, int nz) {
     constexpr int back = kTaps == 8 ? 3 : 1, lead = kTaps - 1;
     constexpr int HL = lead - back, HR = back;         // taps reach HL before and HR after the centre
     constexpr int AW = QX + HL + HR, AH = QY + HL + HR;
     static_assert((AW + 3) / 4 <= kMeanSub && 4 * kMeanSub <= kMeanSA && QX <= kMeanSB, "tile layout");
     __shared__ float sA[AH * kMeanSA];                 // input (negatives as -10) with halo, swizzled
     __shared__ float sB[AH * kMeanSB];                 // horizontal-pass result (D_tmp), rows with halo
+    TileIdx tb;
+    if (!tile_index(QX, QY, DW, DH, nz, &tb)) return;   // (block-uniform, before any barrier)
     int pair;
-    float* D = post_map(m, blockIdx.z, nside, &pair);
+    float* D = post_map(m, tb.z, nside, &pair);
     if (!G.hdr->active[pair]) return;
-    const float* in = S.tmp + (size_t)blockIdx.z * DW * DH;   // written by k_gap_tile
-    const int x0 = blockIdx.x * QX, y0 = blockIdx.y * QY;
+    const float* in = S.tmp + (size_t)tb.z * DW * DH;   // written by k_gap_tile
+    const int x0 = tb.x * QX, y0 = tb.y * QY;
     const int lane = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
     float orig[QY / 4];
@@ -3134,9 +3175,12 @@ void launch_gap_mean_tiles(const LaunchCtx& cx, const svh_elas_params& p, const 
     const dim3 gr((d.DW + QX - 1) / QX, (d.DH + QY - 1) / QY, g * nside), b(64, 4);
     int min_size = p.speckle_size;
     if (p.subsampling) min_size = (int)(sqrtf((float)p.speckle_size) * 2);  // elas.cpp:1218
-    LAUNCH("k_gap_tile", k_gap_tile, gr, b, G, out, S, nside, d.DW, d.DH, gap, min_size > 1 ? min_size : 0);
-    if (p.subsampling) LAUNCH("k_mean_tile", k_mean_tile<4>, gr, b, G, out, S, nside, d.DW, d.DH);
-    else               LAUNCH("k_mean_tile", k_mean_tile<8>, gr, b, G, out, S, nside, d.DW, d.DH);
+    static const bool tile_xcd = !(getenv("SVH_TILE_XCD") && atoi(getenv("SVH_TILE_XCD")) == 0);
+    const int nz = tile_xcd ? g * nside : 0;
+    const dim3 gl = tile_xcd ? dim3(xcd_blocks((int)(gr.x * gr.y * gr.z))) : gr;
+    LAUNCH("k_gap_tile", k_gap_tile, gl, b, G, out, S, nside, d.DW, d.DH, gap, min_size > 1 ? min_size : 0, nz);
+    if (p.subsampling) LAUNCH("k_mean_tile", k_mean_tile<4>, gl, b, G, out, S, nside, d.DW, d.DH, nz);
+    else               LAUNCH("k_mean_tile", k_mean_tile<8>, gl, b, G, out, S, nside, d.DW, d.DH, nz);
 }
 
 void launch_adaptive_mean(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, int32_t g,
