@@ -988,11 +988,15 @@ template <bool kFix>
 __global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri_arg, int W, int H, int sub, int fix_all) {
     const int total_tri = total_tri_arg >= 0 ? total_tri_arg : G.hdr->total_tri;   // see k_prior
     const int lane = threadIdx.x & 63;
-    // (launched with a multiple of 8 workgroups: XCD k takes the k-th eighth of the triangles, which Triangle emits
-    // in an order that keeps neighbours close -- the partial lines two neighbouring triangles write meet in one L2)
-    const int bid = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    // XCD-aware order (launched with a multiple of 8 workgroups): XCD k takes the k-th eighth of the triangles THERE
+    // ARE (the launch is sized for a bound when the count is only known on the device), which Triangle emits in an
+    // order that keeps neighbours close -- the partial lines two neighbouring triangles write meet in one L2
+    const int need = (((total_tri + 3) >> 2) + 7) >> 3, have = (int)(gridDim.x >> 3);
+    const int per_xcd = need < have ? need : have;          // workgroups per XCD that take part
+    if ((int)(blockIdx.x >> 3) >= per_xcd) return;
+    const int bid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     for (int T = __builtin_amdgcn_readfirstlane((int)((bid * 256 + threadIdx.x) >> 6)); T < total_tri;
-         T += gridDim.x * 4) {
+         T += per_xcd * 32) {
     const TriRaster tr = G.raster[T];
     const int slot = tr.slot, first = tr.first;
     // stored value = owner_base + 1 + triangle index: everything <= owner_base is a leftover of
