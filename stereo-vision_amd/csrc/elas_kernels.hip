@@ -601,13 +601,15 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
                                                      int16_t* __restrict__ dcan_all,
                                                      SupportParams P) {
     extern __shared__ uint4 s_strip[];
-    // XCD-aware block order.  Workgroups go to the 8 XCDs round-robin by linear id, and the
-    // chunks of one lattice row re-read each other's strips (every strip is 2*disp_max wider
-    // than its candidates).  Ids are therefore taken in super-groups of 8*chunks: XCD k gets
-    // all chunks of lattice row q*8+k, so the overlap is served by that XCD's L2, not HBM.
+    // XCD-aware block order.  Workgroups go to the 8 XCDs round-robin by linear id; the chunks of one
+    // lattice row re-read each other's strips (every strip is 2*disp_max wider than its candidates), and
+    // neighbouring lattice rows (5 px apart) read 4 of their 9 Sobel lines in common.  XCD k therefore takes
+    // the k-th contiguous eighth of the (pair, lattice row) list with all chunks of each row (round 2: row
+    // q*8+k, which kept the chunks together and spread neighbouring rows over the eight L2s).
     const int chunks = (P.Wc + kSB - 1) / kSB;
     const int bid = blockIdx.x;
-    const int row_id = (bid / (8 * chunks)) * 8 + (bid & 7);   // (pair, lattice row) pair index
+    const int per_xcd = (P.Hc * P.npairs + 7) >> 3;            // rows per XCD (the grid is 8 * per_xcd * chunks)
+    const int row_id = (bid & 7) * per_xcd + (bid >> 3) / chunks;   // (pair, lattice row) pair index
     if (row_id >= P.Hc * P.npairs) return;
     const int pair = row_id / P.Hc, vc = row_id - pair * P.Hc;
     const int uc0 = ((bid >> 3) % chunks) * kSB;
