@@ -1303,7 +1303,11 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P, 
     // both passes; the first half of the block matches the left map, the second half the right.
     extern __shared__ uint4 s_rows[];   // [2][W]: row of image 1, row of image 2; then raw [2][DW]
     __shared__ int s_P[64];
-    const int row_id = blockIdx.x;      // (pair, image row)
+    // (pair, image row); XCD-aware order as in k_match_list: the grid is a multiple of 8, XCD k takes the k-th
+    // contiguous eighth of the rows
+    const int total_rows = P.DH * P.npairs;
+    const int row_id = (int)(blockIdx.x & 7) * ((total_rows + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (row_id >= total_rows) return;
     const int pair = row_id / P.DH, y = row_id - pair * P.DH;
     if (!G.hdr->active[pair]) return;
     if (threadIdx.x < 64) s_P[threadIdx.x] = (int)threadIdx.x <= P.disp_max ? G.P[threadIdx.x] : 0;
@@ -2784,7 +2788,7 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
         static const int mt = std::min(256, std::max(64, getenv("SVH_MATCH_THREADS") ? atoi(getenv("SVH_MATCH_THREADS")) : 256));
         const int iters = (d.DW + mt - 1) / mt;
         const int half = std::min(256, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
-        const dim3 grid((unsigned)(d.DH * g)), block(2 * half);
+        const dim3 grid(xcd_blocks(d.DH * g)), block(2 * half);   // (a multiple of 8: the kernel's XCD-aware row order)
         hipStream_t s = (hipStream_t)cx.stream;
         if (lr_out) {
             hipLaunchKernelGGL(k_match_keyed<true>, grid, block, lds2, s, G, P, *lr_out, write_raw ? 1 : 0,
