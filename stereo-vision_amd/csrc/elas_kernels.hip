@@ -1621,7 +1621,10 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
         row_id = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
         if (row_id >= total) return;
     }
-    const int pair = row_id / P.DH, v = row_id - pair * P.DH;
+    // subsampling (round 5): the map row y is image row v = 2 y, the map column x image column u = 2 x; descriptors,
+    // cells, planes and ownership stay in image coordinates (elas.cpp:1098-1113)
+    const int mul = P.sub ? 2 : 1;
+    const int pair = row_id / P.DH, y = row_id - pair * P.DH, v = y * mul;
     if (!G.hdr->active[pair]) return;
     const size_t N = (size_t)P.W * P.H;
     uint4* s_rows = s_dyn;
@@ -1678,14 +1681,14 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
     int tk[kIters];
 #pragma unroll
     for (int k = 0; k < kIters; k++) {
-        const int u = x0 + k * half;
+        const int u = (x0 + k * half) * mul;
         tk[k] = own_t[u < P.W ? u : 0];
     }
     const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kIters; k++) {
-        const int u = x0 + k * half;
+        const int u = (x0 + k * half) * mul;
         const int t = tk[k] - G.owner_base - 1;
         tk[k] = (u >= 2 && u < P.W - 2) ? t : -1;
     }
@@ -1698,18 +1701,18 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
                                 (uint32_t)__builtin_amdgcn_readfirstlane(s_band[rad + 2]));
     const uint32_t rows_addr = lds_addr_of(s_rows), rec_addr = lds_addr_of(s_rec) + (uint32_t)(side * P.gw * ML_CAP * 2);
     const uint32_t own_base = rows_addr + (uint32_t)(side * Q.Ws) * 16u, oth_base = rows_addr + (uint32_t)((1 - side) * Q.Ws) * 16u;
-    float* out_row = G.Draw + (size_t)z * P.DW * P.DH + (size_t)v * P.DW;
+    float* out_row = G.Draw + (size_t)z * P.DW * P.DH + (size_t)y * P.DW;
     int16_t* raw_row = s_raw + side * Q.Wr;
     uint32_t cold = 0;     // pixels (bit k) of this wave that need the checked form
 #pragma unroll
     for (int k = 0; k < kIters; k++) {
-        const int u = x0 + k * half;
+        const int x = x0 + k * half, u = x * mul;
         const float4 pl = pl_next;
         if (k + 1 < kIters) {
             pl_next = *reinterpret_cast<const float4*>(G.raster + (tk[k + 1] >= 0 ? (uint32_t)(tri0 + tk[k + 1]) : 0u));
             asm volatile("" ::: "memory");   // the request goes out HERE (hipcc would sink it to its use, a pixel later)
         }
-        if (u < P.DW) {
+        if (x < P.DW) {
             int res = -10;
             const uint4 own = lds_read16(own_base + (uint32_t)(u < P.W ? u : 0) * 16u);
             const bool live = tk[k] >= 0 && (int)texture16(own) >= P.match_texture;
@@ -1738,8 +1741,8 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
                     }
                 }
             }
-            if (!kLr || write_raw) out_row[u] = (float)res;
-            if (kLr) raw_row[u] = (int16_t)res;
+            if (!kLr || write_raw) out_row[x] = (float)res;
+            if (kLr) raw_row[x] = (int16_t)res;
         }
     }
     // the waves that could not take the fast form redo those pixels (everything reloaded: this is the cold path)
@@ -1747,8 +1750,8 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
 #pragma unroll 1
     for (int k = 0; cold >> k; k++) {
         if (!((cold >> k) & 1)) continue;
-        const int u = x0 + k * half;
-        if (u >= P.DW) continue;
+        const int x = x0 + k * half, u = x * mul;
+        if (x >= P.DW) continue;
         int t = own_t[u < P.W ? u : 0] - G.owner_base - 1;
         t = (u >= 2 && u < P.W - 2) ? t : -1;
         const uint4 own = lds_read16(own_base + (uint32_t)(u < P.W ? u : 0) * 16u);
@@ -1760,20 +1763,27 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
         const uint32_t* bits = G.mask + ((size_t)z * cells + (size_t)cr * P.gw + c) * P.gwords;
         const int res = side ? ml_pixel_checked<1>(own, ml_plan<1>(pl, u, v, lrec, P), u, rowaddr, lrec, s_band, P, bits)
                              : ml_pixel_checked<0>(own, ml_plan<0>(pl, u, v, lrec, P), u, rowaddr, lrec, s_band, P, bits);
-        if (!kLr || write_raw) out_row[u] = (float)res;
-        if (kLr) raw_row[u] = (int16_t)res;
+        if (!kLr || write_raw) out_row[x] = (float)res;
+        if (kLr) raw_row[x] = (int16_t)res;
     }
     if (!kLr) return;
     __syncthreads();
     // E12: keep d iff the other map, at the warped position, agrees within lr_threshold
-    float* D = out.D[side] + (size_t)pair * out.stride[side] + (size_t)v * P.DW;
+    float* D = out.D[side] + (size_t)pair * out.stride[side] + (size_t)y * P.DW;
     const int16_t* other = s_raw + (1 - side) * Q.Wr;
     for (int x = x0; x < P.DW; x += half) {
         const int d = raw_row[x];
-        const int uw = side ? x + d : x - d;
         float o = -10.f;
-        if (d >= 0 && uw >= 0 && uw < P.DW)
-            if (!(fabsf((float)other[uw] - (float)d) > lr_threshold)) o = (float)d;
+        if (P.sub) {
+            // the reference's float form (elas.cpp:1150-1175): the warped column is x -+ d / 2
+            const float fd = (float)d, step = fd / 2, uwf = side ? (float)x + step : (float)x - step;
+            if (d >= 0 && uwf >= 0 && uwf < (float)P.DW)
+                if (!(fabsf((float)other[(int)uwf] - fd) > lr_threshold)) o = fd;
+        } else {
+            const int uw = side ? x + d : x - d;
+            if (d >= 0 && uw >= 0 && uw < P.DW)
+                if (!(fabsf((float)other[uw] - (float)d) > lr_threshold)) o = (float)d;
+        }
         D[x] = o;
     }
 }
@@ -2657,7 +2667,8 @@ static bool match_list_usable(const svh_elas_params& p, const Dims& d, int32_t p
     const bool keyed_ok = !ordered && prior_absmax < (1 << 19) && p.disp_max < 512 && plane_radius <= 15 &&
                           d.W < 65536 && p.grid_size > 1;
     static const bool list_off = getenv("SVH_MATCH_LIST") && atoi(getenv("SVH_MATCH_LIST")) == 0;
-    if (!(keyed_ok && !list_off && !p.subsampling && d.gwords <= 8 && have_lists && prior_absmax < 28000 &&
+    static const bool list_sub = !(getenv("SVH_MATCH_LIST_SUB") && atoi(getenv("SVH_MATCH_LIST_SUB")) == 0);
+    if (!(keyed_ok && !list_off && (!p.subsampling || list_sub) && d.gwords <= 8 && have_lists && prior_absmax < 28000 &&
           d.DW <= 8 * 256))
         return false;
     MatchList Q;
