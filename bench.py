@@ -466,13 +466,14 @@ def map_bench(iters=30):
     return out
 
 
-def settings_bench(S, torch, dev, batch=1536, steps=8, only=None):
+def settings_bench(S, torch, dev, batch=6144, steps=3, only=None):
     """pairs/s for the parameter sets the APPLICATION uses, next to the headline's plain ROBOTICS preset:
     stereomapper/stereothread.cpp:76-114 (ROBOTICS + support_texture = 30, postprocess_only_left, adaptive mean),
     the same with the GUI's subsampling checkbox (maindialog.cpp:473 -> param.subsampling), and the MIDDLEBURY
     preset (libelas/src/main.cpp, elas.h:118-146) on the reference's `cones` pair.  Device-resident batches through
-    the same entry as the headline; the first maps of each leg are compared with the reference's own output
-    (tests/golden where a golden exists, oracle/_ref otherwise)."""
+    the same entry as the headline, steps of the headline's size (a call returns when its last pair is done: with
+    1 536 pairs per call the ramp and the drain of the six workers cost 7 %); the first maps of each leg are compared
+    with the reference's own output (tests/golden where a golden exists, oracle/_ref otherwise)."""
     import helpers as Hh
     legs = []
     u1, u2 = urban_inputs()
@@ -497,7 +498,8 @@ def settings_bench(S, torch, dev, batch=1536, steps=8, only=None):
             st = e.process_batch_device(batch, dI1.data_ptr(), dI2.data_ptr(), w * h, dD1.data_ptr(), dD2.data_ptr(),
                                         dw * dh * 4, w, h, w)
             assert all(x == 0 for x in st), [x for x in st if x][:4]
-        step()
+        for _ in range(3):      # untimed: lane pool of the new shape, and the clocks the host-bound legs before let down
+            step()
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(steps):
@@ -709,9 +711,11 @@ def main():
     # triangulation / pair) occupy their queue while using almost none of the machine: with 16 queues
     # every stream has its own (round 3: 28.2 k pairs/s at 8, 29.6 k at 16, 29.3-29.6 k at 24-32; round 2
     # measured 4 -> 8 at +4 %).  Must be set before the runtime starts; an explicit setting of the caller wins.
-    # (round 5: libsvhip sets 24 itself when it is loaded -- room for an RCCL communicator's streams -- and a C++
-    # caller gets the same; set here as well so that os.environ, which `hw_queues` below reports, shows it)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+    # (round 5: libsvhip sets 20 itself when it is loaded -- room for an RCCL communicator's streams, yet few enough
+    # that the idle streams of many Matcher / visual-odometry objects do not open queues that cost the device: see
+    # csrc/elas_engine.cpp -- and a C++ caller gets the same; set here as well so that os.environ, which `hw_queues`
+    # below reports, shows it)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
     devcount_so = os.path.join(ROOT, "tools", "libdevcount.so")
     if args.devcount:
         if not os.path.exists(devcount_so):

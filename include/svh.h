@@ -104,7 +104,7 @@ typedef struct svh_elas svh_elas;
  *   SVH_DT_THREADS=256|512|1024, SVH_DT_SPREAD=n, SVH_DT_LDS_KB=n, SVH_DT_SPLIT=0   shape of the device
  *                          triangulation (defaults 512, 64, 96, split on for large point sets)
  *   SVH_DESC_FLY_KEYED=0   subsampling / disp_max > 255 keep the stored descriptor maps
- *   SVH_HW_QUEUES=n        loading the library sets GPU_MAX_HW_QUEUES=24 (a hardware queue per worker stream + spare)
+ *   SVH_HW_QUEUES=n        loading the library sets GPU_MAX_HW_QUEUES=20 (a hardware queue per worker stream + spare)
  *                          unless the process has set that variable itself; n: another count, 0: leave it alone
  *   SVH_MATCH_WIDE768=0    rows of 1281-1920 px: 512-thread blocks (8 pixels per thread) in k_match_list instead of 768
  *   SVH_GAP_SEQ=1          wide interpolation gaps / add_corners: one thread per line (k_gap_lines) instead of the

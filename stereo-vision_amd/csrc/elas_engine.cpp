@@ -388,14 +388,18 @@ static std::mutex g_mu;
 // The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and the kernels of one
 // queue run one after the other: a worker's stream then waits behind another worker's k_delaunay / k_lattice (one
 // workgroup per triangulation, ~1 ms, almost none of the machine).  With 16 queues each of the 12 worker streams has
-// its own (4 -> 8: +4 %, 8 -> 16: +5 % pairs/s); 24 leave room for the streams of others in the process -- an RCCL
-// communicator's take queues too (svh_shard with its communicator open: 31.8-32.0 k pairs/s at 16, 34.2 k at 24 and
-// 32; without one 34.1-34.3 k at 16).  The runtime reads the variable when it starts, so it is set when this
-// library is loaded -- unless the process has set it already (the caller's choice wins) or SVH_HW_QUEUES=0.
+// its own (4 -> 8: +4 %, 8 -> 16: +5 % pairs/s); a few more leave room for the streams of others in the process -- an
+// RCCL communicator's take queues too (svh_shard with its communicator open: 32.1 k pairs/s at 16, 34.4 k at 20,
+// 34.5 k at 24; without one 34.1-34.3 k at 16).  More is NOT better: every queue that exists costs the device, used or
+// not -- with 40 idle foreign streams in the process (Matcher / visual-odometry objects, torch) the same batches run at
+// 35.1-35.3 k with 16 or 20 queues, 32.6-33.7 k with 24, 28.8-30.1 k with 32, and with 48 or 96 at half and a quarter
+// (profiles/r05_hw_queues_foreign_streams.txt).  Hence 20.  The runtime reads the variable when it starts, so it is
+// set when this library is loaded -- unless the process has set it already (the caller's choice wins) or
+// SVH_HW_QUEUES=0.
 __attribute__((constructor)) static void svh_default_hw_queues() {
     const char* own = getenv("SVH_HW_QUEUES");
     if (own && atoi(own) <= 0) return;
-    setenv("GPU_MAX_HW_QUEUES", own ? own : "24", /*overwrite=*/0);
+    setenv("GPU_MAX_HW_QUEUES", own ? own : "20", /*overwrite=*/0);
 }
 
 static std::map<int, Pool*>& g_pools = *new std::map<int, Pool*>();

@@ -7,6 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")   # (as bench.py does before the runtime starts: a queue per worker stream)
 import torch  # noqa: E402,F401  (HIP runtime of the torch wheel first)
 
 torch.cuda.init()
