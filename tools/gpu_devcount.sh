@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out; mkdir -p $O
 SUF=$1; [ $# -gt 0 ] && shift
 run() {  # name counters
-  timeout 240 python bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline --profile-in-timed-region 0 --devcount "$2" "${@:3}" \
+  timeout 400 python bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline --profile-in-timed-region 0 --devcount "$2" "${@:3}" \
       > $O/devcount_$1$SUF.json 2> $O/devcount_$1$SUF.err
   echo "devcount $1 rc $?"; tail -c 600 $O/devcount_$1$SUF.err
 }
