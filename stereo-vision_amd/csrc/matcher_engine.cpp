@@ -203,32 +203,48 @@ hipError_t BatchRec::reuse() {
     return hipSuccess;
 }
 
-// Parked helper threads for the per-object HOST work of a batch call (outlier votes, prior statistics):
+// Parked helper threads for the per-object HOST work of a batch call (outlier votes, prior statistics, row packing):
 // parallel_for(n, fn) runs fn(0..n-1) on the helpers and the caller, returns when all are done.
+// Several calls may be in flight at once (the prefetch thread packing frame t+1 while the caller votes on frame t,
+// two calling threads with their own objects): every call is a job on the pool's list, the helpers take tasks from
+// the jobs in turn, a caller works on its OWN job only (it returns as soon as that job is done).  Until round 5's
+// last session the calls took turns on a mutex: the packing of the next frame and the votes of this one -- both on
+// the critical path of a pipelined lockstep call -- waited for each other with helpers idle in the tail of either.
+// SVH_POOL_SERIAL=1 keeps the take-turns form (A/B).
 namespace {
 class BatchPool {
+    struct Job {
+        const std::function<void(int)>* fn;
+        int n;
+        int next = 0, done = 0;
+    };
+
 public:
     void parallel_for(int n, const std::function<void(int)>& fn) {
         if (n <= 1) {
             for (int i = 0; i < n; i++) fn(i);
             return;
         }
-        std::lock_guard<std::mutex> one_call(call_mu_);   // batches of several caller threads take turns
+        static const bool serial = getenv("SVH_POOL_SERIAL") && atoi(getenv("SVH_POOL_SERIAL")) != 0;
+        std::unique_lock<std::mutex> one_call(call_mu_, std::defer_lock);
+        if (serial) one_call.lock();
+        Job job{&fn, n};
         {
             std::lock_guard<std::mutex> lk(mu_);
             const int want = std::min(n - 1, max_threads());
             while ((int)threads_.size() < want) threads_.emplace_back(&BatchPool::run, this);
-            fn_ = &fn;
-            n_ = n;
-            next_ = 0;
-            done_ = 0;
-            gen_++;
+            jobs_.push_back(&job);
         }
         cv_.notify_all();
-        work();
         std::unique_lock<std::mutex> lk(mu_);
-        cv_done_.wait(lk, [&] { return done_ == n_; });
-        fn_ = nullptr;
+        while (job.next < job.n) {            // the caller's share of its own job
+            const int i = take(&job);
+            lk.unlock();
+            fn(i);
+            lk.lock();
+            job.done++;
+        }
+        cv_done_.wait(lk, [&] { return job.done == job.n; });   // (the job left the list with its last task)
     }
     static BatchPool& get() {
         static BatchPool* p = new BatchPool();   // leaked on purpose: its threads outlive static destruction
@@ -240,42 +256,31 @@ private:
         static const int n = std::max(1, std::min(15, (int)std::thread::hardware_concurrency() - 1));
         return n;
     }
-    void work() {
-        for (;;) {
-            int i;
-            const std::function<void(int)>* fn;
-            {
-                std::lock_guard<std::mutex> lk(mu_);
-                if (!fn_ || next_ >= n_) return;
-                i = next_++;
-                fn = fn_;
-            }
-            (*fn)(i);
-            bool last;
-            {
-                std::lock_guard<std::mutex> lk(mu_);
-                last = ++done_ == n_;
-            }
-            if (last) cv_done_.notify_all();
-        }
+    // mu_ held: next task of the job; a job whose tasks are all handed out leaves the list
+    int take(Job* j) {
+        const int i = j->next++;
+        if (j->next == j->n) jobs_.erase(std::find(jobs_.begin(), jobs_.end(), j));
+        return i;
     }
     void run() {
-        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
-            }
-            work();
+            cv_.wait(lk, [&] { return !jobs_.empty(); });
+            Job* j = jobs_[turn_++ % jobs_.size()];   // the jobs in turn: neither call starves the other
+            const int i = take(j);
+            const std::function<void(int)>* fn = j->fn;
+            lk.unlock();
+            (*fn)(i);
+            lk.lock();
+            // (the job lives on its caller's stack until done == n, and this is the helper's last touch of it)
+            if (++j->done == j->n) cv_done_.notify_all();
         }
     }
     std::mutex mu_, call_mu_;
     std::condition_variable cv_, cv_done_;
     std::vector<std::thread> threads_;
-    const std::function<void(int)>* fn_ = nullptr;
-    int n_ = 0, next_ = 0, done_ = 0;
-    uint64_t gen_ = 0;
+    std::vector<Job*> jobs_;      // jobs with tasks left to hand out
+    size_t turn_ = 0;
 };
 // One parked thread that runs the host side of svh_matcher_prefetch_batch (row packing on the helper threads,
 // uploads, the recorded feature extraction) while the caller goes on with the frame before.
