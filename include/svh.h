@@ -101,6 +101,8 @@ typedef struct svh_elas svh_elas;
  *                          copy kernel in the stream's own queue
  *   SVH_UPLOAD_BATCH=0     lockstep pushBack / prefetch: one k_upload launch per image from the packing threads instead
  *                          of one recorded launch per camera over the call's objects
+ *   SVH_POOL_SERIAL=1      helper pool of the lockstep entries: parallel_for calls take turns (the form before the job
+ *                          list: A/B runs, profiles/r05_pool_jobs_ab.txt)
  *   SVH_DT_THREADS=256|512|1024, SVH_DT_SPREAD=n, SVH_DT_LDS_KB=n, SVH_DT_SPLIT=0   shape of the device
  *                          triangulation (defaults 512, 64, 96, split on for large point sets)
  *   SVH_DESC_FLY_KEYED=0   subsampling / disp_max > 255 keep the stored descriptor maps
