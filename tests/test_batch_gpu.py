@@ -328,6 +328,61 @@ def test_vo_pipelined_loop_equals_plain_loop(private, K):
             assert len(got) == len(want[i][3][k]) and (got == want[i][3][k]).all(), ("matches", i, k)
 
 
+def test_two_threads_pipelined_vo_loops_equal_plain_loops():
+    """two calling threads, each with K objects in the pipelined loop (svh_vo_prefetch_batch +
+    svh_vo_process_next_batch): the packing of the next frames (prefetch thread) and the outlier votes of both
+    callers are jobs in flight on the one helper pool at the same time -- every object's return values, motions,
+    inliers and matches equal the plain single-threaded loop (private random streams: the draw order of a shared
+    rand() would depend on the interleaving)"""
+    frames, K, T = 6, 4, 2
+    prm = H.vo_defaults()
+    im = quad()
+    seqs = [variant(im, k) for k in range(T * K)]
+
+    def pick(g, i):
+        sq = seqs[g * K:(g + 1) * K]
+        return ([s[0] if i % 2 == 0 else s[2] for s in sq], [s[1] if i % 2 == 0 else s[3] for s in sq])
+    want = []
+    for g in range(T):
+        plain = [H.ProductVo(prm, private_rand=0) for _ in range(K)]
+        rows = []
+        for i in range(frames):
+            _, ok = H.product_vo_process_batch(plain, *pick(g, i))
+            rows.append((list(ok), [v.motion().copy() for v in plain], [v.inliers().copy() for v in plain],
+                         [v.matches().copy() for v in plain]))
+        want.append(rows)
+    shape = seqs[0][0].shape
+    pipes = [[H.ProductVo(prm, private_rand=0) for _ in range(K)] for _ in range(T)]
+    got = [[] for _ in range(T)]
+    errs = []
+
+    def work(g):
+        try:
+            H.product_vo_prefetch_batch(pipes[g], *pick(g, 0))
+            for i in range(frames):
+                nxt = pick(g, i + 1) if i + 1 < frames else (None, None)
+                _, ok = H.product_vo_process_next_batch(pipes[g], nxt[0], nxt[1], shape)
+                got[g].append((list(ok), [v.motion().copy() for v in pipes[g]], [v.inliers().copy() for v in pipes[g]],
+                               [v.matches().copy() for v in pipes[g]]))
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(g,)) for g in range(T)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for g in range(T):
+        assert sum(sum(o == 1 for o in w[0]) for w in want[g]) >= K * (frames - 2)
+        for i in range(frames):
+            assert got[g][i][0] == want[g][i][0], (g, i)
+            for k in range(K):
+                assert np.array_equal(got[g][i][1][k], want[g][i][1][k]), ("motion", g, i, k)
+                assert np.array_equal(got[g][i][2][k], want[g][i][2][k]), ("inliers", g, i, k)
+                a, b = got[g][i][3][k], want[g][i][3][k]
+                assert len(a) == len(b) and (a == b).all(), ("matches", g, i, k)
+
+
 @pytest.mark.parametrize("seed", range(300, 312))
 def test_param_fuzz_lockstep_equals_separate_calls(seed):
     """random points of Matcher::parameters x method x ragged crop x predicted motion (helpers.fuzz_matcher_case,
