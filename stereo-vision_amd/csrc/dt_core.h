@@ -169,7 +169,19 @@ DT_FN long long mad64(int a, int b, long long c) {
     return (long long)a * b + c;
 #endif
 }
+// kPlain: the multiply-adds in plain C++ (a wave that runs ONE merge on all its lanes keeps the walk in scalar
+// registers, and inline assembly with vector operands would make everything behind the test lane-dependent)
+template <bool kPlain = false>
 DT_FN int incircle(const Vtx& a, const Vtx& b, const Vtx& c, const Vtx& d) {
+    if (kPlain) {
+        const int adx = vx(a) - vx(d), ady = vy(a) - vy(d);
+        const int bdx = vx(b) - vx(d), bdy = vy(b) - vy(d);
+        const int cdx = vx(c) - vx(d), cdy = vy(c) - vy(d);
+        const int al = adx * adx + ady * ady, bl = bdx * bdx + bdy * bdy, cl = cdx * cdx + cdy * cdy;
+        const long long det = (long long)al * (bdx * cdy - cdx * bdy) + (long long)bl * (cdx * ady - adx * cdy) +
+                              (long long)cl * (adx * bdy - bdx * ady);
+        return det > 0 ? 1 : (det < 0 ? -1 : 0);
+    }
     const int adx = vx(a) - vx(d), ady = vy(a) - vy(d);
     const int bdx = vx(b) - vx(d), bdy = vy(b) - vy(d);
     const int cdx = vx(c) - vx(d), cdy = vy(c) - vy(d);
@@ -250,7 +262,7 @@ DT_FN void dt_leaf(const M& m, const int* order, const int* oxy, int s, int n, i
 // was chosen, when no flip has rewritten that record since (saves the step's first trip).  The record ranges of the
 // two halves are disjoint, a seam edge of the other side writes into the record of an EARLIER candidate only, and a
 // record is never its own neighbour; the CPU check compares the shortcut with the fresh read on every step.
-template <bool kShort, class M>
+template <bool kShort, class M, bool kPlain = false>
 DT_FN void dt_merge(const M& m, unsigned* farleft_io, unsigned innerleft, unsigned innerright, unsigned* farright_io,
                     int axis, int ctr) {
     unsigned farleft = *farleft_io, farright = *farright_io;
@@ -334,7 +346,7 @@ DT_FN void dt_merge(const M& m, unsigned* farleft_io, unsigned innerleft, unsign
         if (leftdone && rightdone) break;
         if (!leftdone && napL.id >= 0) {
             // strip left-side edges that fail the in-circle test (flips in place)
-            bool bad = incircle(lowerleft, lowerright, upperleft, napL) > 0;
+            bool bad = incircle<kPlain>(lowerleft, lowerright, upperleft, napL) > 0;
             while (bad) {
                 rl_ok = false;
                 unsigned nx = hnext(nxL);
@@ -360,11 +372,11 @@ DT_FN void dt_merge(const M& m, unsigned* farleft_io, unsigned innerleft, unsign
                 nxL = sidec;
                 NL = NS;
                 napL = r_apex(NL, nxL);
-                bad = napL.id >= 0 && incircle(lowerleft, lowerright, upperleft, napL) > 0;
+                bad = napL.id >= 0 && incircle<kPlain>(lowerleft, lowerright, upperleft, napL) > 0;
             }
         }
         if (!rightdone && napR.id >= 0) {
-            bool bad = incircle(lowerleft, lowerright, upperright, napR) > 0;
+            bool bad = incircle<kPlain>(lowerleft, lowerright, upperright, napR) > 0;
             while (bad) {
                 rr_ok = false;
                 unsigned nx = hprev(nxR);
@@ -389,10 +401,10 @@ DT_FN void dt_merge(const M& m, unsigned* farleft_io, unsigned innerleft, unsign
                 nxR = sidec;
                 NR = NS;
                 napR = r_apex(NR, nxR);
-                bad = napR.id >= 0 && incircle(lowerleft, lowerright, upperright, napR) > 0;
+                bad = napR.id >= 0 && incircle<kPlain>(lowerleft, lowerright, upperright, napR) > 0;
             }
         }
-        if (leftdone || (!rightdone && incircle(upperleft, lowerleft, lowerright, upperright) > 0)) {
+        if (leftdone || (!rightdone && incircle<kPlain>(upperleft, lowerleft, lowerright, upperright) > 0)) {
             // new edge lowerleft -> upperright
             m.bond(base, rcand);
             const unsigned nb = hprev(rcand);
@@ -496,7 +508,7 @@ DT_FN void dt_segment(int m, int depth, int i, int* s, int* n) {
 
 // one node of the bottom-up recursion: a leaf, or the merge of its two children (hull handles of the children's
 // depth in cfl / cfr, by first vertex)
-template <bool kShort, class M>
+template <bool kShort, class M, bool kPlain = false>
 DT_FN void dt_node(const M& mesh, int m, int d, unsigned j, const int* order, const int* oxy, const unsigned* cfl,
                    const unsigned* cfr, unsigned* fl, unsigned* fr) {
     int s, n, base;
@@ -508,7 +520,7 @@ DT_FN void dt_node(const M& mesh, int m, int d, unsigned j, const int* order, co
         const int h = n >> 1;
         a = cfl[s];
         b = cfr[s + h];
-        dt_merge<kShort>(mesh, &a, cfr[s], cfl[s + h], &b, d & 1, base + 2 * n - 4);
+        dt_merge<kShort, M, kPlain>(mesh, &a, cfr[s], cfl[s + h], &b, d & 1, base + 2 * n - 4);
     }
     fl[s] = a;
     fr[s] = b;

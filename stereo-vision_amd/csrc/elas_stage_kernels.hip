@@ -412,6 +412,7 @@ struct DtParams {
     int W, H, sup_cap, rec_cap;   // W: columns the points may use (image width + disp_max: the two
                                   // right-image corner points of addCornerSupportPoints lie at W-1+d)
     int spread;                   // depths with at most this many nodes give consecutive nodes to different waves
+    int uniform;                  // 1: depths with no more nodes than waves run one node per wave on all lanes (scalar walk)
 };
 
 // The recursion of the divide and conquer, bottom-up: all nodes of one depth are independent (one
@@ -419,8 +420,11 @@ struct DtParams {
 // of the nodes of a depth, by first vertex, two depths alternating.
 template <int kT, class M>
 __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const int* order, const int* oxy,
-                                         unsigned* FL, unsigned* FR, int sup_cap, int64_t* dbg, bool stamp, int spread) {
+                                         unsigned* FL, unsigned* FR, int sup_cap, int64_t* dbg, bool stamp, int spread, int uniform) {
     const int tid = threadIdx.x;
+    // (block-uniform by construction; said explicitly, they come out of __syncthreads_or loops)
+    m = __builtin_amdgcn_readfirstlane(m);
+    depth = __builtin_amdgcn_readfirstlane(depth);
     if (tid == 0) mesh.make_rec(0);   // record 0 = outer space
     __syncthreads();
     for (int d = depth; d >= 0; d--) {
@@ -439,7 +443,23 @@ __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const 
         constexpr unsigned kWaves = kT / 64;
         const bool spr = spread < 0 || tasks <= (unsigned)spread;
         const unsigned j0 = spr ? (unsigned)(tid & 63) * kWaves + (unsigned)(tid >> 6) : (unsigned)tid;
+        if (uniform > 0 && tasks <= kWaves * (unsigned)uniform) {
+            // P.uniform = n > 0 (SVH_DT_UNIFORM; default: 1 for short groups, see launch_stage_device): a depth with at most n nodes per wave: wave w runs nodes w, w + waves, ..
+            // one after the other on ALL its lanes with identical operands -- every address and every branch is
+            // wave-uniform, so the seam walk compiles to scalar code (s_cbranch instead of exec-mask bookkeeping,
+            // SALU arithmetic, v_readfirstlane behind every record read): 1.46 x faster per merge than one lane.
+            // Measured (profiles/r05_delaunay_scalar_walk.txt): n = 1, 512 threads 672 -> 597 us per 64
+            // triangulations (1024 threads 586), n = 2 618, n = 4 710 (two divergent lanes share half their
+            // instructions, two scalar merges in a row share nothing) -- but the PIPELINE loses 1.2 % with it
+            // (34.3 -> 33.9 k pairs/s, x 3): the scalar unit of a SIMD is shared with the matchers' waves, whose
+            // loop control and waits then queue behind a wave that issues scalar instructions back to back.
+            // Default: on for launches of at most 8 pairs (latency-bound calls), off for the throughput path.
+            const unsigned jw = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
+            // (all 64 lanes run it; with one lane active the same scalar code measured SLOWER: 640 vs 597 us)
+            for (unsigned j = jw; j < tasks; j += kWaves) dt_node<true, M, true>(mesh, m, d, j, order, oxy, cfl, cfr, fl, fr);
+        } else {
         for (unsigned j = j0; j < tasks; j += kT) dt_node<true>(mesh, m, d, j, order, oxy, cfl, cfr, fl, fr);
+        }
         __syncthreads();
         if (stamp && tid == 0 && 11 + (depth - d) < 30) dbg[11 + (depth - d)] = wall_clock64();
     }
@@ -747,7 +767,7 @@ __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
     if (m <= P.lds_cap) {
         MeshL ml;
         ml.base = reinterpret_cast<unsigned char*>(s_hist);      // 24 bytes per record, 2m + 2 records
-        dt_build<kT>(ml, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0, P.spread);
+        dt_build<kT>(ml, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0, P.spread, P.uniform);
         // corner indices out for k_stage_pack (records 1 .. 2m-2)
         // (after coincident points were dropped the triangulation's point p is support point dmap[p])
         auto sid = [&](int a) { return a < 0 ? -1 : (remap ? dmap[a] : a); };
@@ -757,7 +777,7 @@ __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
         }
         __syncthreads();
     } else {
-        dt_build<kT>(mg, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0, P.spread);
+        dt_build<kT>(mg, m, depth, order, oxy, FL, FR, P.sup_cap, S.counts->dbg, slot == 0, P.spread, P.uniform);
         if (remap) {
             for (int t = 1 + tid; t < 2 * m - 1; t += kT) {
                 int4 v = *reinterpret_cast<const int4*>(mg.ids + 4 * (size_t)t);
@@ -971,6 +991,13 @@ void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Di
     const bool big = dt_large(d) && dt_lds_optin(true, 159 * 1024);
     static const int dt_spread = getenv("SVH_DT_SPREAD") ? atoi(getenv("SVH_DT_SPREAD")) : 64;
     D.spread = big ? -1 : dt_spread;      // (large sets: every depth spread)
+    // scalar seam walk (see dt_build): on for SHORT groups -- a launch of at most 8 pairs is a latency-bound call or a
+    // stream of small steps, the device is far from full and nobody competes for the scalar units; off for the 32-pair
+    // launches of the throughput path, where it costs 1.2 %, and for large point sets (records in L2: 8-pair batches of
+    // 1920x1080 lost 5 % with it although the kernel alone got 6 % faster).  KITTI-size batches of 8 pairs through the
+    // batch entry: 6.4 -> 6.7 k pairs/s.  SVH_DT_UNIFORM=0 / n: never / always with n nodes per wave
+    static const int dt_uniform = getenv("SVH_DT_UNIFORM") ? atoi(getenv("SVH_DT_UNIFORM")) : -1;
+    D.uniform = dt_uniform >= 0 ? dt_uniform : (g <= 8 && !big ? 1 : 0);
     const size_t dt_lds = dt_lds_bytes(p, d, big);
     D.lds_ints = (int)(dt_lds / 4);
     D.lds_cap = (int)std::min<size_t>((dt_lds - 32) / 48 - 1, 8000);   // 16-bit handles: < 8191 points

@@ -225,3 +225,19 @@ def test_every_stage_with_descriptors_on_the_fly():
                         os.path.join(here, "test_stage_gpu.py"), os.path.join(here, "test_elas_gpu.py")],
                        env=env, capture_output=True, text=True, cwd=here, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.skipif(os.environ.get("SVH_DT_UNIFORM") is not None, reason="already inside the switched run")
+def test_device_stage_with_the_scalar_seam_walk():
+    """SVH_DT_UNIFORM=1 (read once per process): depths of the triangulation with no more nodes than waves run one
+    merge per wave as wave-uniform (scalar) code -- the goldens, the global-memory forms of large images, the
+    coincident-point corner and part of the parameter fuzz again in a process with the switch set: same triangle
+    lists, order included"""
+    import subprocess
+    import sys
+    env = dict(os.environ, SVH_DT_UNIFORM="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "golden or large_image or coincident or param_fuzz"],
+                       env=env, capture_output=True, text=True, cwd=H.ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
