@@ -891,7 +891,7 @@ def main():
     if in_region and prof_all:
         # timed region: HIP events only around the dominant kernel (2 records per group)
         # (among the kernels that fill the device: see the roofline block below)
-        fill0 = [k for k in prof_all if not k.startswith(("k_delaunay", "k_lattice", "k_stage_pack"))] or list(prof_all)
+        fill0 = [k for k in prof_all if k in ALG_BYTES_DESIGN_PER_PIXEL] or list(prof_all)   # (see the roofline block)
         dom0 = max(fill0, key=lambda k: prof_all[k][0])
         S.lib().svh_profile_only(dom0.encode())
         S.lib().svh_profile_reset()
@@ -992,7 +992,9 @@ def main():
             # (one workgroup per triangulation / pair: k_delaunay, k_lattice and k_stage_pack are latency chains that use
             # almost none of the machine -- they overlap with the other workers' kernels and are not what a roofline
             # describes; the dominant kernel is chosen among the ones that fill the device)
-            fill = [k for k in prof if not k.startswith(("k_delaunay", "k_lattice", "k_stage_pack"))] or list(prof)
+            # -- i.e. among the kernels bench.py has a byte model for: when several ranks share one GPU the in-run time of
+            # every kernel is mostly waiting, and a grid kernel without a model once came out on top with frac > 1)
+            fill = [k for k in prof if k in ALG_BYTES_DESIGN_PER_PIXEL] or list(prof)
             dom = max(fill, key=lambda k: prof[k][0])
             ms, cnt = prof[dom]
             avg_s = ms / cnt / 1e3
