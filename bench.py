@@ -578,12 +578,14 @@ def self_spawn(argv, n):
     return subprocess.call(cmd, env=env)
 
 
-def load_pmc(build):
+def load_pmc(build, suffix=""):
     """the committed rocprofv3 --pmc summaries, only if they were taken on the library that is
     loaded now (tools/pmc_*.py stamp them with svh_version(), which carries the source hash)"""
     import glob
     out = {"traffic": None, "issue": None, "devcount": None, "notes": []}
-    for key, pat in (("traffic", "*_pmc_traffic.json"), ("issue", "*_pmc_issue.json"), ("devcount", "*_devcount.json")):
+    # (suffix "_hd1080": the passes of tools/gpu_pmc_all.sh _hd1080 --workload hd1080)
+    for key, pat in (("traffic", "*_pmc_traffic%s.json" % suffix), ("issue", "*_pmc_issue%s.json" % suffix),
+                     ("devcount", "*_devcount.json")):
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
         if not files:
             continue
@@ -987,7 +989,7 @@ def main():
     roofline = None
     if rank == 0:
         prof = read_profile(S) if in_region else prof_all
-        pmc = load_pmc(build)
+        pmc = load_pmc(build, "_hd1080" if args.workload == "hd1080" else "")
         if prof:
             # (one workgroup per triangulation / pair: k_delaunay, k_lattice and k_stage_pack are latency chains that use
             # almost none of the machine -- they overlap with the other workers' kernels and are not what a roofline
@@ -1065,8 +1067,8 @@ def main():
             alias_back = {"k_support": "k_support_lds", "k_match": "k_match_list", "k_descriptor": "k_descriptor_stream"}
             alias = {v: k for k, v in alias_back.items()}
             alias["k_match_keyed"] = "k_match"
-            # measured HBM traffic of that kernel (rocprofv3 --pmc passes, taken on the KITTI workload)
-            if tr and args.workload != "hd1080":
+            # measured HBM traffic of that kernel (rocprofv3 --pmc passes, taken on this workload's image size)
+            if tr:
                 kk = tr["kernels"].get(dom)
                 if kk:
                     roofline["traffic"] = kk["hbm_bytes"] * gl / tr["pairs_per_launch"]
@@ -1077,7 +1079,7 @@ def main():
             # Issue-slot view of the same launch: wave-level VALU instructions (SQ_INSTS_VALU of the PMC
             # pass, scaled to the pairs per launch) against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64
             # instruction of the SAD / min / compare class (profiles/r03_microbench_valu.txt).
-            if iss and args.workload != "hd1080":
+            if iss:
                 kk = iss["kernels"].get(alias_back.get(dom, dom)) or iss["kernels"].get(dom)
                 if kk:
                     peak = 1024 * 2.4e9 / 4
@@ -1102,7 +1104,7 @@ def main():
             roofline["end_to_end"] = {"alg_bytes_per_pair": ALG_BYTES_PER_PIXEL_PAIR * N_PIX,
                                       "achieved": e2e, "frac": e2e / HBM_PEAK_GBS,
                                       "note": "this rank's pairs; staged model 174.8 B/pixel"}
-            if tr and args.workload != "hd1080":
+            if tr:
                 twice = ("k_adaptive_mean", "k_gap_local", "k_owner")   # two launches per group share a symbol
                 per_pair = sum(v["hbm_bytes"] * (2 if k in twice else 1)
                                for k, v in tr["kernels"].items()) / tr["pairs_per_launch"]
@@ -1137,7 +1139,7 @@ def main():
                 # issue-slot view of the same run: wave-level VALU instructions of one pair (PMC,
                 # kernels serialised) x this run's pairs/s, against 1024 SIMDs issuing one VALU
                 # instruction per 4 cycles at the nominal 2.4 GHz
-                if args.workload != "hd1080":
+                if True:
                     per_pair = sum(v["valu_wave_instr"] for v in iss["kernels"].values()) / float(tr["pairs_per_launch"])
                     rate = B * args.steps / elapsed_local
                     roofline["valu_issue"] = {"wave_instr_per_pair": round(per_pair),
@@ -1162,8 +1164,8 @@ def main():
                                                           overlapped_valu_active=oc.get("valu_active"),
                                                           overlapped_hbm_frac=oc.get("hbm_frac_of_8TBps"))
                 roofline["isolated_kernels_hbm"] = {"source": "profiles/%s + %s (rocprofv3 --pmc, kernels "
-                                                              "serialised, KITTI workload)"
-                                                              % (pmc["traffic_file"], pmc["issue_file"]),
+                                                              "serialised, %s workload)"
+                                                              % (pmc["traffic_file"], pmc["issue_file"], args.workload),
                                                     "top": rows[:5]}
     if use_dist:
         dist.barrier()
