@@ -16,6 +16,11 @@ GRAFT_REPO_ROOT=$R timeout 600 bash $R/tools/gpu_pmc_all.sh > $O/pmc_summary.txt
 cp $R/gpurun_out/pmc_issue.json $R/gpurun_out/pmc_traffic.json $O/
 cp $R/gpurun_out/pmc_issue.json $R/profiles/${ROUND}_pmc_issue.json
 cp $R/gpurun_out/pmc_traffic.json $R/profiles/${ROUND}_pmc_traffic.json
+# the same passes on the 1920x1080 workload (bench.py --workload hd1080 quotes these)
+GRAFT_REPO_ROOT=$R timeout 600 bash $R/tools/gpu_pmc_all.sh _hd1080 --workload hd1080 > $O/pmc_summary_hd1080.txt 2>&1
+cp $R/gpurun_out/pmc_issue_hd1080.json $R/gpurun_out/pmc_traffic_hd1080.json $O/
+cp $R/gpurun_out/pmc_issue_hd1080.json $R/profiles/${ROUND}_pmc_issue_hd1080.json
+cp $R/gpurun_out/pmc_traffic_hd1080.json $R/profiles/${ROUND}_pmc_traffic_hd1080.json
 # counters of the overlapped run (device-wide, nothing serialised): tools/devcount.cpp
 make -C $R/tools libdevcount.so > /dev/null 2>&1
 GRAFT_REPO_ROOT=$R timeout 900 bash $R/tools/gpu_devcount.sh > $O/devcount_summary.txt 2>&1
