@@ -181,6 +181,7 @@ struct Lane {
     hipEvent_t match_ev = nullptr, copy_ev = nullptr;
     bool poll_wait = false;         // batch workers sleep-poll; single calls spin (lowest latency)
     bool parallel_host = true;      // host stage may use helper threads (off when every core is a worker)
+    bool lone_group = true;         // the lane's group is the only one of its call (single call, batch of one group): latency-bound
     // geometry the buffers were sized for
     int32_t W = 0, H = 0, disp_max = -1, step = 0, grid_size = 0, sub = -1, gcap = 0;
     Dims d{};
@@ -627,7 +628,7 @@ static int run_group_body(Lane& L, const svh_elas_params& p, const int32_t* dims
     const Dims& d = L.d;
     hipStream_t s = L.stream;
     L.prof.stream = s;
-    const LaunchCtx cx = {s, g_prof_on.load() ? &L.prof : nullptr};
+    const LaunchCtx cx = {s, g_prof_on.load() ? &L.prof : nullptr, L.lone_group};
     const size_t N = (size_t)W * H, DN = (size_t)d.DW * d.DH;
     const size_t nc = (size_t)d.Wc * d.Hc;
     const bool tapping = taps && taps->enabled;
@@ -1363,6 +1364,7 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
                 // the two triangulations of a pair may run on two threads and the waits block in
                 // the driver; otherwise every core already has a worker and the waits sleep-poll
                 L->parallel_host = ngroups <= lanes;
+                L->lone_group = ngroups == 1;
                 L->poll_wait = !L->parallel_host;
                 // (a failure here -- out of device memory -- is reported by the first run_group on this lane,
                 // which sizes it again and returns the error for its group)
@@ -1425,6 +1427,7 @@ static int32_t batch_impl(svh_elas* e, int32_t n, const int32_t* dims, int32_t* 
                                                nullptr, RG_FINISH));
                 slot[q]->poll_wait = false;
                 slot[q]->parallel_host = true;
+                slot[q]->lone_group = true;
                 release_lane(slot[q]);
             }
     };
@@ -1565,6 +1568,7 @@ static void stream_worker(svh_elas_stream* s) {
         acquire_lanes(s->device, 2, slot);
         for (Lane* L : slot) {
             L->parallel_host = false;
+            L->lone_group = false;
             L->poll_wait = true;      // the workers sleep between polls: a stream must not cost a core per lane
             (void)L->ensure(s->p, s->dims[0], s->dims[1], s->G);   // (a failure is reported by the group's run_group)
         }
@@ -1592,6 +1596,7 @@ static void stream_worker(svh_elas_stream* s) {
         for (Lane*& L : slot) {
             L->poll_wait = false;
             L->parallel_host = true;
+            L->lone_group = true;
             release_lane(L);
             L = nullptr;
         }

@@ -444,7 +444,7 @@ __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const 
         const bool spr = spread < 0 || tasks <= (unsigned)spread;
         const unsigned j0 = spr ? (unsigned)(tid & 63) * kWaves + (unsigned)(tid >> 6) : (unsigned)tid;
         if (uniform > 0 && tasks <= kWaves * (unsigned)uniform) {
-            // P.uniform = n > 0 (SVH_DT_UNIFORM; default: 1 for short groups, see launch_stage_device): a depth with at most n nodes per wave: wave w runs nodes w, w + waves, ..
+            // P.uniform = n > 0 (SVH_DT_UNIFORM; default: 1 for latency-bound calls, see launch_stage_device): a depth with at most n nodes per wave: wave w runs nodes w, w + waves, ..
             // one after the other on ALL its lanes with identical operands -- every address and every branch is
             // wave-uniform, so the seam walk compiles to scalar code (s_cbranch instead of exec-mask bookkeeping,
             // SALU arithmetic, v_readfirstlane behind every record read): 1.46 x faster per merge than one lane.
@@ -453,7 +453,7 @@ __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const 
             // instructions, two scalar merges in a row share nothing) -- but the PIPELINE loses 1.2 % with it
             // (34.3 -> 33.9 k pairs/s, x 3): the scalar unit of a SIMD is shared with the matchers' waves, whose
             // loop control and waits then queue behind a wave that issues scalar instructions back to back.
-            // Default: on for launches of at most 8 pairs (latency-bound calls), off for the throughput path.
+            // Default: on for a group that has the device to itself, off otherwise (launch_stage_device).
             const unsigned jw = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
             // (all 64 lanes run it; with one lane active the same scalar code measured SLOWER: 640 vs 597 us)
             for (unsigned j = jw; j < tasks; j += kWaves) dt_node<true, M, true>(mesh, m, d, j, order, oxy, cfl, cfr, fl, fr);
@@ -991,13 +991,14 @@ void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Di
     const bool big = dt_large(d) && dt_lds_optin(true, 159 * 1024);
     static const int dt_spread = getenv("SVH_DT_SPREAD") ? atoi(getenv("SVH_DT_SPREAD")) : 64;
     D.spread = big ? -1 : dt_spread;      // (large sets: every depth spread)
-    // scalar seam walk (see dt_build): on for SHORT groups -- a launch of at most 8 pairs is a latency-bound call or a
-    // stream of small steps, the device is far from full and nobody competes for the scalar units; off for the 32-pair
-    // launches of the throughput path, where it costs 1.2 %, and for large point sets (records in L2: 8-pair batches of
-    // 1920x1080 lost 5 % with it although the kernel alone got 6 % faster).  KITTI-size batches of 8 pairs through the
-    // batch entry: 6.4 -> 6.7 k pairs/s.  SVH_DT_UNIFORM=0 / n: never / always with n nodes per wave
+    // scalar seam walk (see dt_build): on for a group that is the ONLY one of its call (single call, batch entry with
+    // one group): the device is far from full and nobody competes for the scalar units (batch entry, 8 / 16 / 32 pairs
+    // per call: 6.4 -> 6.7, 11.1 -> 11.8, 17.6 -> 18.6 k pairs/s).  Off where groups share the device -- a batch of six
+    // groups on six workers lost 2 % (31.8 -> 31.1 k), deep batches 1.2 %, streams of 8-pair steps 1.8 % -- and for
+    // large point sets (records in L2: 8-pair batches of 1920x1080 lost 5 % although the kernel alone got 6 %
+    // faster).  SVH_DT_UNIFORM=0 / n: never / always with n nodes per wave
     static const int dt_uniform = getenv("SVH_DT_UNIFORM") ? atoi(getenv("SVH_DT_UNIFORM")) : -1;
-    D.uniform = dt_uniform >= 0 ? dt_uniform : (g <= 8 && !big ? 1 : 0);
+    D.uniform = dt_uniform >= 0 ? dt_uniform : (cx.latency && !big ? 1 : 0);
     const size_t dt_lds = dt_lds_bytes(p, d, big);
     D.lds_ints = (int)(dt_lds / 4);
     D.lds_cap = (int)std::min<size_t>((dt_lds - 32) / 48 - 1, 8000);   // 16-bit handles: < 8191 points

@@ -140,6 +140,7 @@ struct Profiler {
 struct LaunchCtx {
     void* stream;
     Profiler* prof;
+    bool latency = false;   // the group is the only one of its call (single call, batch of one group): nothing else on the device
 };
 
 // images of a group: image k of pair j starts at I[k] + j*stride, rows pitch apart
