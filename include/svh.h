@@ -106,8 +106,9 @@ typedef struct svh_elas svh_elas;
  *   SVH_DT_THREADS=256|512|1024, SVH_DT_SPREAD=n, SVH_DT_LDS_KB=n, SVH_DT_SPLIT=0   shape of the device
  *                          triangulation (defaults 512, 64, 96, split on for large point sets)
  *   SVH_DT_UNIFORM=0|n     scalar (wave-uniform) seam walk of the device triangulation at depths with at most n nodes per
- *                          wave; default: n = 1 for launches of at most 8 KITTI-size pairs, off otherwise (costs the
- *                          throughput path 1.2 %: profiles/r05_delaunay_scalar_walk.txt)
+ *                          wave; default: n = 1 for a group that is the only one of its call (single call, batch of
+ *                          one group: +5 %), off otherwise (costs the throughput path 1.2 %:
+ *                          profiles/r05_delaunay_scalar_walk.txt)
  *   SVH_DESC_FLY_KEYED=0   subsampling / disp_max > 255 keep the stored descriptor maps
  *   SVH_HW_QUEUES=n        loading the library sets GPU_MAX_HW_QUEUES=20 (a hardware queue per worker stream + spare)
  *                          unless the process has set that variable itself; n: another count, 0: leave it alone
