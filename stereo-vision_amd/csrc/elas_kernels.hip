@@ -1371,6 +1371,9 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P, 
         if (kLr) s_raw[side * P.DW + x] = out;
     }
     if (!kLr) return;
+#if SVH_ML_PROBE == 6
+    return;
+#endif
     __syncthreads();
     // E12: keep d iff the other map, at the warped position, agrees within lr_threshold
     float* D = out.D[side] + (size_t)pair * out.stride[side] + (size_t)y * P.DW;
@@ -1407,6 +1410,19 @@ __global__ __launch_bounds__(512) void k_match_keyed(GroupDev G, MatchParams P, 
 //  * rows and lists land by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write
 //    pass; owner words and planes of all of a thread's pixels are requested before the scan starts.
 // ---------------------------------------------------------------------------
+// SVH_ML_PROBE (tools/Makefile `probe`, never in the product build): cut-down instances of k_match_list whose
+// instruction counters, subtracted from one another, give the kernel's VALU split (profiles/r06_match_split.txt):
+//   1 staging only   2 + own descriptor, texture, live vote   3 + plane, plan, votes   4 fast form without the band
+//   5 fast form without the cell loop   6 everything but the L/R pass   7 event counters (g_ml_cnt)   8 no cold redo
+#ifndef SVH_ML_PROBE
+#define SVH_ML_PROBE 0
+#endif
+#if SVH_ML_PROBE == 7
+__device__ unsigned long long g_ml_cnt[16];
+#define ML_CNT(i, n) do { if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_ml_cnt[i], (unsigned long long)(n)); } while (0)
+#else
+#define ML_CNT(i, n) do { } while (0)
+#endif
 constexpr int ML_CAP = 32;     // uint16 per cell record: [0..27] candidates, [28..30] last candidate, [31] count
 constexpr int ML_FAST = 28;    // cells with more candidates are decoded from their bit set
 
@@ -1471,9 +1487,14 @@ __device__ __forceinline__ int ml_pixel_fast(const uint4& own, const PixelPlan& 
     int best = 0x7FFFFFFF;
     // ---- cell candidates, four per trip; rank = list index (ascending d, the reference's order)
     uint2 cc = lds_read8(lrec);
+#if SVH_ML_PROBE == 5
+    if (false) {
+#else
     if (!excl) {
+#endif
         for (int i = 0; __builtin_amdgcn_ballot_w64(i < q.n) != 0; i += 4) {
             const uint2 cn = lds_read8(lrec + 2 * i + 8);   // next trip's four ([28..31] at the end: read, not used)
+            ML_CNT(7, 1); ML_CNT(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < q.n)));
             if (i < q.n) {   // (an empty record is padded with d = 0, which is not a candidate)
                 const uint32_t c0 = cc.x & 0xFFFFu, c1 = cc.x >> 16, c2 = cc.y & 0xFFFFu, c3 = cc.y >> 16;
                 const uint4 o0 = lds_read16(kSide ? rowaddr + c0 : rowaddr - c0);
@@ -1485,12 +1506,17 @@ __device__ __forceinline__ int ml_pixel_fast(const uint4& own, const PixelPlan& 
             }
             cc = cn;
         }
+#if SVH_ML_PROBE == 5
+    } else if (false) {
+#else
     } else {
+#endif
         const uint32_t lo16 = (uint32_t)q.dlo * 16u;
         const uint32_t len16 = q.dhi >= q.dlo ? (uint32_t)(q.dhi - q.dlo) * 16u : 0u;
         const uint32_t off16 = q.dhi >= q.dlo ? lo16 : 0x40000000u;   // empty band: nothing is inside
         for (int i = 0; __builtin_amdgcn_ballot_w64(i < q.n) != 0; i += 4) {
             const uint2 cn = lds_read8(lrec + 2 * i + 8);
+            ML_CNT(9, 1); ML_CNT(10, __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < q.n)));
             if (i < q.n) {
                 const uint32_t c0 = cc.x & 0xFFFFu, c1 = cc.x >> 16, c2 = cc.y & 0xFFFFu, c3 = cc.y >> 16;
                 const uint4 o0 = lds_read16(kSide ? rowaddr + c0 : rowaddr - c0);
@@ -1507,6 +1533,10 @@ __device__ __forceinline__ int ml_pixel_fast(const uint4& own, const PixelPlan& 
             cc = cn;
         }
     }
+#if SVH_ML_PROBE == 4
+    if (best == 0x7FFFFFFF) return -1;
+    return (int)(lds_read2(lrec + 2 * (best & 0xFFFF)) >> 4);
+#endif
     // ---- the plane band with its prior; rank = 512 + d
     const uint32_t a0 = kSide ? rowaddr + (uint32_t)(q.d_plane - rad) * 16u : rowaddr - (uint32_t)(q.d_plane - rad) * 16u;
     const uint32_t rk0 = (uint32_t)(512 + q.d_plane - rad);
@@ -1686,6 +1716,10 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
     }
     const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
     __syncthreads();
+#if SVH_ML_PROBE == 1
+    if (tid == 0) G.Draw[(size_t)z * P.DW * P.DH + (size_t)y * P.DW] = (float)(s_rows[5].x + tk[0]);
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < kIters; k++) {
         const int u = (x0 + k * half) * mul;
@@ -1716,7 +1750,14 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
             int res = -10;
             const uint4 own = lds_read16(own_base + (uint32_t)(u < P.W ? u : 0) * 16u);
             const bool live = tk[k] >= 0 && (int)texture16(own) >= P.match_texture;
+            ML_CNT(0, 1);
+#if SVH_ML_PROBE == 2
+            res = live ? 0 : -10;
+            if (false) {
+#else
             if (__builtin_amdgcn_ballot_w64(live) != 0) {
+#endif
+                ML_CNT(1, 1); ML_CNT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(live)));
                 const uint32_t lrec = rec_addr + __umulhi((uint32_t)(u < P.W ? u : 0), P.grid_magic) * (ML_CAP * 2);
                 const uint32_t rowaddr = oth_base + (uint32_t)u * 16u;
                 // (the plan is evaluated on every lane so that the choice of the form is made outside the
@@ -1726,8 +1767,15 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
                     const bool band_ok = __builtin_amdgcn_ballot_w64(live && !q.band_in) == 0;
                     if (__builtin_amdgcn_ballot_w64(live && !(q.cell_in && q.n <= ML_FAST)) == 0 && (band_ok || rad == 2)) {
                         const bool excl = !neg_prior || __builtin_amdgcn_ballot_w64(live && !q.valid) != 0;
+                        ML_CNT(3, 1); ML_CNT(4, excl ? 1 : 0); ML_CNT(5, band_ok ? 0 : 1);
+                        ML_CNT(11, __builtin_popcountll(__builtin_amdgcn_ballot_w64(live)));
+#if SVH_ML_PROBE == 3
+                        if (live) res = (q.d_plane ^ q.n ^ q.dmax) + (excl ? 1 : 0) + (band_ok ? 2 : 0) + q.valid;
+#else
                         if (live) res = ml_pixel_fast<1>(own, q, u, rowaddr, lrec, s_band, bp, excl, band_ok, P);
+#endif
                     } else {
+                        ML_CNT(6, 1);
                         cold |= 1u << k;
                     }
                 } else {
@@ -1735,8 +1783,15 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
                     const bool band_ok = __builtin_amdgcn_ballot_w64(live && !q.band_in) == 0;
                     if (__builtin_amdgcn_ballot_w64(live && !(q.cell_in && q.n <= ML_FAST)) == 0 && (band_ok || rad == 2)) {
                         const bool excl = !neg_prior || __builtin_amdgcn_ballot_w64(live && !q.valid) != 0;
+                        ML_CNT(3, 1); ML_CNT(4, excl ? 1 : 0); ML_CNT(5, band_ok ? 0 : 1);
+                        ML_CNT(11, __builtin_popcountll(__builtin_amdgcn_ballot_w64(live)));
+#if SVH_ML_PROBE == 3
+                        if (live) res = (q.d_plane ^ q.n ^ q.dmax) + (excl ? 1 : 0) + (band_ok ? 2 : 0) + q.valid;
+#else
                         if (live) res = ml_pixel_fast<0>(own, q, u, rowaddr, lrec, s_band, bp, excl, band_ok, P);
+#endif
                     } else {
+                        ML_CNT(6, 1);
                         cold |= 1u << k;
                     }
                 }
@@ -1747,6 +1802,9 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
     }
     // the waves that could not take the fast form redo those pixels (everything reloaded: this is the cold path)
     cold = (uint32_t)__builtin_amdgcn_readfirstlane((int)cold);   // (uniform already: set under a wave-wide vote)
+#if SVH_ML_PROBE >= 2 && SVH_ML_PROBE <= 5 || SVH_ML_PROBE == 8
+    cold = 0;
+#endif
 #pragma unroll 1
     for (int k = 0; cold >> k; k++) {
         if (!((cold >> k) & 1)) continue;
@@ -1767,6 +1825,9 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
         if (kLr) raw_row[x] = (int16_t)res;
     }
     if (!kLr) return;
+#if SVH_ML_PROBE == 6
+    return;
+#endif
     __syncthreads();
     // E12: keep d iff the other map, at the warped position, agrees within lr_threshold
     float* D = out.D[side] + (size_t)pair * out.stride[side] + (size_t)y * P.DW;
@@ -3224,3 +3285,16 @@ void launch_median(const LaunchCtx& cx, const Dims& d, int32_t g, int32_t nside,
 }
 
 }  // namespace svh
+
+#if SVH_ML_PROBE == 7
+// probe build only (tools/Makefile `probe`): read (and clear) the event counters of k_match_list
+extern "C" int svh_probe_ml_counters(unsigned long long* out16, int clear) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(svh::g_ml_cnt), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (clear) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(svh::g_ml_cnt), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -100,6 +100,54 @@ def test_device_stage_large_image_takes_the_global_memory_forms(w, h, seed, dmax
     assert_same(want, got)
 
 
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
+@pytest.mark.parametrize("stage", [0, 1])
+@pytest.mark.parametrize("dmin", [7, 20, -5, 33])
+@pytest.mark.parametrize("image", ["urban3_640x240", "synth_1242x375"])
+def test_disp_min_moves_the_support_search(image, dmin, stage, oracle_lib):
+    """Elas::parameters::disp_min (elas.h:61; settable through libelas/matlab/elasMex.cpp:60): the support search
+    scans d = max(disp_min, 0) .. disp_max_valid and gives up below a range of 10 (elas.cpp:384-396).  The LDS
+    support kernel builds its trip order and lane offsets on that lower bound, so the candidate map is compared
+    first, then every later stage, in both forms of the middle stages."""
+    import svhip as S
+    S.lib()
+    if image.startswith("synth"):
+        l, r = H.synth_pair(1242, 375, 61 + dmin, dmax=96, planes=7)
+    else:
+        l, r = H.golden_pair(image)
+    prm = H.robotics(disp_min=dmin)
+    S.set_stage(stage)
+    try:
+        got = product_run(S, prm, l, r)
+    finally:
+        S.set_stage(-1)
+    want = H.oracle_elas_run(prm, l, r)
+    assert got.status == want.status == 0
+    assert np.array_equal(got[H.DCAN_RAW], want[H.DCAN_RAW]), "candidate disparities (E3/E4)"
+    base = H.oracle_elas_run(H.robotics(), l, r)
+    if dmin > 0:
+        assert not np.array_equal(base[H.DCAN_RAW], want[H.DCAN_RAW]), "disp_min had no effect on this input"
+    else:
+        assert np.array_equal(base[H.DCAN_RAW], want[H.DCAN_RAW])       # negative bounds clamp to 0
+    assert_same(want, got)
+
+
+@pytest.mark.skipif(not H.have_ref_elas(), reason="needs oracle/_ref triangulator")
+def test_disp_min_leaving_less_than_ten_disparities_fails_like_the_reference(capfd, oracle_lib):
+    """disp_max_valid - disp_min_valid < 10 at every lattice point (elas.cpp:390): no support point, the reference's
+    message, maps untouched"""
+    import svhip as S
+    l, r = H.golden_pair("urban3_640x240")
+    prm = H.robotics(disp_min=250)
+    want = H.oracle_elas_run(prm, l, r)
+    D1 = np.full(l.shape, 7.0, np.float32)
+    D2 = np.full(l.shape, 7.0, np.float32)
+    rc, D1, D2 = S.Elas(prm).process(l, r, D1, D2)
+    assert want.status != 0 and rc != 0
+    assert "ERROR: Need at least 3 support points!" in capfd.readouterr().out
+    assert (D1 == 7.0).all() and (D2 == 7.0).all()
+
+
 FUZZ_SHAPES = [(320, 200), (401, 177), (512, 160), (288, 240)]
 
 
