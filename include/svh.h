@@ -74,12 +74,50 @@ void svh_elas_params_default(svh_elas_params* p, int32_t setting);
 const char* svh_version(void);
 /* thread-local text of the last failure on the calling thread */
 const char* svh_last_error(void);
-/* TEST HOOK -- fault injection at the HIP layer: "<malloc|launch|copy|wait>:<n>[:<count>]" makes the n-th call of
- * that kind (counted from now, process-wide) fail, and count-1 more after it (0: all of them); "" or NULL
- * disarms.  Also read once from the environment variable SVH_TEST_FAIL_AT.  A HIP failure, real or injected,
- * surfaces as SVH_ERR_HIP from the entry that was running (per pair / per object in the batch, stream and
- * lockstep entries), with svh_last_error() naming the call and one line on stderr; the object stays usable. */
-int32_t     svh_test_fail_at(const char* spec);
+/* ---- process configuration -------------------------------------------------------------------------
+ * Loading libsvhip.so does nothing: no environment variable is read or written, no thread is started, the HIP
+ * runtime is not touched.  The settings below are fixed ONCE, by svh_init() -- call it at program start, before the
+ * process creates a HIP context -- or, for a program that never calls it, by an implicit svh_init(NULL) inside the
+ * first svh_* entry that needs the device (svh_device_count, svh_set_device, the *_create entries).
+ *   hw_queues   hardware queues the HIP runtime should multiplex its streams onto (its GPU_MAX_HW_QUEUES, default
+ *               4): 0 = the measured default, 20 (12 ELAS worker streams + spare; profiles/r05_hw_queues_*.txt),
+ *               n > 0 = n, < 0 = hands off.  The runtime reads the variable when it starts, so it is written only
+ *               if the runtime has NOT started in this process and the process has not set it itself;
+ *               svh_runtime_info() tells which of the four cases applied.
+ *   elas_workers, elas_pairs_per_launch, elas_stage, wait_us   = svh_elas_set_lanes / _set_group / _set_stage and
+ *               the workers' poll interval (0 / 0 / -1 / -1 = defaults: 6, automatic, automatic, 40 us).
+ *   read_env    1 (default): the SVH_* environment switches listed below are honoured (A/B measurements);
+ *               0: the library never calls getenv (GPU_MAX_HW_QUEUES, read once by svh_init, excepted).
+ * A later svh_init() may change everything except hw_queues.  Returns SVH_OK or SVH_ERR_BAD_ARG.          */
+typedef struct svh_config {
+    uint32_t size;                    /* sizeof(svh_config) of the caller's header (svh_config_default sets it) */
+    int32_t  hw_queues;
+    int32_t  elas_workers;
+    int32_t  elas_pairs_per_launch;
+    int32_t  elas_stage;
+    int32_t  wait_us;
+    int32_t  read_env;
+    int32_t  reserved_[9];
+} svh_config;
+void    svh_config_default(svh_config* c);
+int32_t svh_init(const svh_config* c);          /* NULL: defaults */
+#define SVH_HWQ_NONE        0   /* not initialised yet                                          */
+#define SVH_HWQ_APPLIED     1   /* GPU_MAX_HW_QUEUES was set by the library (env_modified = 1)  */
+#define SVH_HWQ_CALLER_SET  2   /* the process had set it: left alone (hw_queues_env = its value) */
+#define SVH_HWQ_TOO_LATE    3   /* the HIP runtime had already started: left alone              */
+#define SVH_HWQ_HANDS_OFF   4   /* hw_queues < 0 (or SVH_HW_QUEUES=0)                           */
+typedef struct svh_runtime_info {
+    int32_t initialised;          /* the configuration is fixed                                   */
+    int32_t implicit;             /* ... by the implicit svh_init(NULL) of a first use            */
+    int32_t hw_queues_asked;      /* count asked for (-1: hands off)                              */
+    int32_t hw_queues_state;      /* SVH_HWQ_*                                                    */
+    int32_t hw_queues_env;        /* value of GPU_MAX_HW_QUEUES after svh_init (0: unset)         */
+    int32_t hip_started_before;   /* the HIP runtime was already up when the configuration was fixed */
+    int32_t env_modified;         /* the library wrote GPU_MAX_HW_QUEUES                          */
+    int32_t read_env;
+    int32_t reserved_[8];
+} svh_runtime_info;
+int32_t svh_runtime_info(svh_runtime_info* out);
 int32_t     svh_device_count(void);
 /* bind the calling thread's subsequent svh_* objects to a HIP device */
 int32_t     svh_set_device(int32_t device);
@@ -89,7 +127,7 @@ int32_t     svh_set_device(int32_t device);
 /* ------------------------------------------------------------------------ */
 typedef struct svh_elas svh_elas;
 
-/* Environment switches read by the library (all optional):
+/* Environment switches read by the library (all optional; none is read with svh_config::read_env = 0):
  *   SVH_MATCHER_WAIT=0|1   Matcher / visual odometry waits: 0 spin in the driver, 1 sleep between polls
  *                          (default: spin while at most two threads are inside the library, poll otherwise)
  *   SVH_WAIT_US=n          sleep of the ELAS batch / stream workers between completion polls (40; 0 = spin)
@@ -110,12 +148,10 @@ typedef struct svh_elas svh_elas;
  *                          one group: +5 %), off otherwise (costs the throughput path 1.2 %:
  *                          profiles/r05_delaunay_scalar_walk.txt)
  *   SVH_DESC_FLY_KEYED=0   subsampling / disp_max > 255 keep the stored descriptor maps
- *   SVH_HW_QUEUES=n        loading the library sets GPU_MAX_HW_QUEUES=20 (a hardware queue per worker stream + spare)
- *                          unless the process has set that variable itself; n: another count, 0: leave it alone
+ *   SVH_HW_QUEUES=n        the count svh_init asks for when svh_config::hw_queues is 0 (default 20); 0: hands off
  *   SVH_MATCH_WIDE768=0    rows of 1281-1920 px: 512-thread blocks (8 pixels per thread) in k_match_list instead of 768
  *   SVH_GAP_SEQ=1          wide interpolation gaps / add_corners: one thread per line (k_gap_lines) instead of the
  *                          per-row scan and the segmented column pass
- *   SVH_TEST_FAIL_AT=kind:n[:count]   tests: fault injection (svh_test_fail_at below)
  * (the full list with defaults: INTEGRATION.md, "Environment switches")                                      */
 /* Elas::Elas(parameters) -- libelas/src/elas.h:151.  Cheap: callers build one
  * per frame (stereomapper/stereothread.cpp:113); device buffers live in a

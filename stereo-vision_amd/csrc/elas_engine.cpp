@@ -86,12 +86,6 @@ bool fi_parse(const char* spec) {
     g_fi_kind.store(kind);
     return true;
 }
-struct FiEnv {
-    FiEnv() {
-        const char* e = getenv("SVH_TEST_FAIL_AT");
-        if (e && !fi_parse(e)) fprintf(stderr, "svhip: SVH_TEST_FAIL_AT=%s is not <malloc|launch|copy|wait>:<n>[:<count>]\n", e);
-    }
-} g_fi_env;
 }   // namespace
 bool fi_armed() { return g_fi_kind.load(std::memory_order_relaxed) >= 0; }
 bool fi_hit(const char* expr_text) {
@@ -278,7 +272,7 @@ struct Lane {
         HIP_TRY(hipMemset(owner, 0, G2 * N * sizeof(int32_t)));
         // SVH_TEST_OWNER_HI: start the moving base just below the int32 limit so that a test
         // reaches the (otherwise once-per-40 000-groups) re-clear path with its first groups
-        owner_hi = getenv("SVH_TEST_OWNER_HI") ? atoll(getenv("SVH_TEST_OWNER_HI")) : 0;
+        owner_hi = svh::env("SVH_TEST_OWNER_HI") ? atoll(svh::env("SVH_TEST_OWNER_HI")) : 0;
         HIP_TRY(hipMalloc(&Draw, G2 * DN * sizeof(float)));
         HIP_TRY(hipMalloc(&D, G2 * DN * sizeof(float)));
         HIP_TRY(hipMalloc(&tmp, G2 * DN * sizeof(float)));
@@ -356,7 +350,8 @@ struct Lane {
 // Delaunay / lattice-filter work of the other workers needs those cycles (measured on the
 // 16-core-quota MI355X box: same throughput at 10 instead of 16 cores).  They poll a completion
 // event and sleep in between (SVH_WAIT_US, default 40; 0 = spin).
-static int g_wait_us = getenv("SVH_WAIT_US") ? atoi(getenv("SVH_WAIT_US")) : 40;
+static int g_wait_us = 40;   // (SVH_WAIT_US / svh_config::wait_us: apply_config below)
+static bool g_hostprof = false;   // SVH_HOST_PROF (apply_config)
 static hipError_t lane_wait(Lane& L) {
     if (!L.poll_wait || g_wait_us <= 0) return hipStreamSynchronize(L.stream);
     if (!L.wait_ev) {
@@ -386,22 +381,10 @@ struct Pool {
 static std::mutex g_mu;
 // (the pools live as long as the process -- batch crew and stream workers may still be parked on them at exit -- and
 // stay reachable through this never-destroyed map, so that leak checkers do not report them)
-// The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and the kernels of one
-// queue run one after the other: a worker's stream then waits behind another worker's k_delaunay / k_lattice (one
-// workgroup per triangulation, ~1 ms, almost none of the machine).  With 16 queues each of the 12 worker streams has
-// its own (4 -> 8: +4 %, 8 -> 16: +5 % pairs/s); a few more leave room for the streams of others in the process -- an
-// RCCL communicator's take queues too (svh_shard with its communicator open: 32.1 k pairs/s at 16, 34.4 k at 20,
-// 34.5 k at 24; without one 34.1-34.3 k at 16).  More is NOT better: every queue that exists costs the device, used or
-// not -- with 40 idle foreign streams in the process (Matcher / visual-odometry objects, torch) the same batches run at
-// 35.1-35.3 k with 16 or 20 queues, 32.6-33.7 k with 24, 28.8-30.1 k with 32, and with 48 or 96 at half and a quarter
-// (profiles/r05_hw_queues_foreign_streams.txt).  Hence 20.  The runtime reads the variable when it starts, so it is
-// set when this library is loaded -- unless the process has set it already (the caller's choice wins) or
-// SVH_HW_QUEUES=0.
-__attribute__((constructor)) static void svh_default_hw_queues() {
-    const char* own = getenv("SVH_HW_QUEUES");
-    if (own && atoi(own) <= 0) return;
-    setenv("GPU_MAX_HW_QUEUES", own ? own : "20", /*overwrite=*/0);
-}
+// (hardware queues: the ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues, default 4, and the
+// kernels of one queue run one after the other -- a worker's stream then waits behind another worker's k_delaunay.  The
+// count the engine wants, 20, is asked for by svh_init / the implicit initialisation, see svh_init.cpp; round 5 set it
+// from a load-time constructor here.)
 
 static std::map<int, Pool*>& g_pools = *new std::map<int, Pool*>();
 // Defaults = the settings the headline number is measured with (bench.py used to set them itself; a C++ caller
@@ -411,6 +394,22 @@ static std::map<int, Pool*>& g_pools = *new std::map<int, Pool*>();
 static std::atomic<int> g_lanes{6};
 static std::atomic<int> g_group{32};
 static std::atomic<bool> g_group_set{false};   // svh_elas_set_group was called: take the value as is
+static std::atomic<int> g_stage_mode{-1};   // where E5-E7 run, see stage_mode_from_env() below
+static int stage_mode_from_env();
+// svh_init / the implicit initialisation (svh_init.cpp): an explicit call applies its fields, then -- in either case, while
+// the environment is honoured -- the switches that used to be read when the library was loaded
+static void apply_config(const svh_config& c, int explicit_call) {
+    if (explicit_call) {
+        if (c.elas_workers > 0) svh_elas_set_lanes(c.elas_workers);
+        if (c.elas_pairs_per_launch > 0) svh_elas_set_group(c.elas_pairs_per_launch);
+        svh_elas_set_stage(c.elas_stage);
+        if (c.wait_us >= 0) g_wait_us = c.wait_us;
+    }
+    if (const char* e = svh::env("SVH_WAIT_US")) g_wait_us = atoi(e);
+    if (svh::env("SVH_STAGE")) g_stage_mode.store(stage_mode_from_env());
+    g_hostprof = svh::env("SVH_HOST_PROF") != nullptr;
+}
+namespace { struct ConfigHook { ConfigHook() { svh::on_config(apply_config); } } g_config_hook; }
 // pairs per launch for an image of N pixels: the default (32) is meant for KITTI-size pairs, whose
 // group holds ~1.5 GB of lane buffers; much larger images get proportionally smaller groups (1920x1080:
 // 16 -- round 5 measured 6.5 k pairs/s at 8 per launch, 7.1-7.3 k at 16, a collapse to 4.5 k at 32)
@@ -540,7 +539,6 @@ enum { RG_A = 1, RG_HOST_B = 2, RG_FINISH = 4, RG_ALL = 7 };
 
 // SVH_HOST_PROF=1: per-stage thread-CPU time of the batch workers, printed at exit
 enum { HP_ENQ_A, HP_WAIT, HP_FILTER, HP_DELAUNAY, HP_PACK, HP_ENQ_B, HP_N };
-static const bool g_hostprof = getenv("SVH_HOST_PROF") != nullptr;
 static std::atomic<uint64_t> g_hp_ns[HP_N];
 static std::atomic<uint64_t> g_hp_pairs{0};
 static uint64_t cpu_ns() {
@@ -565,15 +563,14 @@ static HostProfDump g_hp_dump;
 
 // where E5-E7 run: -1 = auto (batches on the device, single calls on the host: two host threads
 // are the lower latency for one pair), 0 = host, 1 = device.  SVH_STAGE=host|device, svh_elas_set_stage()
-static int stage_mode_from_env() {
-    const char* e = getenv("SVH_STAGE");
+static int stage_mode_from_env() {   // (called by apply_config)
+    const char* e = svh::env("SVH_STAGE");
     if (!e || !*e || !strcmp(e, "auto") || !strcmp(e, "-1")) return -1;
     if (!strcmp(e, "host") || !strcmp(e, "0")) return 0;
     if (!strcmp(e, "device") || !strcmp(e, "1")) return 1;
     fprintf(stderr, "svhip: SVH_STAGE=%s is not one of auto|-1, host|0, device|1: using auto\n", e);
     return -1;
 }
-static std::atomic<int> g_stage_mode{stage_mode_from_env()};
 
 static std::atomic<int64_t> g_stage_dev_groups{0}, g_stage_redo_groups{0};
 
@@ -741,7 +738,7 @@ static int run_group_body(Lane& L, const svh_elas_params& p, const int32_t* dims
     // map k of the active pairs [j0, j1) -> the callers' buffers.  Runs of pairs whose host buffers follow
     // one another (one big array, the usual case) go down as ONE strided copy (device maps of a pair are
     // interleaved D1, D2: source pitch 2 DN, destination pitch DN) instead of one copy per pair.
-    static const bool strided = !(getenv("SVH_D2H_STRIDED") && atoi(getenv("SVH_D2H_STRIDED")) == 0);
+    static const bool strided = !(svh::env("SVH_D2H_STRIDED") && atoi(svh::env("SVH_D2H_STRIDED")) == 0);
     auto copy_map = [&](int k, hipStream_t cs, const int32_t* active) -> int {
         const size_t bytes = DN * sizeof(float);
         for (int32_t j = 0; j < g;) {
@@ -836,7 +833,7 @@ static int run_group_body(Lane& L, const svh_elas_params& p, const int32_t* dims
             if (pinned) {
                 // packed images whose buffers follow one another go up as one strided copy per camera
                 // (device layout: I1, I2 of a pair interleaved)
-                static const bool strided_up = !(getenv("SVH_H2D_STRIDED") && atoi(getenv("SVH_H2D_STRIDED")) == 0);
+                static const bool strided_up = !(svh::env("SVH_H2D_STRIDED") && atoi(svh::env("SVH_H2D_STRIDED")) == 0);
                 for (int k = 0; k < 2; k++)
                     for (int32_t j = 0; j < g;) {
                         uint8_t* dst = L.img + ((size_t)2 * j + k) * N;
@@ -876,7 +873,7 @@ static int run_group_body(Lane& L, const svh_elas_params& p, const int32_t* dims
             int32_t absmax = 0;
             for (int32_t dd = 0; dd <= pr && dd < (int32_t)Pt.size(); dd++)
                 absmax = std::max(absmax, (int32_t)std::min<int64_t>(std::llabs((long long)Pt[dd]), INT32_MAX));
-            static const int fly_env = getenv("SVH_DESC_FLY") ? atoi(getenv("SVH_DESC_FLY")) : 1;
+            static const int fly_env = svh::env("SVH_DESC_FLY") ? atoi(svh::env("SVH_DESC_FLY")) : 1;
             L.desc_fly = (!tapping || fly_env == 2) && descriptors_on_the_fly(p, d, absmax, pr, L.lists != nullptr);
         }
         if (tapping && L.desc_fly) {
@@ -1165,6 +1162,7 @@ const char* svh_version(void) { return "svhip 0.2 (gfx950) src " SVH_SRC_SHA; }
 const char* svh_last_error(void) { return t_error.c_str(); }
 
 int32_t svh_device_count(void) {
+    svh::ensure_init();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
@@ -1272,6 +1270,7 @@ void svh_elas_params_default(svh_elas_params* p, int32_t setting) {
 
 svh_elas* svh_elas_create(const svh_elas_params* p) {
     if (!p) return nullptr;
+    svh::ensure_init();
     svh_elas* e = new svh_elas();
     e->p = *p;
     e->device = t_device;

@@ -398,6 +398,45 @@ __device__ __forceinline__ void fly_desc4(const uint8_t* __restrict__ du, int W,
     }
 }
 
+// The same four descriptors for k_match_list's staging loop (round 6): `base` is wave-uniform and `off` the 32-bit byte
+// offset of du(line, x) from it, so that every load is  scalar base + 32-bit lane offset + constant  (the pointer form
+// above costs ten 64-bit lane additions per task); the row must be an interior one (3 <= line < H - 3) and the masking
+// of the columns outside 3 .. W-4 is the caller's (it concerns the first task of a row and the last two).  `vplane` =
+// byte distance of the dv plane from the du plane.
+__device__ __forceinline__ void fly_desc4_off(const uint8_t* __restrict__ base, uint32_t off, uint32_t pitch,
+                                              uint32_t vplane, uint4 out[4]) {
+    // address = uniform base + zero-extended 32-bit lane offset + constant: the form of a global load with a scalar base
+    auto ld = [base](uint32_t o, int c) { return *reinterpret_cast<const uint32_t*>(base + (size_t)o + c); };
+    const uint32_t oa = off - pitch, ob = off + pitch, ov = off + vplane;
+    const uint32_t Um2 = ld(oa - pitch, 0), Up2 = ld(ob + pitch, 0);
+    const uint32_t UaL = ld(oa, -4), Ua = ld(oa, 0), UaR = ld(oa, 4);     // row line-1
+    const uint32_t UcL = ld(off, -4), Uc = ld(off, 0), UcR = ld(off, 4);  // row line
+    const uint32_t UbL = ld(ob, -4), Ub = ld(ob, 0), UbR = ld(ob, 4);     // row line+1
+    const uint32_t Vm1 = ld(ov - pitch, 0), Vp1 = ld(ov + pitch, 0);
+    const uint32_t VcL = ld(ov, -4), Vc = ld(ov, 0), VcR = ld(ov, 4);
+    uint32_t Wa[4], Wb[4], Y[4], Z[4];
+    Wa[0] = __builtin_amdgcn_perm(Ua, UaL, DP_SEL(2, 4, 6, 0x0c));  Wb[0] = __builtin_amdgcn_perm(Ub, UbL, DP_SEL(2, 4, 6, 0x0c));
+    Wa[1] = __builtin_amdgcn_perm(Ua, UaL, DP_SEL(3, 5, 7, 0x0c));  Wb[1] = __builtin_amdgcn_perm(Ub, UbL, DP_SEL(3, 5, 7, 0x0c));
+    Wa[2] = __builtin_amdgcn_perm(UaR, Ua, DP_SEL(0, 2, 4, 0x0c));  Wb[2] = __builtin_amdgcn_perm(UbR, Ub, DP_SEL(0, 2, 4, 0x0c));
+    Wa[3] = __builtin_amdgcn_perm(UaR, Ua, DP_SEL(1, 3, 5, 0x0c));  Wb[3] = __builtin_amdgcn_perm(UbR, Ub, DP_SEL(1, 3, 5, 0x0c));
+    Y[0] = __builtin_amdgcn_perm(Uc, UcL, DP_SEL(3, 4, 4, 5));
+    Y[1] = __builtin_amdgcn_perm(Uc, Uc, DP_SEL(0, 1, 1, 2));
+    Y[2] = __builtin_amdgcn_perm(Uc, Uc, DP_SEL(1, 2, 2, 3));
+    Y[3] = __builtin_amdgcn_perm(UcR, Uc, DP_SEL(2, 3, 3, 4));
+    Z[0] = __builtin_amdgcn_perm(Vc, VcL, DP_SEL(0x0c, 3, 5, 0x0c));
+    Z[1] = __builtin_amdgcn_perm(Vc, Vc, DP_SEL(0x0c, 0, 2, 0x0c));
+    Z[2] = __builtin_amdgcn_perm(Vc, Vc, DP_SEL(0x0c, 1, 3, 0x0c));
+    Z[3] = __builtin_amdgcn_perm(VcR, Vc, DP_SEL(0x0c, 2, 4, 0x0c));
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        out[i].x = __builtin_amdgcn_perm(Wa[i], Um2, DP_SEL(i, 4, 5, 6));
+        out[i].y = Y[i];
+        out[i].z = __builtin_amdgcn_perm(Up2, Wb[i], DP_SEL(0, 1, 2, 4 + i));
+        const uint32_t t = __builtin_amdgcn_perm(Z[i], Vm1, DP_SEL(i, 5, 6, 0x0c));
+        out[i].w = __builtin_amdgcn_perm(Vp1, t, DP_SEL(0, 1, 2, 4 + i));
+    }
+}
+
 // ---------------------------------------------------------------------------
 // E3+E4  support candidate matching
 //   Elas::computeMatchingDisparity   libelas/src/elas.cpp:322-445
@@ -1011,7 +1050,9 @@ __global__ __launch_bounds__(256) void k_owner(GroupDev G, int total_tri_arg, in
         const int lo = part ? tr.uB : tr.uA, hi = part ? tr.uC : tr.uB;
         if (lo == hi) continue;
         const float ea = part ? tr.BCa : tr.ABa, eb = part ? tr.BCb : tr.ABb;
-        const int ulo = lo > 0 ? lo : 0, uhi = hi < W ? hi : W;
+        // (the matchers return at once in the two columns at either end of a row -- elas.cpp:797-798 -- so those columns
+        // are not written: their words stay stale = "no triangle", and k_match_list needs no column test of its own)
+        const int ulo = lo > 2 ? lo : 2, uhi = hi < W - 2 ? hi : W - 2;
         for (int u = ulo + cl; u < uhi; u += 16) {
             if (sub && (u & 1)) continue;
             const float fu = (float)u;
@@ -1445,7 +1486,7 @@ struct MatchList {
     int half;        // threads per image side (a multiple of 64; the block is 2 * half)
     int xcd;         // 1: blockIdx -> row in eight contiguous runs, one per XCD
     int Wr;          // raw-row stride (int16)
-    int Ws;          // descriptor-row stride in LDS (slots): >= W and == 2 (mod 4), see the staging loop
+    int Ws;          // descriptor-row stride in LDS (slots): >= 4 * ceil(W / 4) and == 2 (mod 4), see the staging loop
 };
 
 // per-pixel quantities both forms of the scan need
@@ -1472,111 +1513,207 @@ __device__ __forceinline__ PixelPlan ml_plan(const float4& pl, int u, int v, uin
     return q;
 }
 
-// The reference's scan of one pixel, hot form: at most ML_FAST candidates in the cell and none of them warps
-// out of the row (anything else is redone by ml_pixel_checked).  Wave-uniform switches:
+// min(a, b, c) as ONE operation (hipcc splits min(min(a, b), c) of four keys and the running best into three)
+__device__ __forceinline__ int min3_op(int a, int b, int c) {
+    int r;
+    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Wave-uniform constants of the hot form (scalar registers).  Band slot j = the j-th of the five band candidates in
+// LDS ADDRESS order: disparity d_plane - 2 + j in the right map (addresses rise with d), d_plane + 2 - j in the left.
+struct FastK {
+    int cell_c;           // cell_in  <=>  16 * dmax <= (right map ? cell_c - 16 u : 16 u - cell_c)
+    int band_c, band_m;   // band_in  <=>  (unsigned)(d_plane - rad) < clamp(right map ? band_c - u : u - band_c, 0, band_m)
+    uint32_t key[5];      // 512 + (disparity of slot j) - (d_plane - 2) + (P[|j - 2|] << 16): key start of a valid plane
+    uint32_t key0[5];     // the same without the prior (invalid plane)
+    uint32_t p16[3];      // P[0], P[1], P[2] << 16
+};
+
+// The reference's scan of one pixel, hot form (round 6: rebuilt around what the instruction split of round 5's form
+// showed -- profiles/r06_match_split.txt): at most ML_FAST candidates in the cell and none of them warps out of the
+// row (anything else is redone by ml_pixel_checked).  Wave-uniform switches:
 //   excl     -- some lane's plane is invalid (its band has no prior) or a band prior is not negative: cell
 //               candidates inside the band are skipped as the reference does (elas.cpp:871), +3 operations each;
 //   band_ok  -- every lane's band lies inside [0, disp_max] and inside the row; otherwise the five band keys
 //               are masked one by one.
-// rowaddr: LDS address of the other image's slot at this pixel's column; lrec: LDS address of the cell's record.
+// rowaddr: LDS address of the other image's slot at this pixel's column; lrec: LDS address of the cell's record;
+// tail: the record's last word (count << 16 | 16 * largest candidate); t1 = d_plane - plane_radius.
+//  * the padding of a record repeats its last candidate, and a repeat carries a higher rank than the original, so the
+//    lanes of a trip are NOT masked by their own count any more: a wave's trips run on one execution mask (cells
+//    without any candidate leave the loop's mask as a whole), and what ends the loop is the wave's longest list;
+//  * two trips per loop turn with the next record words requested a trip ahead into alternating registers (no copies);
+//  * min3 on (best, key, key): two operations per four candidates.
 template <int kSide>
-__device__ __forceinline__ int ml_pixel_fast(const uint4& own, const PixelPlan& q, int u, uint32_t rowaddr,
-                                             uint32_t lrec, const int* s_band, const uint3& bp, bool excl,
-                                             bool band_ok, const MatchParams& P) {
+__device__ __forceinline__ int ml_fast(const uint4& own, uint32_t rowaddr, uint32_t lrec, uint32_t tail, int t1, int u,
+                                       bool valid, bool excl, bool band_ok, const FastK& K, const int* s_band,
+                                       const MatchParams& P) {
     const int rad = P.plane_radius;
     int best = 0x7FFFFFFF;
-    // ---- cell candidates, four per trip; rank = list index (ascending d, the reference's order)
-    uint2 cc = lds_read8(lrec);
-#if SVH_ML_PROBE == 5
-    if (false) {
-#else
-    if (!excl) {
-#endif
-        for (int i = 0; __builtin_amdgcn_ballot_w64(i < q.n) != 0; i += 4) {
-            const uint2 cn = lds_read8(lrec + 2 * i + 8);   // next trip's four ([28..31] at the end: read, not used)
-            ML_CNT(7, 1); ML_CNT(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < q.n)));
-            if (i < q.n) {   // (an empty record is padded with d = 0, which is not a candidate)
-                const uint32_t c0 = cc.x & 0xFFFFu, c1 = cc.x >> 16, c2 = cc.y & 0xFFFFu, c3 = cc.y >> 16;
-                const uint4 o0 = lds_read16(kSide ? rowaddr + c0 : rowaddr - c0);
-                const uint4 o1 = lds_read16(kSide ? rowaddr + c1 : rowaddr - c1);
-                const uint4 o2 = lds_read16(kSide ? rowaddr + c2 : rowaddr - c2);
-                const uint4 o3 = lds_read16(kSide ? rowaddr + c3 : rowaddr - c3);
-                best = min3i(best, sad_hi16(own, o0, (uint32_t)i), sad_hi16(own, o1, (uint32_t)i + 1));
-                best = min3i(best, sad_hi16(own, o2, (uint32_t)i + 2), sad_hi16(own, o3, (uint32_t)i + 3));
+    const uint32_t n = tail >> 16;
+    // lowest LDS address of the band's slots (rad == 2: five slots of 16 bytes from here)
+    const uint32_t bandlo = kSide ? rowaddr + 16u * (uint32_t)t1 : rowaddr - 16u * (uint32_t)t1 - 32u * (uint32_t)rad;
+#define ML_ADDR(c) (kSide ? rowaddr + (c) : rowaddr - (c))
+#define ML_TRIP4(cc, i)                                                                                       \
+    {                                                                                                         \
+        const uint32_t c0 = (cc).x & 0xFFFFu, c1 = (cc).x >> 16, c2 = (cc).y & 0xFFFFu, c3 = (cc).y >> 16;    \
+        const uint4 o0 = lds_read16(ML_ADDR(c0)), o1 = lds_read16(ML_ADDR(c1));                               \
+        const uint4 o2 = lds_read16(ML_ADDR(c2)), o3 = lds_read16(ML_ADDR(c3));                               \
+        best = min3_op(best, sad_hi16(own, o0, (i)), sad_hi16(own, o1, (i) + 1u));                            \
+        best = min3_op(best, sad_hi16(own, o2, (i) + 2u), sad_hi16(own, o3, (i) + 3u));                       \
+    }
+    // (exclusion: a candidate whose slot lies among the band's, i.e. whose address is bandlo .. bandlo + 32 rad)
+#define ML_TRIP4X(cc, i)                                                                                      \
+    {                                                                                                         \
+        const uint32_t c0 = (cc).x & 0xFFFFu, c1 = (cc).x >> 16, c2 = (cc).y & 0xFFFFu, c3 = (cc).y >> 16;    \
+        const uint32_t a0 = ML_ADDR(c0), a1 = ML_ADDR(c1), a2 = ML_ADDR(c2), a3 = ML_ADDR(c3);                \
+        const uint4 o0 = lds_read16(a0), o1 = lds_read16(a1), o2 = lds_read16(a2), o3 = lds_read16(a3);       \
+        const int k0 = a0 - bandlo <= blen ? 0x7FFFFFFF : sad_hi16(own, o0, (i));                             \
+        const int k1 = a1 - bandlo <= blen ? 0x7FFFFFFF : sad_hi16(own, o1, (i) + 1u);                        \
+        const int k2 = a2 - bandlo <= blen ? 0x7FFFFFFF : sad_hi16(own, o2, (i) + 2u);                        \
+        const int k3 = a3 - bandlo <= blen ? 0x7FFFFFFF : sad_hi16(own, o3, (i) + 3u);                        \
+        best = min3_op(best, k0, k1);                                                                         \
+        best = min3_op(best, k2, k3);                                                                         \
+    }
+#if SVH_ML_PROBE != 5
+    if (n != 0) {
+        uint2 ca = lds_read8(lrec), cb;
+        if (!excl) {
+            for (uint32_t i = 0;; i += 8) {
+                cb = lds_read8(lrec + 2 * i + 8);
+                ML_CNT(7, 1);
+                ML_TRIP4(ca, i)
+                __builtin_amdgcn_sched_barrier(0);   // (the second trip's reads stay behind the first trip's keys: registers)
+                if (__builtin_amdgcn_ballot_w64(i + 4 < n) == 0) break;
+                ca = lds_read8(lrec + 2 * i + 16);
+                ML_CNT(7, 1);
+                ML_TRIP4(cb, i + 4u)
+                __builtin_amdgcn_sched_barrier(0);
+                if (__builtin_amdgcn_ballot_w64(i + 8 < n) == 0) break;
             }
-            cc = cn;
-        }
-#if SVH_ML_PROBE == 5
-    } else if (false) {
-#else
-    } else {
-#endif
-        const uint32_t lo16 = (uint32_t)q.dlo * 16u;
-        const uint32_t len16 = q.dhi >= q.dlo ? (uint32_t)(q.dhi - q.dlo) * 16u : 0u;
-        const uint32_t off16 = q.dhi >= q.dlo ? lo16 : 0x40000000u;   // empty band: nothing is inside
-        for (int i = 0; __builtin_amdgcn_ballot_w64(i < q.n) != 0; i += 4) {
-            const uint2 cn = lds_read8(lrec + 2 * i + 8);
-            ML_CNT(9, 1); ML_CNT(10, __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < q.n)));
-            if (i < q.n) {
-                const uint32_t c0 = cc.x & 0xFFFFu, c1 = cc.x >> 16, c2 = cc.y & 0xFFFFu, c3 = cc.y >> 16;
-                const uint4 o0 = lds_read16(kSide ? rowaddr + c0 : rowaddr - c0);
-                const uint4 o1 = lds_read16(kSide ? rowaddr + c1 : rowaddr - c1);
-                const uint4 o2 = lds_read16(kSide ? rowaddr + c2 : rowaddr - c2);
-                const uint4 o3 = lds_read16(kSide ? rowaddr + c3 : rowaddr - c3);
-                const int k0 = c0 - off16 <= len16 ? 0x7FFFFFFF : sad_hi16(own, o0, (uint32_t)i);
-                const int k1 = c1 - off16 <= len16 ? 0x7FFFFFFF : sad_hi16(own, o1, (uint32_t)i + 1);
-                const int k2 = c2 - off16 <= len16 ? 0x7FFFFFFF : sad_hi16(own, o2, (uint32_t)i + 2);
-                const int k3 = c3 - off16 <= len16 ? 0x7FFFFFFF : sad_hi16(own, o3, (uint32_t)i + 3);
-                best = min3i(best, k0, k1);
-                best = min3i(best, k2, k3);
+        } else {
+            const uint32_t blen = 32u * (uint32_t)rad;
+            for (uint32_t i = 0;; i += 8) {
+                cb = lds_read8(lrec + 2 * i + 8);
+                ML_CNT(9, 1);
+                ML_TRIP4X(ca, i)
+                __builtin_amdgcn_sched_barrier(0);
+                if (__builtin_amdgcn_ballot_w64(i + 4 < n) == 0) break;
+                ca = lds_read8(lrec + 2 * i + 16);
+                ML_CNT(9, 1);
+                ML_TRIP4X(cb, i + 4u)
+                __builtin_amdgcn_sched_barrier(0);
+                if (__builtin_amdgcn_ballot_w64(i + 8 < n) == 0) break;
             }
-            cc = cn;
         }
     }
+#endif
+#undef ML_TRIP4
+#undef ML_TRIP4X
+#undef ML_ADDR
 #if SVH_ML_PROBE == 4
     if (best == 0x7FFFFFFF) return -1;
     return (int)(lds_read2(lrec + 2 * (best & 0xFFFF)) >> 4);
 #endif
     // ---- the plane band with its prior; rank = 512 + d
-    const uint32_t a0 = kSide ? rowaddr + (uint32_t)(q.d_plane - rad) * 16u : rowaddr - (uint32_t)(q.d_plane - rad) * 16u;
-    const uint32_t rk0 = (uint32_t)(512 + q.d_plane - rad);
     if (rad == 2) {
-        // the presets' radius: five candidates at constant offsets from one address, priors in scalar registers
-        const uint32_t b = kSide ? a0 : a0 - 64u;
-        const uint4 o0 = lds_read16(b + (kSide ? 0u : 64u)), o1 = lds_read16(b + (kSide ? 16u : 48u));
-        const uint4 o2 = lds_read16(b + 32u), o3 = lds_read16(b + (kSide ? 48u : 16u));
-        const uint4 o4 = lds_read16(b + (kSide ? 64u : 0u));
-        const uint32_t p0 = q.valid ? bp.x : 0u, p1 = q.valid ? bp.y : 0u, p2 = q.valid ? bp.z : 0u;
-        int key0 = sad_hi16(own, o0, rk0 + p2), key1 = sad_hi16(own, o1, rk0 + 1u + p1);
-        int key2 = sad_hi16(own, o2, rk0 + 2u + p0), key3 = sad_hi16(own, o3, rk0 + 3u + p1);
-        int key4 = sad_hi16(own, o4, rk0 + 4u + p2);
-        if (!band_ok) {
-            const int d0 = q.d_plane - 2, w0 = kSide ? u + d0 - 2 : u - d0 - 2;   // warped column - 2 of the first one
-            const uint32_t dm = (uint32_t)P.disp_max, wm = (uint32_t)(P.W - 4);
-            key0 = (uint32_t)d0 <= dm && (uint32_t)w0 < wm ? key0 : 0x7FFFFFFF;
-            key1 = (uint32_t)(d0 + 1) <= dm && (uint32_t)(kSide ? w0 + 1 : w0 - 1) < wm ? key1 : 0x7FFFFFFF;
-            key2 = (uint32_t)(d0 + 2) <= dm && (uint32_t)(kSide ? w0 + 2 : w0 - 2) < wm ? key2 : 0x7FFFFFFF;
-            key3 = (uint32_t)(d0 + 3) <= dm && (uint32_t)(kSide ? w0 + 3 : w0 - 3) < wm ? key3 : 0x7FFFFFFF;
-            key4 = (uint32_t)(d0 + 4) <= dm && (uint32_t)(kSide ? w0 + 4 : w0 - 4) < wm ? key4 : 0x7FFFFFFF;
+        // the presets' radius: five slots at constant offsets from one address, key starts = t1 + a scalar
+        const uint4 o0 = lds_read16(bandlo), o1 = lds_read16(bandlo + 16u), o2 = lds_read16(bandlo + 32u);
+        const uint4 o3 = lds_read16(bandlo + 48u), o4 = lds_read16(bandlo + 64u);
+        int key0, key1, key2, key3, key4;
+        if (!excl) {      // (every live lane's plane is valid)
+            key0 = sad_hi16(own, o0, (uint32_t)t1 + K.key[0]);
+            key1 = sad_hi16(own, o1, (uint32_t)t1 + K.key[1]);
+            key2 = sad_hi16(own, o2, (uint32_t)t1 + K.key[2]);
+            key3 = sad_hi16(own, o3, (uint32_t)t1 + K.key[3]);
+            key4 = sad_hi16(own, o4, (uint32_t)t1 + K.key[4]);
+        } else {
+            const uint32_t p0 = valid ? K.p16[0] : 0u, p1 = valid ? K.p16[1] : 0u, p2 = valid ? K.p16[2] : 0u;
+            key0 = sad_hi16(own, o0, (uint32_t)t1 + K.key0[0] + p2);
+            key1 = sad_hi16(own, o1, (uint32_t)t1 + K.key0[1] + p1);
+            key2 = sad_hi16(own, o2, (uint32_t)t1 + K.key0[2] + p0);
+            key3 = sad_hi16(own, o3, (uint32_t)t1 + K.key0[3] + p1);
+            key4 = sad_hi16(own, o4, (uint32_t)t1 + K.key0[4] + p2);
         }
-        best = min3i(best, key0, key1);
-        best = min3i(best, key2, key3);
+        if (!band_ok) {
+            // slot j holds disparity dj = kSide ? t1 + j : t1 + 4 - j, warped column u +- dj
+            const uint32_t dm = (uint32_t)P.disp_max, wm = (uint32_t)(P.W - 4);
+#define ML_SLOT_OK(j) ((uint32_t)(kSide ? t1 + (j) : t1 + 4 - (j)) <= dm &&                                   \
+                       (uint32_t)(kSide ? u + t1 + (j) - 2 : u - t1 - 4 + (j) - 2) < wm)
+            key0 = ML_SLOT_OK(0) ? key0 : 0x7FFFFFFF;
+            key1 = ML_SLOT_OK(1) ? key1 : 0x7FFFFFFF;
+            key2 = ML_SLOT_OK(2) ? key2 : 0x7FFFFFFF;
+            key3 = ML_SLOT_OK(3) ? key3 : 0x7FFFFFFF;
+            key4 = ML_SLOT_OK(4) ? key4 : 0x7FFFFFFF;
+#undef ML_SLOT_OK
+        }
+        best = min3_op(best, key0, key1);
+        best = min3_op(best, key2, key3);
         best = best < key4 ? best : key4;
     } else {
         // (other radii: the caller sends waves with a clipped band to the checked form)
         const int nb = 2 * rad + 1;
+        const uint32_t a0 = kSide ? bandlo : bandlo + 32u * (uint32_t)rad;   // slot of d_plane - rad
+        const uint32_t rk0 = (uint32_t)(512 + t1);
         for (int k = 0; k < nb; k += 2) {
             const int k1 = k + 1 < nb ? k + 1 : k;
             const uint4 o0 = lds_read16(kSide ? a0 + 16u * k : a0 - 16u * k);
             const uint4 o1 = lds_read16(kSide ? a0 + 16u * k1 : a0 - 16u * k1);
-            const int key0 = sad_hi16(own, o0, rk0 + (uint32_t)k + (q.valid ? (uint32_t)s_band[k] : 0u));
-            const int key1 = sad_hi16(own, o1, rk0 + (uint32_t)k1 + (q.valid ? (uint32_t)s_band[k1] : 0u));
-            best = min3i(best, key0, key1);
+            const int key0 = sad_hi16(own, o0, rk0 + (uint32_t)k + (valid ? (uint32_t)s_band[k] : 0u));
+            const int key1 = sad_hi16(own, o1, rk0 + (uint32_t)k1 + (valid ? (uint32_t)s_band[k1] : 0u));
+            best = min3_op(best, key0, key1);
         }
     }
     if (best == 0x7FFFFFFF) return -1;
     const int rank = best & 0xFFFF;
     return rank >= 512 ? rank - 512 : (int)(lds_read2(lrec + 2 * rank) >> 4);
+}
+
+// One pixel of a wave through the hot form: the plan (record, plane disparity, the tests that decide the form -- on every
+// lane, live or not, so that the votes are taken outside the divergent part; lanes that are not live hold a valid
+// record address and plane 0), the votes, the scan.  *is_cold (wave-uniform): the wave has to take the checked form.
+//  * the ballot of ONE comparison is that comparison's mask, and combining masks is scalar work; the ballot of a
+//    conjunction makes hipcc turn the combined mask into a lane value and compare it again (round 5: 6 operations);
+//  * cell test: 16 dmax <= 16 u - 32 (left map) / <= 16 (W - 3) - 16 u (right map), and at most ML_FAST candidates;
+//  * band test: (unsigned)(d_plane - rad) < clamp(u - 2 rad - 1 | W - 2 - 2 rad - u, 0, disp_max - 2 rad + 1).
+template <int kSide>
+__device__ __forceinline__ int ml_pixel(const uint4& own, const float4& pl, int u, float vf, bool live, uint64_t m_live,
+                                        uint32_t rec_addr, uint32_t oth_base, int neg_prior, const FastK& K,
+                                        const int* s_band, const MatchParams& P, bool* is_cold) {
+    const int rad = P.plane_radius;
+    const uint32_t u16 = (uint32_t)u * 16u;
+    uint32_t lrec;
+    {
+        const uint32_t cell = __umulhi((uint32_t)u, P.grid_magic);
+        asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(lrec) : "v"(cell), "s"(rec_addr));   // + cell * 2 ML_CAP
+    }
+    static_assert(ML_CAP * 2 == 64, "record size of the shift above");
+    const uint32_t tail = lds_read4(lrec + 2 * (ML_CAP - 2));   // [30] last candidate, [31] count
+    const uint32_t rowaddr = oth_base + u16;
+    const int d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pl.x, (float)u), __fmul_rn(pl.y, vf)), pl.z);
+    const int t1 = d_plane - rad;
+    const uint32_t lim = kSide ? (uint32_t)K.cell_c - u16 : u16 - (uint32_t)K.cell_c;
+    const uint64_t m_cell = __builtin_amdgcn_ballot_w64((tail & 0xFFFFu) > lim) |
+                            __builtin_amdgcn_ballot_w64(tail >= ((uint32_t)(ML_FAST + 1) << 16));
+    int bl = kSide ? K.band_c - u : u - K.band_c;
+    bl = bl < K.band_m ? bl : K.band_m;
+    bl = bl > 0 ? bl : 0;
+    const bool band_ok = (m_live & __builtin_amdgcn_ballot_w64((uint32_t)t1 >= (uint32_t)bl)) == 0;
+    *is_cold = !((m_live & m_cell) == 0 && (band_ok || rad == 2));
+    if (*is_cold) {
+        ML_CNT(6, 1);
+        return -10;
+    }
+    const bool excl = !neg_prior || (m_live & __builtin_amdgcn_ballot_w64(__float_as_int(pl.w) == 0)) != 0;
+    ML_CNT(3, 1); ML_CNT(4, excl ? 1 : 0); ML_CNT(5, band_ok ? 0 : 1);
+    ML_CNT(11, __builtin_popcountll(m_live));
+    int res = -10;
+#if SVH_ML_PROBE == 3
+    if (live) res = (d_plane ^ (int)tail) + (excl ? 1 : 0) + (band_ok ? 2 : 0) + (int)(rowaddr & 1u);
+#else
+    if (live) res = ml_fast<kSide>(own, rowaddr, lrec, tail, t1, u, __float_as_int(pl.w) != 0, excl, band_ok, K, s_band, P);
+#endif
+    return res;
 }
 
 // checked form: per-candidate range and band tests (waves next to the image border, invalid planes,
@@ -1672,15 +1809,29 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
             // even lanes take the left image, odd lanes the right one, and the second row starts at a slot == 2
             // (mod 4), so a group's 8 stores fall on four different slots modulo 8 (2-way: 16 LDS cycles against
             // the 13 the store's data transfer takes anyway).  No data is moved between lanes.
+            // Round 6: the row stride Ws covers the whole last task (Ws >= 4 nq), so the four stores are unconditional;
+            // the loads go through one uniform base + a 32-bit lane offset; the two border rows whose descriptors are
+            // all zero are a branch of the block, the columns outside 3 .. W-4 a branch of the three tasks they touch.
             const int nq = (P.W + 3) >> 2;
-            for (int task = tid; task < 2 * nq; task += (int)blockDim.x) {
-                const int im = task & 1, x = 4 * (task >> 1);
-                uint4 o[4];
-                fly_desc4(G.desc + (size_t)(2 * pair + im) * N * 16, P.W, P.H, x, line, o);
-                uint4* dst = s_rows + im * Q.Ws + x;
+            const uint8_t* pbase = G.desc + (size_t)(2 * pair) * N * 16;
+            const uint32_t pitch = (uint32_t)fly_pitch(P.W), vplane = (uint32_t)P.H * pitch;
+            const uint32_t imstride = (uint32_t)(N * 16), off0 = (uint32_t)line * pitch + 8u;
+            if (line < 3 || line >= P.H - 3) {
+                for (int j = tid; j < 2 * Q.Ws; j += (int)blockDim.x) s_rows[j] = make_uint4(0, 0, 0, 0);
+            } else {
+                for (int task = tid; task < 2 * nq; task += (int)blockDim.x) {
+                    const int im = task & 1, x = 4 * (task >> 1);
+                    uint4 o[4];
+                    fly_desc4_off(pbase, (im ? imstride : 0u) + off0 + (uint32_t)x, pitch, vplane, o);
+                    if (x == 0 || x + 4 > P.W - 3) {
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (x + i < P.W) dst[i] = o[i];
+                        for (int i = 0; i < 4; i++)
+                            if (x + i < 3 || x + i >= P.W - 3) o[i] = make_uint4(0, 0, 0, 0);
+                    }
+                    uint4* dst = s_rows + im * Q.Ws + x;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) dst[i] = o[i];
+                }
             }
         } else {
             const uint4* l1 = reinterpret_cast<const uint4*>(G.desc) + (size_t)(2 * pair) * N + (size_t)line * P.W;
@@ -1703,16 +1854,18 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
         s_neg = neg;
     }
     const int half = blockDim.x >> 1;
-    const int side = tid >= half;                 // wave-uniform: half is a multiple of 64
+    const int side = wave >= (half >> 6) ? 1 : 0;   // a SCALAR: half is a multiple of 64 (the constants of FastK depend on it)
     const int z = 2 * pair + side;
     const int x0 = tid - side * half;
     const int32_t* own_t = G.owner + (size_t)z * N + (size_t)v * P.W;
-    // owner words of all of the thread's pixels, then (after the barrier drained them) their planes
+    // owner words of all of the thread's pixels, then (after the barrier drained them) their planes.  Round 6: k_owner
+    // leaves the two columns at either end of a row alone (findMatch returns there, elas.cpp:797-798), so a stale word
+    // says "no triangle" and the column test is gone from this loop.
     int tk[kIters];
 #pragma unroll
     for (int k = 0; k < kIters; k++) {
         const int u = (x0 + k * half) * mul;
-        tk[k] = own_t[u < P.W ? u : 0];
+        tk[k] = own_t[u < P.W ? u : P.W - 1];
     }
     const int tri0 = z ? G.hdr->tri_end[z - 1] : 0;
     __syncthreads();
@@ -1720,19 +1873,34 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
     if (tid == 0) G.Draw[(size_t)z * P.DW * P.DH + (size_t)y * P.DW] = (float)(s_rows[5].x + tk[0]);
     return;
 #endif
-#pragma unroll
-    for (int k = 0; k < kIters; k++) {
-        const int u = (x0 + k * half) * mul;
-        const int t = tk[k] - G.owner_base - 1;
-        tk[k] = (u >= 2 && u < P.W - 2) ? t : -1;
-    }
-    // the plane of the owning triangle is requested one pixel ahead (all of them at once would cost a sixth wave per SIMD)
-    float4 pl_next = *reinterpret_cast<const float4*>(G.raster + (tk[0] >= 0 ? (uint32_t)(tri0 + tk[0]) : 0u));
+    const int own1 = G.owner_base + 1;
+    // plane records through one scalar base + a 32-bit lane offset; the plane of the owning triangle is requested one
+    // pixel ahead (all of them at once would cost a sixth wave per SIMD)
+    const char* rbase = reinterpret_cast<const char*>(G.raster + tri0);
+    auto plane_of = [rbase](int t) {
+        const uint32_t off = (uint32_t)(t > 0 ? t : 0) * (uint32_t)sizeof(TriRaster);
+        return *reinterpret_cast<const float4*>(rbase + (size_t)off);
+    };
+    float4 pl_next = plane_of(tk[0] - own1);
     const int neg_prior = s_neg, rad = P.plane_radius;
-    // P[0], P[1], P[2] << 16 (uniform): the band priors of the presets' plane radius
-    const uint3 bp = make_uint3((uint32_t)__builtin_amdgcn_readfirstlane(s_band[rad]),
-                                (uint32_t)__builtin_amdgcn_readfirstlane(s_band[rad + 1]),
-                                (uint32_t)__builtin_amdgcn_readfirstlane(s_band[rad + 2]));
+    // scalar constants of the hot form (see FastK)
+    FastK K;
+    {
+        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane(s_band[rad]);
+        const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane(s_band[rad + 1]);
+        const uint32_t p2 = (uint32_t)__builtin_amdgcn_readfirstlane(s_band[rad + 2]);
+        K.p16[0] = p0; K.p16[1] = p1; K.p16[2] = p2;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            K.key0[j] = 512u + (uint32_t)(side ? j : 4 - j);
+            K.key[j] = K.key0[j] + (j == 2 ? p0 : (j == 1 || j == 3) ? p1 : p2);
+        }
+        K.cell_c = side ? 16 * (P.W - 3) : 32;
+        K.band_c = side ? P.W - 2 - 2 * rad : 2 * rad + 1;
+        K.band_m = P.disp_max - 2 * rad + 1;
+        K.band_m = K.band_m > 0 ? K.band_m : 0;
+    }
+    const float vf = (float)v;
     const uint32_t rows_addr = lds_addr_of(s_rows), rec_addr = lds_addr_of(s_rec) + (uint32_t)(side * P.gw * ML_CAP * 2);
     const uint32_t own_base = rows_addr + (uint32_t)(side * Q.Ws) * 16u, oth_base = rows_addr + (uint32_t)((1 - side) * Q.Ws) * 16u;
     float* out_row = G.Draw + (size_t)z * P.DW * P.DH + (size_t)y * P.DW;
@@ -1743,58 +1911,28 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
         const int x = x0 + k * half, u = x * mul;
         const float4 pl = pl_next;
         if (k + 1 < kIters) {
-            pl_next = *reinterpret_cast<const float4*>(G.raster + (tk[k + 1] >= 0 ? (uint32_t)(tri0 + tk[k + 1]) : 0u));
+            pl_next = plane_of(tk[k + 1] - own1);
             asm volatile("" ::: "memory");   // the request goes out HERE (hipcc would sink it to its use, a pixel later)
         }
         if (x < P.DW) {
             int res = -10;
-            const uint4 own = lds_read16(own_base + (uint32_t)(u < P.W ? u : 0) * 16u);
-            const bool live = tk[k] >= 0 && (int)texture16(own) >= P.match_texture;
+            const uint4 own = lds_read16(own_base + (uint32_t)u * 16u);
+            // (votes: the ballot of ONE comparison is that comparison's mask -- see ml_pixel)
+            const bool owned = tk[k] >= own1, textured = (int)texture16(own) >= P.match_texture;
+            const bool live = owned && textured;
+            const uint64_t m_live = __builtin_amdgcn_ballot_w64(owned) & __builtin_amdgcn_ballot_w64(textured);
             ML_CNT(0, 1);
 #if SVH_ML_PROBE == 2
             res = live ? 0 : -10;
             if (false) {
 #else
-            if (__builtin_amdgcn_ballot_w64(live) != 0) {
+            if (m_live != 0) {
 #endif
-                ML_CNT(1, 1); ML_CNT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(live)));
-                const uint32_t lrec = rec_addr + __umulhi((uint32_t)(u < P.W ? u : 0), P.grid_magic) * (ML_CAP * 2);
-                const uint32_t rowaddr = oth_base + (uint32_t)u * 16u;
-                // (the plan is evaluated on every lane so that the choice of the form is made outside the
-                // divergent part; lanes that are not live hold a valid record address and plane 0)
-                if (side) {
-                    const PixelPlan q = ml_plan<1>(pl, u, v, lrec, P);
-                    const bool band_ok = __builtin_amdgcn_ballot_w64(live && !q.band_in) == 0;
-                    if (__builtin_amdgcn_ballot_w64(live && !(q.cell_in && q.n <= ML_FAST)) == 0 && (band_ok || rad == 2)) {
-                        const bool excl = !neg_prior || __builtin_amdgcn_ballot_w64(live && !q.valid) != 0;
-                        ML_CNT(3, 1); ML_CNT(4, excl ? 1 : 0); ML_CNT(5, band_ok ? 0 : 1);
-                        ML_CNT(11, __builtin_popcountll(__builtin_amdgcn_ballot_w64(live)));
-#if SVH_ML_PROBE == 3
-                        if (live) res = (q.d_plane ^ q.n ^ q.dmax) + (excl ? 1 : 0) + (band_ok ? 2 : 0) + q.valid;
-#else
-                        if (live) res = ml_pixel_fast<1>(own, q, u, rowaddr, lrec, s_band, bp, excl, band_ok, P);
-#endif
-                    } else {
-                        ML_CNT(6, 1);
-                        cold |= 1u << k;
-                    }
-                } else {
-                    const PixelPlan q = ml_plan<0>(pl, u, v, lrec, P);
-                    const bool band_ok = __builtin_amdgcn_ballot_w64(live && !q.band_in) == 0;
-                    if (__builtin_amdgcn_ballot_w64(live && !(q.cell_in && q.n <= ML_FAST)) == 0 && (band_ok || rad == 2)) {
-                        const bool excl = !neg_prior || __builtin_amdgcn_ballot_w64(live && !q.valid) != 0;
-                        ML_CNT(3, 1); ML_CNT(4, excl ? 1 : 0); ML_CNT(5, band_ok ? 0 : 1);
-                        ML_CNT(11, __builtin_popcountll(__builtin_amdgcn_ballot_w64(live)));
-#if SVH_ML_PROBE == 3
-                        if (live) res = (q.d_plane ^ q.n ^ q.dmax) + (excl ? 1 : 0) + (band_ok ? 2 : 0) + q.valid;
-#else
-                        if (live) res = ml_pixel_fast<0>(own, q, u, rowaddr, lrec, s_band, bp, excl, band_ok, P);
-#endif
-                    } else {
-                        ML_CNT(6, 1);
-                        cold |= 1u << k;
-                    }
-                }
+                ML_CNT(1, 1); ML_CNT(2, __builtin_popcountll(m_live));
+                bool is_cold;
+                res = side ? ml_pixel<1>(own, pl, u, vf, live, m_live, rec_addr, oth_base, neg_prior, K, s_band, P, &is_cold)
+                           : ml_pixel<0>(own, pl, u, vf, live, m_live, rec_addr, oth_base, neg_prior, K, s_band, P, &is_cold);
+                if (is_cold) cold |= 1u << k;
             }
             if (!kLr || write_raw) out_row[x] = (float)res;
             if (kLr) raw_row[x] = (int16_t)res;
@@ -1810,8 +1948,7 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
         if (!((cold >> k) & 1)) continue;
         const int x = x0 + k * half, u = x * mul;
         if (x >= P.DW) continue;
-        int t = own_t[u < P.W ? u : 0] - G.owner_base - 1;
-        t = (u >= 2 && u < P.W - 2) ? t : -1;
+        const int t = own_t[u] - G.owner_base - 1;   // (u < W: x < DW; columns 0, 1, W-2, W-1 are never owned)
         const uint4 own = lds_read16(own_base + (uint32_t)(u < P.W ? u : 0) * 16u);
         if (!(t >= 0 && (int)texture16(own) >= P.match_texture)) continue;
         const float4 pl = *reinterpret_cast<const float4*>(G.raster + (tri0 + t));
@@ -1832,21 +1969,38 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
     // E12: keep d iff the other map, at the warped position, agrees within lr_threshold
     float* D = out.D[side] + (size_t)pair * out.stride[side] + (size_t)y * P.DW;
     const int16_t* other = s_raw + (1 - side) * Q.Wr;
-    for (int x = x0; x < P.DW; x += half) {
-        const int d = raw_row[x];
-        float o = -10.f;
-        if (P.sub) {
+    if (P.sub) {
+        for (int x = x0; x < P.DW; x += half) {
+            const int d = raw_row[x];
+            float o = -10.f;
             // the reference's float form (elas.cpp:1150-1175): the warped column is x -+ d / 2
             const float fd = (float)d, step = fd / 2, uwf = side ? (float)x + step : (float)x - step;
             if (d >= 0 && uwf >= 0 && uwf < (float)P.DW)
                 if (!(fabsf((float)other[(int)uwf] - fd) > lr_threshold)) o = fd;
-        } else {
-            const int uw = side ? x + d : x - d;
-            if (d >= 0 && uw >= 0 && uw < P.DW)
-                if (!(fabsf((float)other[uw] - (float)d) > lr_threshold)) o = (float)d;
+            D[x] = o;
         }
-        D[x] = o;
+        return;
     }
+    // Full resolution (round 6): everything is an integer -- |other - d| <= lr_threshold  <=>  |other - d| <= floor(thr)
+    // (no pixel passes a negative threshold), one unsigned comparison; the other map's value is read without a branch
+    // (an index outside the row reads LDS bytes that the range test then discards).
+    const int ithr = lr_threshold >= 0.f ? (int)fminf(floorf(lr_threshold), 1048576.f) : -1;
+    const uint32_t span = ithr >= 0 ? 2u * (uint32_t)ithr + 1u : 0u;
+    const uint32_t raw_a = lds_addr_of(raw_row), oth_a = lds_addr_of(other);
+    char* Db = reinterpret_cast<char*>(D);     // scalar base + 32-bit lane offset
+#define ML_LR_ROW(WARP)                                                                                        \
+    _Pragma("unroll") for (int k = 0; k < kIters; k++) {                                                       \
+        const int x = x0 + k * half;                                                                           \
+        if (x < P.DW) {                                                                                        \
+            const int d = (int)(int16_t)lds_read2(raw_a + 2u * (uint32_t)x);                                   \
+            const int uw = WARP;                                                                               \
+            const int o = (int)(int16_t)lds_read2(oth_a + 2u * (uint32_t)uw);                                  \
+            const bool keep = d >= 0 && (uint32_t)uw < (uint32_t)P.DW && (uint32_t)(o - d + ithr) < span;      \
+            *reinterpret_cast<float*>(Db + (size_t)(4u * (uint32_t)x)) = keep ? (float)d : -10.f;              \
+        }                                                                                                      \
+    }
+    if (side) { ML_LR_ROW(x + d) } else { ML_LR_ROW(x - d) }
+#undef ML_LR_ROW
 }
 
 // ---------------------------------------------------------------------------
@@ -2632,7 +2786,7 @@ void launch_descriptor(const LaunchCtx& cx, const DevImages& img, int32_t g, int
 
 // candidates per block of the LDS-staged support kernel, 0 when the strips do not fit (generic kernel)
 static int support_strip(const svh_elas_params& p, const Dims& d, size_t* lds_out) {
-    static const int sb_env = getenv("SVH_SUPPORT_SB") ? atoi(getenv("SVH_SUPPORT_SB")) : 64;
+    static const int sb_env = svh::env("SVH_SUPPORT_SB") ? atoi(svh::env("SVH_SUPPORT_SB")) : 64;
     constexpr size_t kSupportStatic = 512;
     auto strip_lds = [&](int sb) {
         const int span = (sb - 1) * d.step;
@@ -2711,7 +2865,7 @@ void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
     // climbs the whole image within one column; beyond 2^22 one ulp of that product is half a row and the
     // margin is gone, so such geometries (not 1920x1080 at disp_max 255: 2.6e6) take the exhaustive pass.
     const bool wide = (double)d.H * ((double)d.W + 2.0 * p.disp_max) > 4194304.0;
-    const int fix_all = getenv("SVH_OWNER_FIX_ALL") ? atoi(getenv("SVH_OWNER_FIX_ALL")) : (wide ? 1 : 0);   // read per launch: tests toggle it
+    const int fix_all = svh::env("SVH_OWNER_FIX_ALL") ? atoi(svh::env("SVH_OWNER_FIX_ALL")) : (wide ? 1 : 0);   // read per launch: tests toggle it
     const dim3 go(xcd_blocks((nt + 3) / 4));   // (a multiple of 8: see the kernel's block order)
     LAUNCH("k_owner", k_owner<false>, go, dim3(256), G, total_tri, d.W, d.H,
            p.subsampling, 0);
@@ -2724,20 +2878,20 @@ void launch_owner(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
 // descriptor rows themselves (descriptors_on_the_fly).
 static bool match_list_usable(const svh_elas_params& p, const Dims& d, int32_t prior_absmax, int32_t plane_radius,
                               bool have_lists, MatchList* Qout, size_t* lds_out) {
-    static const bool ordered = getenv("SVH_MATCH_ORDERED") != nullptr;
+    static const bool ordered = svh::env("SVH_MATCH_ORDERED") != nullptr;
     const bool keyed_ok = !ordered && prior_absmax < (1 << 19) && p.disp_max < 512 && plane_radius <= 15 &&
                           d.W < 65536 && p.grid_size > 1;
-    static const bool list_off = getenv("SVH_MATCH_LIST") && atoi(getenv("SVH_MATCH_LIST")) == 0;
-    static const bool list_sub = !(getenv("SVH_MATCH_LIST_SUB") && atoi(getenv("SVH_MATCH_LIST_SUB")) == 0);
+    static const bool list_off = svh::env("SVH_MATCH_LIST") && atoi(svh::env("SVH_MATCH_LIST")) == 0;
+    static const bool list_sub = !(svh::env("SVH_MATCH_LIST_SUB") && atoi(svh::env("SVH_MATCH_LIST_SUB")) == 0);
     if (!(keyed_ok && !list_off && (!p.subsampling || list_sub) && d.gwords <= 8 && have_lists && prior_absmax < 28000 &&
           d.DW <= 8 * 256))
         return false;
     MatchList Q;
     Q.Wr = (d.W + 7) / 8 * 8;
-    Q.Ws = ((d.W + 1) & ~3) + 2;
+    Q.Ws = ((d.W + 3) & ~3) + 2;   // covers the last staging task of four slots, == 2 (mod 4)
     // threads per side: 256; rows of 1281 .. 1920 px, whose LDS footprint lets two blocks share a CU, take 384 (round
     // 5: 2 x 12 waves = 6 per SIMD with the 5-pixel instance instead of 2 x 8 = 4 per SIMD with the 8-pixel one)
-    static const bool wide768 = !(getenv("SVH_MATCH_WIDE768") && atoi(getenv("SVH_MATCH_WIDE768")) == 0);
+    static const bool wide768 = !(svh::env("SVH_MATCH_WIDE768") && atoi(svh::env("SVH_MATCH_WIDE768")) == 0);
     int iters = (d.DW + 255) / 256;
     Q.half = std::min(256, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
     if (iters > 5 && wide768 && d.DW <= 5 * 384) {
@@ -2745,7 +2899,7 @@ static bool match_list_usable(const svh_elas_params& p, const Dims& d, int32_t p
         Q.half = std::min(384, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
     }
     Q.kIters = iters <= 5 ? 5 : 8;
-    static const bool xcd_rows = !(getenv("SVH_MATCH_XCD") && atoi(getenv("SVH_MATCH_XCD")) == 0);
+    static const bool xcd_rows = !(svh::env("SVH_MATCH_XCD") && atoi(svh::env("SVH_MATCH_XCD")) == 0);
     Q.xcd = xcd_rows ? 1 : 0;
     const size_t ldsl = (size_t)2 * Q.Ws * sizeof(uint4) + (size_t)2 * d.gw * ML_CAP * sizeof(uint16_t) +
                         (size_t)2 * Q.Wr * sizeof(int16_t);
@@ -2772,7 +2926,7 @@ static bool match_list_usable(const svh_elas_params& p, const Dims& d, int32_t p
 // form; the decision before E1 asks for it).  *lds2_out: dynamic LDS of the launch.
 static bool match_keyed_usable(const svh_elas_params& p, const Dims& d, int32_t prior_absmax, int32_t plane_radius,
                                bool with_lr, size_t* lds2_out) {
-    static const bool ordered = getenv("SVH_MATCH_ORDERED") != nullptr;
+    static const bool ordered = svh::env("SVH_MATCH_ORDERED") != nullptr;
     const bool keyed_ok = !ordered && prior_absmax < (1 << 19) && p.disp_max < 512 && plane_radius <= 15 &&
                           d.W < 65536 && p.grid_size > 1;
     const size_t lds = (size_t)d.W * sizeof(uint4);
@@ -2799,8 +2953,8 @@ static bool match_keyed_usable(const svh_elas_params& p, const Dims& d, int32_t 
 // kernel, and the list form or (round 5: subsampling, disp_max > 255) the keyed form of the dense matcher.
 bool descriptors_on_the_fly(const svh_elas_params& p, const Dims& d, int32_t prior_absmax, int32_t plane_radius,
                             bool have_lists) {
-    static const bool off = getenv("SVH_DESC_FLY") && atoi(getenv("SVH_DESC_FLY")) == 0;
-    static const bool keyed_fly = !(getenv("SVH_DESC_FLY_KEYED") && atoi(getenv("SVH_DESC_FLY_KEYED")) == 0);
+    static const bool off = svh::env("SVH_DESC_FLY") && atoi(svh::env("SVH_DESC_FLY")) == 0;
+    static const bool keyed_fly = !(svh::env("SVH_DESC_FLY_KEYED") && atoi(svh::env("SVH_DESC_FLY_KEYED")) == 0);
     if (off || d.W < 8 || support_strip(p, d, nullptr) == 0) return false;
     if (match_list_usable(p, d, prior_absmax, plane_radius, have_lists, nullptr, nullptr)) return true;
     return keyed_fly && match_keyed_usable(p, d, prior_absmax, plane_radius, true, nullptr);
@@ -2857,7 +3011,7 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
         Timed timed_(cx, "k_match");
         // threads per map and row block: the row is covered in `iters` equal passes with little idle tail
         // threads per map (64..256; 256 measured best: isolated 32-pair launch 359 us vs 450 at 512 and 526 at 128)
-        static const int mt = std::min(256, std::max(64, getenv("SVH_MATCH_THREADS") ? atoi(getenv("SVH_MATCH_THREADS")) : 256));
+        static const int mt = std::min(256, std::max(64, svh::env("SVH_MATCH_THREADS") ? atoi(svh::env("SVH_MATCH_THREADS")) : 256));
         const int iters = (d.DW + mt - 1) / mt;
         const int half = std::min(256, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
         const dim3 grid(xcd_blocks(d.DH * g)), block(2 * half);   // (a multiple of 8: the kernel's XCD-aware row order)
@@ -2871,7 +3025,7 @@ bool launch_match(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, 
         hipLaunchKernelGGL(k_match_keyed<false>, grid, block, lds2, s, G, P, none, 1, 0.f);
     } else if (lds + kStaticLds <= 64 * 1024) {
         Timed timed_(cx, "k_match");
-        static const int mt = getenv("SVH_MATCH_THREADS") ? atoi(getenv("SVH_MATCH_THREADS")) : 256;
+        static const int mt = svh::env("SVH_MATCH_THREADS") ? atoi(svh::env("SVH_MATCH_THREADS")) : 256;
         const int iters = (d.DW + mt - 1) / mt;
         const int threads = std::min(512, ((d.DW + iters - 1) / iters + 63) / 64 * 64);
         hipLaunchKernelGGL(k_match<true>, dim3(1, d.DH, 2 * g), dim3(threads), lds,
@@ -2907,7 +3061,7 @@ void launch_segments_label(const LaunchCtx& cx, const svh_elas_params& p, const 
     if (p.subsampling) min_size = (int)(sqrtf((float)p.speckle_size) * 2);  // elas.cpp:1218
     const dim3 lin((n + 255) / 256, z), b256(256);
     const dim3 tiles((d.DW + CX - 1) / CX, (d.DH + CY - 1) / CY, z);
-    static const bool tile_xcd = !(getenv("SVH_TILE_XCD") && atoi(getenv("SVH_TILE_XCD")) == 0);
+    static const bool tile_xcd = !(svh::env("SVH_TILE_XCD") && atoi(svh::env("SVH_TILE_XCD")) == 0);
     if (tile_xcd)
         LAUNCH("k_seg_tile", k_seg_tile, dim3(xcd_blocks((int)(tiles.x * tiles.y * tiles.z))), dim3(CX, 4), G, in, S, nside,
                d.DW, d.DH, p.speckle_sim_threshold, z);
@@ -2934,7 +3088,7 @@ void launch_gap(const LaunchCtx& cx, const svh_elas_params& p, const Dims& d, in
         LAUNCH("k_gap_cols", k_gap_local<true>, grid2d(d.DW, d.DH, z), dim3(64, 4), G, out, S, nside,
                d.DW, d.DH, gap);
     } else {
-        static const bool seq = getenv("SVH_GAP_SEQ") && atoi(getenv("SVH_GAP_SEQ")) != 0;   // (A/B: the one-thread-per-line form)
+        static const bool seq = svh::env("SVH_GAP_SEQ") && atoi(svh::env("SVH_GAP_SEQ")) != 0;   // (A/B: the one-thread-per-line form)
         const int nch = (d.DW + 63) / 64;
         if (!seq && nch <= kGapChunks) {
             {
@@ -3244,7 +3398,7 @@ __global__ __launch_bounds__(256) void k_mean_tile(GroupDev G, DevMaps m, PostSc
 
 // the two tile kernels replace k_gap_rows/cols + k_mean_h/v (four map round trips -> two)
 bool post_tiles_ok(const svh_elas_params& p) {
-    static const bool off = getenv("SVH_NO_POST_TILES") != nullptr;
+    static const bool off = svh::env("SVH_NO_POST_TILES") != nullptr;
     int gap = p.ipol_gap_width;
     if (p.subsampling) gap = p.ipol_gap_width / 2 + 1;
     return !off && gap <= 4 && !p.add_corners && p.filter_adaptive_mean && !p.filter_median;
@@ -3257,7 +3411,7 @@ void launch_gap_mean_tiles(const LaunchCtx& cx, const svh_elas_params& p, const 
     const dim3 gr((d.DW + QX - 1) / QX, (d.DH + QY - 1) / QY, g * nside), b(64, 4);
     int min_size = p.speckle_size;
     if (p.subsampling) min_size = (int)(sqrtf((float)p.speckle_size) * 2);  // elas.cpp:1218
-    static const bool tile_xcd = !(getenv("SVH_TILE_XCD") && atoi(getenv("SVH_TILE_XCD")) == 0);
+    static const bool tile_xcd = !(svh::env("SVH_TILE_XCD") && atoi(svh::env("SVH_TILE_XCD")) == 0);
     const int nz = tile_xcd ? g * nside : 0;
     const dim3 gl = tile_xcd ? dim3(xcd_blocks((int)(gr.x * gr.y * gr.z))) : gr;
     LAUNCH("k_gap_tile", k_gap_tile, gl, b, G, out, S, nside, d.DW, d.DH, gap, min_size > 1 ? min_size : 0, nz);

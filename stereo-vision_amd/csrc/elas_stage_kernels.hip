@@ -903,11 +903,11 @@ static bool dt_large(const Dims& d) { return (size_t)d.Wc * d.Hc / 8 * 16 > 63 *
 // form at 63 KB (records of larger point sets then live in L2).
 // large point sets: ordering and build as two launches (SVH_DT_SPLIT=0: one launch, round 4's form)
 static bool dt_split() {
-    static const bool on = !(getenv("SVH_DT_SPLIT") && atoi(getenv("SVH_DT_SPLIT")) == 0);
+    static const bool on = !(svh::env("SVH_DT_SPLIT") && atoi(svh::env("SVH_DT_SPLIT")) == 0);
     return on;
 }
 static int dt_small_threads() {
-    static const int t = getenv("SVH_DT_THREADS") ? atoi(getenv("SVH_DT_THREADS")) : 512;
+    static const int t = svh::env("SVH_DT_THREADS") ? atoi(svh::env("SVH_DT_THREADS")) : 512;
     return t == 512 || t == 1024 ? t : 256;
 }
 static bool dt_lds_optin(bool big, size_t bytes) {
@@ -933,7 +933,7 @@ static bool dt_lds_optin(bool big, size_t bytes) {
 // blocks of k_match_list beside it -- with whole-record reads the build is short enough to pay for the one block
 // (SVH_DT_LDS_KB overrides: A/B in profiles/r05_delaunay.txt)
 static size_t dt_small_kb() {
-    static const size_t kb = getenv("SVH_DT_LDS_KB") ? (size_t)atoi(getenv("SVH_DT_LDS_KB")) : 96;
+    static const size_t kb = svh::env("SVH_DT_LDS_KB") ? (size_t)atoi(svh::env("SVH_DT_LDS_KB")) : 96;
     return std::min<size_t>(159, std::max<size_t>(kb, 8));
 }
 static size_t dt_lds_bytes(const svh_elas_params& p, const Dims& d, bool big) {
@@ -989,7 +989,7 @@ void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Di
     D.W = dt_columns(p, d); D.H = d.H; D.sup_cap = S.sup_cap; D.rec_cap = S.rec_cap;
     D.xoff = std::max(p.disp_max, 0);
     const bool big = dt_large(d) && dt_lds_optin(true, 159 * 1024);
-    static const int dt_spread = getenv("SVH_DT_SPREAD") ? atoi(getenv("SVH_DT_SPREAD")) : 64;
+    static const int dt_spread = svh::env("SVH_DT_SPREAD") ? atoi(svh::env("SVH_DT_SPREAD")) : 64;
     D.spread = big ? -1 : dt_spread;      // (large sets: every depth spread)
     // scalar seam walk (see dt_build): on for a group that is the ONLY one of its call (single call, batch entry with
     // one group): the device is far from full and nobody competes for the scalar units (batch entry, 8 / 16 / 32 pairs
@@ -997,7 +997,7 @@ void launch_stage_device(const LaunchCtx& cx, const svh_elas_params& p, const Di
     // groups on six workers lost 2 % (31.8 -> 31.1 k), deep batches 1.2 %, streams of 8-pair steps 1.8 % -- and for
     // large point sets (records in L2: 8-pair batches of 1920x1080 lost 5 % although the kernel alone got 6 %
     // faster).  SVH_DT_UNIFORM=0 / n: never / always with n nodes per wave
-    static const int dt_uniform = getenv("SVH_DT_UNIFORM") ? atoi(getenv("SVH_DT_UNIFORM")) : -1;
+    static const int dt_uniform = svh::env("SVH_DT_UNIFORM") ? atoi(svh::env("SVH_DT_UNIFORM")) : -1;
     D.uniform = dt_uniform >= 0 ? dt_uniform : (cx.latency && !big ? 1 : 0);
     const size_t dt_lds = dt_lds_bytes(p, d, big);
     D.lds_ints = (int)(dt_lds / 4);

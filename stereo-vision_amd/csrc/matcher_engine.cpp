@@ -63,7 +63,7 @@ ActiveCaller::~ActiveCaller() {
 }
 int wait_stream(void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    static const int forced = getenv("SVH_MATCHER_WAIT") ? atoi(getenv("SVH_MATCHER_WAIT")) : -1;   // 0 spin, 1 sleep-poll
+    static const int forced = svh::env("SVH_MATCHER_WAIT") ? atoi(svh::env("SVH_MATCHER_WAIT")) : -1;   // 0 spin, 1 sleep-poll
     const bool poll = forced >= 0 ? forced == 1 : g_active_callers.load(std::memory_order_relaxed) > 2;
     if (!poll) return (int)hipStreamSynchronize(s);
     for (;;) {
@@ -225,7 +225,7 @@ public:
             for (int i = 0; i < n; i++) fn(i);
             return;
         }
-        static const bool serial = getenv("SVH_POOL_SERIAL") && atoi(getenv("SVH_POOL_SERIAL")) != 0;
+        static const bool serial = svh::env("SVH_POOL_SERIAL") && atoi(svh::env("SVH_POOL_SERIAL")) != 0;
         std::unique_lock<std::mutex> one_call(call_mu_, std::defer_lock);
         if (serial) one_call.lock();
         Job job{&fn, n};
@@ -457,7 +457,12 @@ struct svh_matcher {
 static double mnow_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-static const bool g_mtiming = getenv("SVH_MATCHER_TIMING") != nullptr;
+// SVH_MATCHER_TIMING, evaluated at the first use (never while the library is loaded)
+static bool mtiming_on() {
+    static const bool on = svh::env("SVH_MATCHER_TIMING") != nullptr;
+    return on;
+}
+#define g_mtiming mtiming_on()
 enum { T_PACK = 0, T_PUSH_GPU, T_SPARSE, T_OUT1, T_PRIOR, T_DENSE, T_OUT2 };
 // SVH_MATCHER_TIMING=1: wall-clock of the phases of the lockstep entries, printed at exit
 struct BatchTiming {
@@ -671,7 +676,7 @@ static int remove_outliers(const svh_matcher_params& p, std::vector<svh_p_match>
     }
     std::vector<int32_t> tri((size_t)3 * (2 * n + 16));
     // the Matcher is a single-stream, latency-bound path: large votes triangulate on 4 threads
-    static const int par = getenv("SVH_DELAUNAY_PAR") ? atoi(getenv("SVH_DELAUNAY_PAR")) : 2;
+    static const int par = svh::env("SVH_DELAUNAY_PAR") ? atoi(svh::env("SVH_DELAUNAY_PAR")) : 2;
     // (several callers at once = several sequences on this GPU: their host threads already fill the
     // cores, the helper pool would only be fought over)
     const bool alone = g_active_callers.load(std::memory_order_relaxed) <= 2 && !t_in_batch;
@@ -1126,7 +1131,7 @@ static int32_t prefetch_body(const std::vector<svh_matcher*>& ms, const std::vec
     // Lockstep hand-over: the K * ncam image uploads are recorded with the features (one k_upload_b launch per camera
     // over the K objects instead of one k_upload per image -- 32 launches a call at K = 16); the packing threads then
     // launch nothing.  SVH_UPLOAD_BATCH=0: every packing thread launches its image's upload as soon as it is packed.
-    static const bool upload_batch = !(getenv("SVH_UPLOAD_BATCH") && atoi(getenv("SVH_UPLOAD_BATCH")) == 0);
+    static const bool upload_batch = !(svh::env("SVH_UPLOAD_BATCH") && atoi(svh::env("SVH_UPLOAD_BATCH")) == 0);
     const bool upload_recorded = lockstep && upload_batch;
     batch_parallel_for(K * ncam, [&](int j) {
         (void)hipSetDevice(ms[0]->device);
@@ -1300,7 +1305,7 @@ int32_t svh_matcher_push_back_batch(svh_matcher* const* ms, int32_t K, const uin
     // every image is packed instead of overlapping the packing, which costs less than 2 K launches from the packing
     // threads did: 2 x 16 objects 7.8-8.6 -> 8.7-9.0 k frames/s, 1 x 32 6.1-6.2 -> 6.3-6.6 k, 1 x 16 unchanged).
     // SVH_UPLOAD_BATCH=0: every packing thread launches its image's upload, rotating over the side streams.
-    static const bool upload_recorded = !(getenv("SVH_UPLOAD_BATCH") && atoi(getenv("SVH_UPLOAD_BATCH")) == 0);
+    static const bool upload_recorded = !(svh::env("SVH_UPLOAD_BATCH") && atoi(svh::env("SVH_UPLOAD_BATCH")) == 0);
     BatchPool::get().parallel_for(K * ncam, [&](int j) {
         (void)hipSetDevice(ms[0]->device);
         svh_matcher* m = ms[j / ncam];

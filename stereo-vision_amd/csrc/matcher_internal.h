@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "../../include/svh.h"
+#include "svh_config.h"
 
 namespace svh {
 

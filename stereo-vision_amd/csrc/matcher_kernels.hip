@@ -1068,7 +1068,7 @@ void mlaunch_copy(void* stream, void* dst, const void* src, size_t bytes, int ki
     // Small transfers go by a kernel as well: both ends are device-addressable (pinned host memory), and a copy
     // kernel in the stream's own queue spares the hand-over to a DMA engine and back (~15 us per copy; a frame has
     // five of them between kernels that wait for each other).
-    static const bool by_kernel = !(getenv("SVH_MATCHER_COPY_KERNEL") && atoi(getenv("SVH_MATCHER_COPY_KERNEL")) == 0);
+    static const bool by_kernel = !(svh::env("SVH_MATCHER_COPY_KERNEL") && atoi(svh::env("SVH_MATCHER_COPY_KERNEL")) == 0);
     if (by_kernel && bytes % 4 == 0 && bytes > 0 && bytes <= ((size_t)1 << 20)) {
         hipLaunchKernelGGL(k_copy4, dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
         return;

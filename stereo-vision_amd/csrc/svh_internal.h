@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/svh.h"
+#include "svh_config.h"
 
 namespace svh {
 
@@ -31,8 +32,9 @@ Dims make_dims(const svh_elas_params& p, int32_t W, int32_t H);
 constexpr int kMaxGroup = 32;
 
 // ---------------------------------------------------------------- fault injection (tests)
-// SVH_TEST_FAIL_AT=<kind>:<n>[:<count>] (environment, read once) or svh_test_fail_at("<kind>:<n>[:<count>]") at run
-// time: the n-th (1-based) HIP call of that kind in this process, counted from the moment the specification is set, is
+// TEST HOOK, not part of the public C-ABI (include/svh.h does not declare it; tests bind it by name, the sanitizer
+// drivers pass their SVH_TEST_FAIL_AT on): svh_test_fail_at("<kind>:<n>[:<count>]") arms it, "" / NULL disarms; the
+// library itself never reads a specification from the environment.  The n-th (1-based) HIP call of that kind in this process, counted from the moment the specification is set, is
 // NOT issued and reports an error instead, and so do the count-1 calls of the kind after it (count 0: every one from the
 // n-th on).  Kinds, as the engines' error macros see their calls:
 //   malloc  hipMalloc / hipHostMalloc              copy  hipMemcpy*Async / hipMemset*Async
@@ -43,6 +45,9 @@ constexpr int kMaxGroup = 32;
 bool fi_armed();
 bool fi_hit(const char* expr_text);
 void report_hip_failure(const char* entry);   // "svhip: <entry>: <last error>" on stderr, once per failing call
+}   // namespace svh
+extern "C" int32_t svh_test_fail_at(const char* spec);
+namespace svh {
 
 // Per-pair header, uploaded with the support points and triangle lists after
 // the host stage.  Triangles of all pairs and both sides are packed in one

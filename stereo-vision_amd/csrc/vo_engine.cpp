@@ -364,7 +364,7 @@ static int32_t process_batch(svh_vo* const* vs, int32_t K, const uint8_t* const*
         }
         return good;
     }
-    static const bool timing = getenv("SVH_MATCHER_TIMING") != nullptr;
+    static const bool timing = svh::env("SVH_MATCHER_TIMING") != nullptr;
     struct Acc {
         double t[5] = {0, 0, 0, 0, 0};
         int64_t calls = 0;

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "../../include/svh.h"
+#include "svh_config.h"
 
 namespace svh {
 
