@@ -651,6 +651,7 @@ def main():
                          "step is shorter than the pipeline is deep (sequence, hd1080), batch for kitti")
     ap.add_argument("--depth", type=int, default=0, help="stream: pairs in flight (0: lanes x 2 groups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bind", action="store_true", help="several ranks: do not bind a rank's threads to its GPU's NUMA node")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary legs (synthetic, host buffers, latency, Matcher, VO, map)")
     ap.add_argument("--cpu-budget", type=float, default=5.0, help="seconds per CPU baseline leg")
@@ -713,10 +714,12 @@ def main():
     # triangulation / pair) occupy their queue while using almost none of the machine: with 16 queues
     # every stream has its own (round 3: 28.2 k pairs/s at 8, 29.6 k at 16, 29.3-29.6 k at 24-32; round 2
     # measured 4 -> 8 at +4 %).  Must be set before the runtime starts; an explicit setting of the caller wins.
-    # (round 5: libsvhip sets 20 itself when it is loaded -- room for an RCCL communicator's streams, yet few enough
-    # that the idle streams of many Matcher / visual-odometry objects do not open queues that cost the device: see
-    # csrc/elas_engine.cpp -- and a C++ caller gets the same; set here as well so that os.environ, which `hw_queues`
-    # below reports, shows it)
+    # Round 6: libsvhip no longer edits the environment when it is loaded; a program asks for the count through
+    # svh_init (include/svh.h) BEFORE anything starts the HIP runtime -- the C++ callers (apps/svh_shard.cpp,
+    # tests/cxx/elas_dropin.cpp via the implicit initialisation) do exactly that.  This script cannot: the library must be
+    # loaded AFTER torch (torch ships its own copy of the HIP runtime, and the copy that is loaded first serves both), so
+    # it does what svh_init documents for such hosts -- it sets GPU_MAX_HW_QUEUES itself, as the host program, before the
+    # runtime starts; `library_init` in the line then reports "caller_set".
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
     devcount_so = os.path.join(ROOT, "tools", "libdevcount.so")
     if args.devcount:
@@ -763,7 +766,16 @@ def main():
 
     import svhip as S
     import helpers as Hh
+    library_init = S.init()          # (the explicit form of what the first svh_* call would do; the queues: see above)
     S.lib().svh_set_device(device_index)
+    # 8-GPU readiness (round 6): with several ranks, each one binds its threads (the engine's workers inherit the mask) to
+    # the CPUs of its GPU's NUMA node, at most its share of the host cores; the PCI address travels in the rank's record
+    # and rank 0 checks "one rank per device, distinct addresses" whenever there are enough devices
+    topo = S.device_topology(device_index)
+    cpus_bound = 0
+    if world > 1 and not args.no_bind:
+        share = max(1, int(len(os.sched_getaffinity(0)) // max(1, min(world, 8))))
+        cpus_bound = S.bind_host_to_device(device_index, share)
     S.set_stage({"auto": -1, "host": 0, "device": 1}[args.stage])
     build = S.lib().svh_version().decode()
     if args.workload == "sequence" and args.kitti_dir:
@@ -960,7 +972,8 @@ def main():
             R1, R2 = Hh.ref_elas_process(params, I1[k % U], I2[k % U])
             oracle_bad += float((dD1[k].cpu().numpy() != R1).sum() + (dD2[k].cpu().numpy() != R2).sum())
     rec = [float(my_pairs), float((dD1[0] >= 0).sum().item()), host_cores_used, float(lanes),
-           elapsed_local, cpu_s / my_pairs, float(device_index), oracle_bad]
+           elapsed_local, cpu_s / my_pairs, float(device_index), oracle_bad,
+           float(shard.pack_bus_id(topo["pci_bus_id"])), float(topo["numa_node"]), float(cpus_bound)]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -975,7 +988,12 @@ def main():
               # what this rank's share of the host cores could feed at that CPU cost per pair
               "host_core_ceiling_pairs_per_s": round(cores_per_rank / x[5]) if x[5] > 0 else None,
               "d1_valid_px_first_pair": int(x[1]),
-              "oracle_mismatch_px_first_two_pairs": (int(x[7]) if x[7] >= 0 else None)} for r, x in enumerate(recs)]
+              "oracle_mismatch_px_first_two_pairs": (int(x[7]) if x[7] >= 0 else None),
+              "pci_bus_id": shard.unpack_bus_id(int(x[8])), "numa_node": int(x[9]), "cpus_bound": int(x[10])}
+             for r, x in enumerate(recs)]
+    placement = shard.check_placement([(q["device"], q["pci_bus_id"]) for q in ranks], ndev)
+    if rank == 0 and world > 1 and not placement["ok"]:
+        raise SystemExit("bench.py: " + placement["why"])
 
     # ---- roofline of the dominant kernel.  Three measurements, kept apart:
     #   in_run     HIP events around its launches DURING the timed steps: ~10 kernels of different workers
@@ -1253,7 +1271,7 @@ def main():
                        "dist_backend": args.dist_backend if world > 1 else None,
                        "gpus_visible": ndev, "build": build, "stage": args.stage, "api": api,
                        "stream_depth_pairs": depth if api == "stream" else None,
-                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "preflight": preflight,
+                       "hw_queues": hwq, "library_init": library_init, "preflight": preflight, "placement": placement,
                        "stage_groups_device_handed_back": list(S.stage_stats()),
                        "d1_valid_fraction": round(valid, 4)},
             "ranks": ranks,
@@ -1306,6 +1324,42 @@ def main():
                 "note": "svh_elas_process_batch: pinned host images in, pinned host D1+D2 out (the reference's "
                         "ownership contract, SURVEY 8b); PCIe-inclusive, never `value`"}
             out["throughput_host_buffers"]["maps_equal_device_path"] = same
+            # ... and as a STREAM (round 6; BASELINE configs[2] is a sequence streamed frame by frame, the reference's
+            # producer hands host frames over, readfromfilesthread.cpp:25-112): a 430-frame sequence in pinned host
+            # memory through svh_elas_stream_push_n in rings of 43 frames, a consumer thread popping in order; maps
+            # back in host memory.  Timed from the first push to the last pop, 3 passes.
+            import threading as _th
+            ns, ring = 430, 43
+            ns = min(ns, nb)
+            srm = e.stream(W, H)
+            got = []
+
+            def seq_pass():
+                del got[:]
+                cons = _th.Thread(target=lambda: got.extend(srm.pop_n(ns)))
+                cons.start()
+                for r0 in range(0, ns, ring):
+                    k = min(ring, ns - r0)
+                    srm.push_n_raw(k, (C.c_void_p * k)(*a1[r0:r0 + k]), (C.c_void_p * k)(*a2[r0:r0 + k]),
+                                   (C.c_void_p * k)(*d1[r0:r0 + k]), (C.c_void_p * k)(*d2[r0:r0 + k]))
+                srm.flush()
+                cons.join()
+            hD1.zero_(); hD2.zero_()
+            seq_pass()
+            t = time.perf_counter()
+            for _ in range(3):
+                seq_pass()
+            dts = time.perf_counter() - t
+            srm.close()
+            same_s = bool(got == [0] * ns and all(
+                torch.equal(hD1[i].to(dev), dD1[i]) and torch.equal(hD2[i].to(dev), dD2[i]) for i in (0, 1, ns // 2, ns - 1)))
+            out["throughput_host_buffers_stream"] = {
+                "value": 3 * ns / dts, "unit": "pairs/s", "frames": ns, "passes": 3, "ring": ring,
+                "vs_batch_entry": round(3 * ns / dts / out["throughput_host_buffers"]["value"], 3),
+                "pcie_GBps": 3 * ns * 10 * N_PIX / dts / 1e9, "maps_equal_device_path": same_s,
+                "note": "svh_elas_stream_push_n / pop_n: a %d-frame sequence from pinned host frames, maps back to "
+                        "pinned host memory, submission order preserved; each pass includes the stream's ramp-up and "
+                        "drain (the sequence is shorter than a second); PCIe-inclusive, never `value`" % ns}
             del hI1, hI2, hD1, hD2
         if extras and args.workload == "kitti" and args.data == "urban":
             # the round-1 headline workload for comparison: seeded synthetic pairs, same step

@@ -83,7 +83,7 @@ const char* svh_last_error(void);
  *               4): 0 = the measured default, 20 (12 ELAS worker streams + spare; profiles/r05_hw_queues_*.txt),
  *               n > 0 = n, < 0 = hands off.  The runtime reads the variable when it starts, so it is written only
  *               if the runtime has NOT started in this process and the process has not set it itself;
- *               svh_runtime_info() tells which of the four cases applied.
+ *               svh_get_runtime_info() tells which of the four cases applied.
  *   elas_workers, elas_pairs_per_launch, elas_stage, wait_us   = svh_elas_set_lanes / _set_group / _set_stage and
  *               the workers' poll interval (0 / 0 / -1 / -1 = defaults: 6, automatic, automatic, 40 us).
  *   read_env    1 (default): the SVH_* environment switches listed below are honoured (A/B measurements);
@@ -117,8 +117,31 @@ typedef struct svh_runtime_info {
     int32_t read_env;
     int32_t reserved_[8];
 } svh_runtime_info;
-int32_t svh_runtime_info(svh_runtime_info* out);
+int32_t svh_get_runtime_info(svh_runtime_info* out);
 int32_t     svh_device_count(void);
+/* ---- where a GPU sits (one process per GPU) ------------------------------------------------------
+ * svh_get_device_topology: PCI bus id (hipDeviceGetPCIBusId), NUMA node (sysfs numa_node of that PCI device, -1 when the
+ * machine reports none) and the CPUs of that node (cpu_mask bit c = CPU c; cpulist as sysfs prints it; falls back to
+ * the device's local_cpulist, then to every online CPU).
+ * svh_bind_host_to_device: restricts the CALLING process' CPU mask to those CPUs (at most max_cpus of them, <= 0: all;
+ * intersected with the mask the process already has -- a container's quota is respected); threads created afterwards,
+ * the engine's included, inherit it.  Call it once per rank, before the first batch.  Returns the number of CPUs
+ * bound (0: nothing known or nothing allowed -- the mask is left alone) or a negative error.
+ * svh_topology_from_sysfs / svh_bind_host_to_topology: the two halves, for tests and for callers that know the bus id. */
+#define SVH_TOPO_MASK_WORDS 16
+typedef struct svh_device_topology {
+    int32_t  device;
+    int32_t  numa_node;
+    int32_t  n_cpus;
+    int32_t  reserved_;
+    char     pci_bus_id[32];
+    char     cpulist[256];
+    uint64_t cpu_mask[SVH_TOPO_MASK_WORDS];
+} svh_device_topology;
+int32_t     svh_get_device_topology(int32_t device, svh_device_topology* out);
+int32_t     svh_topology_from_sysfs(const char* sysfs_root, const char* pci_bus_id, svh_device_topology* out);
+int32_t     svh_bind_host_to_topology(const svh_device_topology* t, int32_t max_cpus);
+int32_t     svh_bind_host_to_device(int32_t device, int32_t max_cpus);
 /* bind the calling thread's subsequent svh_* objects to a HIP device */
 int32_t     svh_set_device(int32_t device);
 
@@ -228,6 +251,12 @@ int32_t svh_elas_stream_push_device_n(svh_elas_stream* s, int32_t n, const uint8
                                       size_t in_stride, float* dD1, float* dD2, size_t out_stride,
                                       uint64_t* first_ticket);
 int32_t svh_elas_stream_pop_n(svh_elas_stream* s, int32_t n, int32_t* status, int32_t* popped);
+/* the host-buffer form of push_device_n: n pairs through pointer arrays, as svh_elas_process_batch takes them
+ * (readfromfilesthread.cpp:63,104 hands host frames over one by one; a producer with a ring of n decoded frames hands
+ * them over in one call).  Frames whose buffers follow one another in memory travel in one strided copy per camera and
+ * group, finished groups come back the same way, on the lanes' own streams: both PCIe directions are busy at once. */
+int32_t svh_elas_stream_push_n(svh_elas_stream* s, int32_t n, const uint8_t* const* I1, const uint8_t* const* I2,
+                               float* const* D1, float* const* D2, uint64_t* first_ticket);
 
 /* Device buffers, pinned staging, streams and events live in a per-device pool of "lanes" that
  * outlives the svh_elas handles (callers build an Elas per frame).  svh_elas_trim() releases
@@ -256,6 +285,9 @@ int32_t svh_elas_set_stage(int32_t where);
  * many of them it handed back to the host path (coincident support points in a triangulation,
  * whose survivor depends on Triangle's pivot stream -- triangle.cpp:5446-5501, 6179-6196) */
 void svh_elas_stage_stats(int64_t* device_groups, int64_t* handed_back);
+/* the engine settings in effect: out[0] workers (svh_elas_set_lanes), out[1] pairs per launch (0: automatic by image
+ * size), out[2] stage (-1 / 0 / 1, svh_elas_set_stage), out[3] the workers' poll interval in microseconds */
+void svh_elas_get_settings(int32_t out[4]);
 
 /* Stage taps for parity tests: after a successful svh_elas_process() the
  * intermediate of the given stage (of the last pair processed through handle

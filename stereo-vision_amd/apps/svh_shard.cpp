@@ -16,7 +16,10 @@
 // every rank (replicated inputs: they must be equal across ranks; tests compare them with tests/golden/*.npz).
 //
 //   svh_shard --ranks N [--pairs-per-rank B | --total P] [--steps K] [--warmup W] [--gather auto|rccl|pipes]
-//             [--images DIR] [--lanes L] [--spinup-ms T] [--timeout-s S] [--selftest-gather]
+//             [--images DIR] [--lanes L] [--cores-per-rank C] [--no-bind] [--spinup-ms T] [--timeout-s S] [--selftest-gather]
+// Round 6 (8-GPU readiness): a rank binds its threads to at most C (16) CPUs of its GPU's NUMA node, the record carries
+// the GPU's PCI address, NUMA node, CPUs bound and CPU time; rank 0 checks "one rank per device, distinct PCI addresses"
+// whenever there are at least as many devices as ranks, and prints per-rank host cores beside the budget.
 #include <errno.h>
 #include <poll.h>
 #include <signal.h>
@@ -39,12 +42,26 @@
 
 namespace {
 
-constexpr int kRecWords = 16;   // one record = 16 x uint64
-enum { R_RANK, R_DEVICE, R_PAIRS, R_NS, R_STATUS, R_D1, R_D2 = R_D1 + 4, R_LO = R_D2 + 4, R_HI, R_SPARE };
+constexpr int kRecWords = 24;   // one record = 24 x uint64 (192 bytes)
+// R_BUS: the GPU's PCI address (domain << 16 | bus << 8 | device << 3 | function); R_NUMA: NUMA node + 1 (0: unknown) |
+// CPUs the rank bound itself to << 16 | CPUs of the node << 32; R_CPU_NS: process CPU time over the timed steps
+enum { R_RANK, R_DEVICE, R_PAIRS, R_NS, R_STATUS, R_D1, R_D2 = R_D1 + 4, R_LO = R_D2 + 4, R_HI, R_BUS, R_NUMA, R_CPU_NS, R_SPARE };
 static_assert(R_SPARE < kRecWords, "record layout");
+
+uint64_t pack_bus_id(const char* s) {   // "0000:c5:00.0"
+    unsigned dom = 0, bus = 0, dev = 0, fn = 0;
+    if (sscanf(s, "%x:%x:%x.%x", &dom, &bus, &dev, &fn) != 4) return 0;
+    return (uint64_t)dom << 16 | (uint64_t)(bus & 0xFF) << 8 | (uint64_t)(dev & 0x1F) << 3 | (uint64_t)(fn & 7);
+}
+double cpu_s() {
+    timespec t;
+    clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
 
 struct Options {
     int ranks = 1, per_rank = 256, lanes = 6, total = 0, steps = 5, warmup = 2, rank = -1, fd = -1, timeout_s = 900, spinup_ms = 1000;
+    int cores_per_rank = 16, bind = 1;   // host-core budget of a rank (its threads are bound to that many CPUs of its GPU's NUMA node)
     std::string gather = "auto", images = "tests/golden";
     bool selftest = false;
 };
@@ -313,6 +330,14 @@ int rank_main(const Options& o) {
     const int device = o.rank % ndev;
     if (svh_set_device(device) != SVH_OK || hipSetDevice(device) != hipSuccess) return fail(g, "cannot bind the device");
     const bool own_device = o.ranks <= ndev;
+    // where the GPU sits, and this rank's threads next to it: the CPUs of the GPU's NUMA node, at most the rank's core
+    // budget of them, inside whatever mask the process already has (include/svh.h: svh_bind_host_to_device).  Done before
+    // the engine starts its workers, which inherit the mask.
+    svh_device_topology topo;
+    memset(&topo, 0, sizeof topo);
+    topo.numa_node = -1;
+    (void)svh_get_device_topology(device, &topo);
+    const int bound = o.bind ? svh_bind_host_to_topology(&topo, o.cores_per_rank) : 0;
     if (o.gather == "rccl" && !own_device) return fail(g, "--gather rccl needs one device per rank");
     if ((o.gather == "rccl" || (o.gather == "auto" && own_device)) && !g.init_rccl()) return fail(g, "RCCL communicator");
 
@@ -373,10 +398,10 @@ int rank_main(const Options& o) {
     memset(rec, 0, sizeof rec);
     std::vector<uint64_t> all;
     if (!g.run(rec, all)) return fail(g, "barrier gather");   // every rank is warm: start together
-    const double t0 = now_s();
+    const double t0 = now_s(), c0 = cpu_s();
     for (int i = 0; i < o.steps; i++)
         if (!step()) return fail(g, "timed step");
-    const double t1 = now_s();
+    const double t1 = now_s(), c1 = cpu_s();
     // sums of the maps of this rank's first pair of every crop
     std::vector<float> h1(N), h2(N);
     rec[R_RANK] = (uint64_t)o.rank;
@@ -386,6 +411,9 @@ int rank_main(const Options& o) {
     rec[R_STATUS] = (uint64_t)bad;
     rec[R_LO] = (uint64_t)lo;
     rec[R_HI] = (uint64_t)hi;
+    rec[R_BUS] = pack_bus_id(topo.pci_bus_id);
+    rec[R_NUMA] = (uint64_t)(topo.numa_node + 1) | (uint64_t)(bound > 0 ? bound : 0) << 16 | (uint64_t)(topo.n_cpus > 0 ? topo.n_cpus : 0) << 32;
+    rec[R_CPU_NS] = (uint64_t)((c1 - c0) * 1e9);
     for (int i = 0; i < n && i < 4; i++) {
         const int k = (lo + i) & 3;
         if (hipMemcpy(h1.data(), dD1 + (size_t)i * N, N * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
@@ -409,15 +437,29 @@ int rank_main(const Options& o) {
                 if (q[R_D1 + k] && (q[R_D1 + k] != ref1[k] || q[R_D2 + k] != ref2[k])) equal = false;
             }
         }
+        // one rank per device?  (RCCL needs it; a scaling run is only what it says if it holds)
+        bool distinct = true;
+        for (int r = 0; r < o.ranks; r++)
+            for (int q2 = 0; q2 < r; q2++) {
+                const uint64_t* a = all.data() + (size_t)r * kRecWords;
+                const uint64_t* b = all.data() + (size_t)q2 * kRecWords;
+                if (a[R_DEVICE] == b[R_DEVICE] || (a[R_BUS] && a[R_BUS] == b[R_BUS])) distinct = false;
+            }
+        if (own_device && !distinct) {
+            fprintf(stderr, "svh_shard: %d ranks on %d devices, yet two ranks report the same device / PCI address\n", o.ranks, ndev);
+            rc = 1;
+        }
         const double secs = 1e-9 * (double)ns_max;
         printf("{\"driver\": \"svh_shard (C++ over the C-ABI)\", \"library\": \"%s\", \"metric\": \"stereo pairs/sec (ELAS %dx%d, ROBOTICS, D1+D2+LR)\", "
                "\"value\": %.1f, \"unit\": \"pairs/s\", \"ranks\": %d, \"devices\": %d, \"gather\": \"%s\", \"gather_rounds\": %ld, "
                "\"lanes\": %d, \"hw_queues\": \"%s\", \"steps\": %d, \"warmup\": %d, \"pairs\": %llu, \"seconds_max_over_ranks\": %.6f, \"scaling\": \"%s\", "
-               "\"pairs_failed\": %llu, \"maps_equal_across_ranks\": %s, ",
+               "\"pairs_failed\": %llu, \"maps_equal_across_ranks\": %s, \"ranks_seen\": %d, \"one_rank_per_device\": %s, "
+               "\"host_core_budget_per_rank\": %d, \"record_bytes\": %d, ",
                svh_version(), W, H, secs > 0 ? (double)pairs / secs : 0.0, o.ranks, ndev, g.rccl ? "rccl" : "pipes",
                g.rccl ? g.rounds_rccl : g.rounds_pipes, o.lanes, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "runtime default",
                o.steps, o.warmup, (unsigned long long)pairs, secs,
-               o.total > 0 ? "strong" : "weak", (unsigned long long)badsum, equal ? "true" : "false");
+               o.total > 0 ? "strong" : "weak", (unsigned long long)badsum, equal ? "true" : "false", (int)(all.size() / kRecWords),
+               distinct ? "true" : "false", o.cores_per_rank, (int)(kRecWords * sizeof(uint64_t)));
         printf("\"d1_fnv1a\": [");
         for (int k = 0; k < 4; k++) printf("%s\"%016llx\"", k ? ", " : "", (unsigned long long)ref1[k]);
         printf("], \"d2_fnv1a\": [");
@@ -426,13 +468,17 @@ int rank_main(const Options& o) {
         for (int r = 0; r < o.ranks; r++) {
             const uint64_t* q = all.data() + (size_t)r * kRecWords;
             const double s = 1e-9 * (double)q[R_NS];
-            printf("%s{\"rank\": %llu, \"device\": %llu, \"slice\": [%llu, %llu], \"pairs\": %llu, \"seconds\": %.6f, \"pairs_per_s\": %.1f}",
-                   r ? ", " : "", (unsigned long long)q[R_RANK], (unsigned long long)q[R_DEVICE], (unsigned long long)q[R_LO],
+            printf("%s{\"rank\": %llu, \"device\": %llu, \"pci_bus_id\": \"%04llx:%02llx:%02llx.%llx\", \"numa_node\": %d, \"cpus_of_node\": %d, "
+                   "\"cpus_bound\": %d, \"host_cores_used\": %.2f, \"slice\": [%llu, %llu], \"pairs\": %llu, \"seconds\": %.6f, \"pairs_per_s\": %.1f}",
+                   r ? ", " : "", (unsigned long long)q[R_RANK], (unsigned long long)q[R_DEVICE],
+                   (unsigned long long)(q[R_BUS] >> 16), (unsigned long long)(q[R_BUS] >> 8 & 0xFF), (unsigned long long)(q[R_BUS] >> 3 & 0x1F),
+                   (unsigned long long)(q[R_BUS] & 7), (int)(q[R_NUMA] & 0xFFFF) - 1, (int)(q[R_NUMA] >> 32), (int)(q[R_NUMA] >> 16 & 0xFFFF),
+                   s > 0 ? 1e-9 * (double)q[R_CPU_NS] / s : 0.0, (unsigned long long)q[R_LO],
                    (unsigned long long)q[R_HI], (unsigned long long)q[R_PAIRS], s, s > 0 ? (double)q[R_PAIRS] / s : 0.0);
         }
         printf("]}\n");
         fflush(stdout);
-        rc = (equal && !badsum) ? 0 : 1;
+        rc = (equal && !badsum && !(own_device && !distinct)) ? 0 : 1;
     }
     svh_elas_destroy(e);
     (void)hipFree(dI1);
@@ -456,6 +502,8 @@ bool parse(int argc, char** argv, Options& o) {
         else if (a == "--fd") { if (!val(&o.fd)) return false; }
         else if (a == "--timeout-s") { if (!val(&o.timeout_s)) return false; }
         else if (a == "--lanes") { if (!val(&o.lanes)) return false; }
+        else if (a == "--cores-per-rank") { if (!val(&o.cores_per_rank)) return false; }
+        else if (a == "--no-bind") o.bind = 0;
         else if (a == "--spinup-ms") { if (!val(&o.spinup_ms)) return false; }
         else if (a == "--gather" && i + 1 < argc) o.gather = argv[++i];
         else if (a == "--images" && i + 1 < argc) o.images = argv[++i];
@@ -473,9 +521,17 @@ int main(int argc, char** argv) {
     if (!parse(argc, argv, o)) {
         fprintf(stderr,
                 "usage: %s --ranks N [--pairs-per-rank B | --total P] [--steps K] [--warmup W] [--gather auto|rccl|pipes]\n"
-                "          [--images DIR] [--lanes L] [--spinup-ms T] [--timeout-s S] [--selftest-gather]\n", argv[0]);
+                "          [--images DIR] [--lanes L] [--cores-per-rank C] [--no-bind] [--spinup-ms T] [--timeout-s S] [--selftest-gather]\n", argv[0]);
         return 2;
     }
     if (o.selftest) o.gather = "pipes";
+    if (o.rank >= 0) {
+        // a rank: fix the library's process settings first (before RCCL or anything else starts the HIP runtime, so that
+        // the hardware-queue count the engine wants can still be asked for) -- svh_init, include/svh.h
+        svh_config cfg;
+        svh_config_default(&cfg);
+        if (o.lanes > 0) cfg.elas_workers = o.lanes;
+        svh_init(&cfg);
+    }
     return o.rank < 0 ? launcher(o, argv) : rank_main(o);
 }

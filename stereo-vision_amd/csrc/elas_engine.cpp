@@ -413,10 +413,23 @@ namespace { struct ConfigHook { ConfigHook() { svh::on_config(apply_config); } }
 // pairs per launch for an image of N pixels: the default (32) is meant for KITTI-size pairs, whose
 // group holds ~1.5 GB of lane buffers; much larger images get proportionally smaller groups (1920x1080:
 // 16 -- round 5 measured 6.5 k pairs/s at 8 per launch, 7.1-7.3 k at 16, a collapse to 4.5 k at 32)
+// The automatic value is also bounded by the device's FREE memory (round 6; the defaults were tuned on one 288 GB
+// part): every worker holds two buffer sets of ~120 bytes per pixel and pair (maps, descriptors / planes, ownership,
+// labels, stage scratch), and all the workers' sets together take at most half of what hipMemGetInfo reports free on
+// the calling thread's device -- a smaller device, or many ranks on one, get smaller groups instead of a failing
+// hipMalloc.  An explicit svh_elas_set_group / svh_config::elas_pairs_per_launch is taken as is.
 static int group_for(size_t N) {
     const int g = std::max(1, std::min(g_group.load(), kMaxGroup));
     if (g_group_set.load()) return g;
-    return (int)std::max<size_t>(1, std::min<size_t>(g, (size_t)32 * 1024 * 1024 / std::max<size_t>(N, 1)));
+    size_t a = std::max<size_t>(1, std::min<size_t>(g, (size_t)32 * 1024 * 1024 / std::max<size_t>(N, 1)));
+    size_t free_b = 0, total_b = 0;
+    if (a > 1 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+        const size_t per_pair = 120 * std::max<size_t>(N, 1), sets = (size_t)2 * std::max(1, g_lanes.load());
+        a = std::max<size_t>(1, std::min<size_t>(a, free_b / 2 / (per_pair * sets)));
+    } else {
+        (void)hipGetLastError();
+    }
+    return (int)a;
 }
 
 static Pool* pool_for(int device) {
@@ -1749,6 +1762,18 @@ int32_t svh_elas_stream_push_device_n(svh_elas_stream* s, int32_t n, const uint8
     return SVH_OK;
 }
 
+int32_t svh_elas_stream_push_n(svh_elas_stream* s, int32_t n, const uint8_t* const* I1, const uint8_t* const* I2,
+                               float* const* D1, float* const* D2, uint64_t* first_ticket) {
+    if (n < 0 || (n > 0 && (!I1 || !I2 || !D1 || !D2))) return fail(SVH_ERR_BAD_ARG, "bad count / null pointer array");
+    for (int32_t i = 0; i < n; i++) {
+        uint64_t t = 0;
+        const int32_t rc = stream_push(s, false, I1[i], I2[i], D1[i], D2[i], &t);
+        if (rc) return rc;
+        if (i == 0 && first_ticket) *first_ticket = t;
+    }
+    return SVH_OK;
+}
+
 int32_t svh_elas_stream_pop_n(svh_elas_stream* s, int32_t n, int32_t* status, int32_t* popped) {
     int32_t first_bad = SVH_OK, k = 0;
     for (; k < n; k++) {
@@ -1833,6 +1858,14 @@ void svh_debug_stage_stamps(int64_t* out32) {
 void svh_elas_stage_stats(int64_t* device_groups, int64_t* handed_back) {
     if (device_groups) *device_groups = g_stage_dev_groups.load();
     if (handed_back) *handed_back = g_stage_redo_groups.load();
+}
+
+void svh_elas_get_settings(int32_t out[4]) {
+    if (!out) return;
+    out[0] = g_lanes.load();
+    out[1] = g_group_set.load() ? g_group.load() : 0;
+    out[2] = g_stage_mode.load();
+    out[3] = g_wait_us;
 }
 
 int32_t svh_elas_set_group(int32_t pairs) {

@@ -683,7 +683,7 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
     if (kFly) {
         // the four strips (rows v-2 / v+2 of both images) assembled from the Sobel planes, four aligned pixels per task
         const uint8_t* pl1 = desc_all + (size_t)(2 * pair) * N16 * 16;
-        const uint8_t* pl2 = pl1 + N16 * 16;
+        const uint32_t fpitch = (uint32_t)fly_pitch(P.W), vplane = (uint32_t)P.H * fpitch, imstride = (uint32_t)(N16 * 16);
         const int al0 = xl0 & ~3, ar0 = xr0 & ~3;
         const int nl = (xl1 - al0) / 4 + 1, nr = (xr1 - ar0) / 4 + 1;      // tasks per row of the left / right strip
         // Lane l takes strip row (l & 3) -- left v-2, left v+2, right v-2, right v+2 -- and the rows start at slots
@@ -696,7 +696,15 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
             if (j >= (rgt ? nr : nl)) continue;
             const int x = (rgt ? ar0 : al0) + 4 * j;
             uint4 o[4];
-            fly_desc4(rgt ? pl2 : pl1, P.W, P.H, x, v + (row ? 2 : -2), o);
+            // (round 6: scalar base + 32-bit lane offset, see fly_desc4_off; rows v -+ 2 are interior ones here -- v is in
+            // [5, H - 6] --, the columns outside 3 .. W-4 are zeroed on the few tasks that touch them)
+            fly_desc4_off(pl1, (rgt ? imstride : 0u) + (uint32_t)(v + (row ? 2 : -2)) * fpitch + 8u + (uint32_t)x, fpitch,
+                          vplane, o);
+            if (x == 0 || x + 4 > P.W - 3) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (x + i < 3 || x + i >= P.W - 3) o[i] = make_uint4(0, 0, 0, 0);
+            }
             const int x0 = rgt ? xr0 : xl0, x1 = rgt ? xr1 : xl1, w = rgt ? wrs : wls;
             uint4* dst = (rgt ? sR : sL) + row * w - x0;
 #pragma unroll
@@ -709,7 +717,12 @@ __global__ __launch_bounds__(kST) void k_support_lds(const uint8_t* __restrict__
             if (task < nr) {
                 const int x = ar0 + 4 * task;
                 uint4 o[4];
-                fly_desc4(pl2, P.W, P.H, x, v, o);
+                fly_desc4_off(pl1, imstride + (uint32_t)v * fpitch + 8u + (uint32_t)x, fpitch, vplane, o);
+                if (x == 0 || x + 4 > P.W - 3) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (x + i < 3 || x + i >= P.W - 3) o[i] = make_uint4(0, 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     if (x + i >= xr0 && x + i <= xr1) s_texR[x + i - xr0] = (uint16_t)texture16(o[i]);

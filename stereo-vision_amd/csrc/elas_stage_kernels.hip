@@ -481,7 +481,8 @@ __device__ __forceinline__ void dt_build(const M& mesh, int m, int depth, const 
 // a triangulation held 159 KB of LDS, i.e. a whole CU, for its entire duration.
 template <int kT, int kPhase>
 __global__ __launch_bounds__(kT) void k_delaunay(StageDev S, DtParams P) {
-    extern __shared__ int s_hist[];   // [W + 1] column starts, [H + 1] row starts, then two cursors copies
+    // (16-byte aligned: MeshL reads whole 8-byte records through this base -- dt_core.h -- whatever static LDS precedes it)
+    extern __shared__ __attribute__((aligned(16))) int s_hist[];   // [W + 1] column starts, [H + 1] row starts, then two cursors copies
     __shared__ int s_scan[kT / 64 + 1];
     __shared__ int s_m;               // points left after coincident ones were dropped (-1: stack overflow)
     const int slot = blockIdx.x, pair = slot >> 1, side = slot & 1, tid = threadIdx.x;

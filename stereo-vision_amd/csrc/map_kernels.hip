@@ -25,6 +25,7 @@
 #include "../../include/matrix.h"
 #include "../../include/svh.h"
 #include "../../include/svh_map.h"
+#include "svh_config.h"
 
 namespace svh {
 int fail(int code, const std::string& msg);   // elas_engine.cpp: sets svh_last_error()
@@ -358,6 +359,7 @@ static int32_t map_ensure(svh_map* m, int32_t w, int32_t h) {
 extern "C" {
 
 svh_map* svh_map_create(const svh_map_params* p) {
+    svh::ensure_init();
     if (!p) return nullptr;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1) {

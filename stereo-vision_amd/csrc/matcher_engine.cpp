@@ -933,6 +933,7 @@ void svh_matcher_params_default(svh_matcher_params* p) {
 
 svh_matcher* svh_matcher_create(const svh_matcher_params* p) {
     if (!p) return nullptr;
+    svh::ensure_init();
     svh_matcher* m = new svh_matcher();
     m->p = *p;
     m->margin = 8 + 1;                                      // matcher.cpp:56
@@ -1032,7 +1033,7 @@ static int32_t push_prepare(svh_matcher* m, const uint8_t* I1, const uint8_t* I2
     if (w <= 0 || h <= 0 || pitch < w || I1 == 0) {
         // matcher.cpp:110-114
         fprintf(stderr, "ERROR: Image dimension mismatch!\n");
-        return SVH_ERR_BAD_DIMS;   // (its own code: callers that mimic the reference ignore THIS one only)
+        return mfail(SVH_ERR_BAD_DIMS, "image dimension mismatch");   // (its own code: callers that mimic the reference ignore THIS one only)
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1197,7 +1198,7 @@ int32_t svh_matcher_prefetch_batch(svh_matcher* const* ms, int32_t K, const uint
                                    const uint8_t* const* I2, const int32_t* dims) {
     if (!ms || K <= 0 || !I1 || !dims) return mfail(SVH_ERR_BAD_ARG, "null argument");
     const int32_t w = dims[0], h = dims[1], pitch = dims[2];
-    if (w <= 0 || h <= 0 || pitch < w) return mfail(SVH_ERR_BAD_ARG, "image dimension mismatch");
+    if (w <= 0 || h <= 0 || pitch < w) return mfail(SVH_ERR_BAD_DIMS, "image dimension mismatch");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return mfail(SVH_ERR_NO_DEVICE, "no HIP device visible: libsvhip has no CPU fallback");

@@ -1,4 +1,4 @@
-// svh_init / svh_config / svh_runtime_info (include/svh.h): the library's process-wide settings, fixed explicitly by
+// svh_init / svh_config / svh_get_runtime_info (include/svh.h): the library's process-wide settings, fixed explicitly by
 // the host program or implicitly at the first use of the library -- never when the library is loaded.
 //
 // Round 5 set GPU_MAX_HW_QUEUES from a load-time constructor (a library editing its host's environment, racing with
@@ -9,7 +9,7 @@
 //     < 0: hands off), and the variable is only written if the HIP runtime has not started in this process and the
 //     process has not set it itself;
 //   * a process that never calls svh_init gets svh_init(NULL) at its first svh_* call that needs the device;
-//   * svh_runtime_info() says what happened (asked / applied / too late / left to the caller).
+//   * svh_get_runtime_info() says what happened (asked / applied / too late / left to the caller).
 #include <dirent.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -138,7 +138,7 @@ void svh_config_default(svh_config* c) {
 
 int32_t svh_init(const svh_config* c) { return svh::fix(c, true); }
 
-int32_t svh_runtime_info(svh_runtime_info* out) {
+int32_t svh_get_runtime_info(svh_runtime_info* out) {
     if (!out) return SVH_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(svh::g_mu);
     *out = svh::g_info;

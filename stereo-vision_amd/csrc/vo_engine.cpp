@@ -246,6 +246,7 @@ void svh_vo_params_default(svh_vo_params* p) {
 }
 
 svh_vo* svh_vo_create(const svh_vo_params* p) {
+    svh::ensure_init();
     if (!p) return nullptr;
     svh_vo* v = new svh_vo();
     v->p = *p;

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVH_LIB") or os.path.join(os.path.dirname(_HERE), "libsvhip.so")
 
 OK, ERR_FEW_SUPPORT, ERR_BAD_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = 0, 1, -1, -2, -3, -4
+ERR_BAD_DIMS = -7    # Matcher::pushBack / prefetch with bad dimensions (the reference's message, call ignored)
 ROBOTICS, MIDDLEBURY = 0, 1
 
 
@@ -34,6 +35,73 @@ class ElasParams(C.Structure):
         ("filter_adaptive_mean", C.c_int32), ("postprocess_only_left", C.c_int32),
         ("subsampling", C.c_int32),
     ]
+
+
+class Config(C.Structure):
+    """svh_config (include/svh.h): the process-wide settings svh_init fixes."""
+    _fields_ = [("size", C.c_uint32), ("hw_queues", C.c_int32), ("elas_workers", C.c_int32),
+                ("elas_pairs_per_launch", C.c_int32), ("elas_stage", C.c_int32), ("wait_us", C.c_int32),
+                ("read_env", C.c_int32), ("reserved_", C.c_int32 * 9)]
+
+
+class RuntimeInfo(C.Structure):
+    """svh_runtime_info (include/svh.h)"""
+    _fields_ = [("initialised", C.c_int32), ("implicit", C.c_int32), ("hw_queues_asked", C.c_int32),
+                ("hw_queues_state", C.c_int32), ("hw_queues_env", C.c_int32), ("hip_started_before", C.c_int32),
+                ("env_modified", C.c_int32), ("read_env", C.c_int32), ("reserved_", C.c_int32 * 8)]
+
+    def as_dict(self):
+        names = {0: "none", 1: "applied", 2: "caller_set", 3: "too_late", 4: "hands_off"}
+        d = {n: getattr(self, n) for n, _ in self._fields_[:-1]}
+        d["hw_queues_state"] = names.get(self.hw_queues_state, self.hw_queues_state)
+        return d
+
+
+def init(**fields):
+    """svh_init(&cfg) with the given svh_config fields over the defaults.  Call it before anything in the process
+    starts the HIP runtime (e.g. before `import torch`): the hardware-queue count can only be asked for until then."""
+    cfg = Config()
+    lib().svh_config_default(C.byref(cfg))
+    for k, v in fields.items():
+        setattr(cfg, k, v)
+    rc = lib().svh_init(C.byref(cfg))
+    if rc < 0:
+        raise SvhError(rc, "svh_init: bad configuration")
+    return runtime_info()
+
+
+class DeviceTopology(C.Structure):
+    """svh_device_topology (include/svh.h)"""
+    _fields_ = [("device", C.c_int32), ("numa_node", C.c_int32), ("n_cpus", C.c_int32), ("reserved_", C.c_int32),
+                ("pci_bus_id", C.c_char * 32), ("cpulist", C.c_char * 256), ("cpu_mask", C.c_uint64 * 16)]
+
+
+def device_topology(device):
+    """PCI bus id, NUMA node and the node's CPUs of a HIP device (svh_get_device_topology)"""
+    t = DeviceTopology()
+    rc = lib().svh_get_device_topology(int(device), C.byref(t))
+    if rc < 0:
+        raise SvhError(rc, "svh_get_device_topology")
+    return {"device": t.device, "pci_bus_id": t.pci_bus_id.decode(), "numa_node": t.numa_node, "cpus_of_node": t.n_cpus,
+            "cpulist": t.cpulist.decode()}
+
+
+def bind_host_to_device(device, max_cpus=0):
+    """restrict this process (and the threads it creates from now on) to the CPUs next to the GPU; returns how many"""
+    return int(lib().svh_bind_host_to_device(int(device), int(max_cpus)))
+
+
+def elas_settings():
+    """svh_elas_get_settings: workers, pairs per launch (0 = automatic), stage, poll interval [us]"""
+    out = (C.c_int32 * 4)()
+    lib().svh_elas_get_settings(out)
+    return dict(workers=out[0], pairs_per_launch=out[1], stage=out[2], wait_us=out[3])
+
+
+def runtime_info():
+    ri = RuntimeInfo()
+    lib().svh_get_runtime_info(C.byref(ri))
+    return ri.as_dict()
 
 
 class SvhError(RuntimeError):
@@ -73,6 +141,7 @@ def lib():
         L.svh_elas_stream_push_device_n.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
                                                     C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
         L.svh_elas_stream_pop_n.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
+        L.svh_elas_stream_push_n.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 4 + [C.POINTER(C.c_uint64)]
         L.svh_elas_set_taps.argtypes = [C.c_void_p, C.c_int32]
         L.svh_elas_get_stage.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
                                          C.POINTER(C.c_size_t)]
@@ -123,6 +192,27 @@ class ElasStream:
         """n consecutive device-resident pairs in one call (blocks while the stream is full)"""
         t = C.c_uint64(0)
         rc = lib().svh_elas_stream_push_device_n(self._h, n, dI1, dI2, in_stride, dD1, dD2, out_stride, C.byref(t))
+        if rc < 0:
+            raise SvhError(rc, last_error())
+        return t.value
+
+    def push_n(self, I1s, I2s, D1s, D2s):
+        """n host pairs in one call: arrays [n,H,W] (uint8 images, float32 maps written in place); they must stay
+        alive and unread until popped -- the stream keeps a reference"""
+        n = len(I1s)
+        arr = C.c_void_p * n
+        a = [arr(*[int(X[i].ctypes.data) for i in range(n)]) for X in (I1s, I2s, D1s, D2s)]
+        t = C.c_uint64(0)
+        rc = lib().svh_elas_stream_push_n(self._h, n, a[0], a[1], a[2], a[3], C.byref(t))
+        if rc < 0:
+            raise SvhError(rc, last_error())
+        self._keep[("n", t.value)] = (I1s, I2s, D1s, D2s)
+        return t.value
+
+    def push_n_raw(self, n, a1, a2, d1, d2):
+        """the same with ready-made ctypes pointer arrays (no per-call marshalling); the caller keeps the buffers alive"""
+        t = C.c_uint64(0)
+        rc = lib().svh_elas_stream_push_n(self._h, n, a1, a2, d1, d2, C.byref(t))
         if rc < 0:
             raise SvhError(rc, last_error())
         return t.value

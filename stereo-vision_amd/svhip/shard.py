@@ -36,3 +36,34 @@ def run_sharded(n_items, process_fn, dist=None, device=None):
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     lo, hi = shard_range(n_items, rank, world)
     return gather_records(process_fn(lo, hi), dist, device)
+
+
+# ---- placement of the ranks (8-GPU readiness): PCI addresses travel in the records as one number ---------------------
+def pack_bus_id(s):
+    """'0000:c5:00.0' -> domain << 16 | bus << 8 | device << 3 | function (0 for anything else)"""
+    try:
+        dom, bus, rest = s.strip().split(":")
+        dev, fn = rest.split(".")
+        return int(dom, 16) << 16 | (int(bus, 16) & 0xFF) << 8 | (int(dev, 16) & 0x1F) << 3 | (int(fn, 16) & 7)
+    except (ValueError, AttributeError):
+        return 0
+
+
+def unpack_bus_id(v):
+    return "%04x:%02x:%02x.%x" % (v >> 16, v >> 8 & 0xFF, v >> 3 & 0x1F, v & 7) if v else ""
+
+
+def check_placement(ranks, devices_visible):
+    """ranks: [(device index, pci bus id)] in rank order.  With at least as many devices as ranks every rank must have a
+    device of its own and the PCI addresses must differ (a scaling curve means nothing otherwise, and RCCL refuses);
+    with fewer devices the ranks share, which the report says.  Returns {"ok", "why", "ranks_seen", "shared"}."""
+    n = len(ranks)
+    devs = [d for d, _ in ranks]
+    buses = [b for _, b in ranks if b]
+    shared = len(set(devs)) < n or len(set(buses)) < len(buses)
+    out = {"ranks_seen": n, "devices_visible": int(devices_visible), "one_rank_per_device": not shared, "ok": True, "why": ""}
+    if devices_visible >= n and shared:
+        out["ok"] = False
+        out["why"] = ("%d ranks on %d visible devices, yet two ranks report the same device or PCI address: %s"
+                      % (n, devices_visible, ranks))
+    return out

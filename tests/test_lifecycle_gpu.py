@@ -80,3 +80,34 @@ def test_trim_releases_the_idle_lanes():
         S.set_lanes(8)
         S.set_group(16)
         S.trim()
+
+
+def test_a_plain_process_gets_the_engines_settings_without_any_environment_variable():
+    """svh_init by first use (include/svh.h): a fresh process that loads only libsvhip -- no torch, no environment
+    variable -- runs a batch; the library asked the HIP runtime for 20 hardware queues before the runtime started
+    (state "applied"), and the maps are the reference's"""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import helpers as H, svhip as S
+before = S.runtime_info()
+z = np.load(os.path.join(H.GOLDEN, "urban3_demo.npz"))
+prm = H.ElasParams.from_buffer_copy(z["params"].tobytes())
+l, r = H.golden_pair(str(z["crop"]))
+st, D1, D2 = S.Elas(prm).process_batch(np.stack([l] * 5), np.stack([r] * 5))
+ok = st == [0] * 5 and all(np.array_equal(D1[k].ravel(), z["d1"]) and np.array_equal(D2[k].ravel(), z["d2"]) for k in range(5))
+print(json.dumps({"before": before, "after": S.runtime_info(), "settings": S.elas_settings(), "ok": bool(ok)}))
+''' % (os.path.join(H.ROOT, "stereo-vision_amd"), os.path.join(H.ROOT, "tests"))
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "SVH_HW_QUEUES")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["before"]["initialised"] == 0 and out["before"]["env_modified"] == 0
+    a = out["after"]
+    assert a["initialised"] == 1 and a["implicit"] == 1 and a["hip_started_before"] == 0
+    assert a["hw_queues_state"] == "applied" and a["hw_queues_env"] == 20 and a["env_modified"] == 1
+    assert out["settings"]["workers"] == 6 and out["ok"]

@@ -148,3 +148,25 @@ def test_bench_two_ranks_on_this_box():
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["ranks"]) == 2
     assert sum(x["pairs"] for x in d["ranks"]) == 2 * 2 * 64
     assert d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_placement_check_and_bus_id_packing():
+    """8-GPU readiness (round 6): PCI addresses travel in the per-rank records as one number; rank 0 refuses a run in
+    which two ranks landed on one device although there were enough devices, and reports sharing otherwise"""
+    from svhip import shard
+    for s in ("0000:c5:00.0", "0001:03:1f.7", "ffff:ff:00.1"):
+        assert shard.unpack_bus_id(shard.pack_bus_id(s)) == s
+        assert float(shard.pack_bus_id(s)) == shard.pack_bus_id(s)            # exact in the float64 records
+    assert shard.pack_bus_id("") == 0 and shard.pack_bus_id("garbage") == 0 and shard.unpack_bus_id(0) == ""
+    eight = [(r, "0000:%02x:00.0" % (0x05 + 16 * r)) for r in range(8)]
+    ok = shard.check_placement(eight, 8)
+    assert ok["ok"] and ok["one_rank_per_device"] and ok["ranks_seen"] == 8
+    twice = list(eight)
+    twice[5] = (3, eight[3][1])
+    bad = shard.check_placement(twice, 8)
+    assert not bad["ok"] and "same device or PCI address" in bad["why"]
+    same_bus = list(eight)
+    same_bus[7] = (7, eight[0][1])                                           # distinct indices, one address
+    assert not shard.check_placement(same_bus, 8)["ok"]
+    sharing = shard.check_placement([(0, "0000:05:00.0")] * 8, 1)             # the 1-GPU dry runs
+    assert sharing["ok"] and not sharing["one_rank_per_device"]

@@ -173,3 +173,57 @@ def test_pop_timeout_and_flush(svhip, crops):
     t, st = s.pop()
     assert (t, st) == (1, 0) and np.array_equal(E2, crops[3][3])
     s.close()
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_host_frame_ring_through_push_n_equals_the_device_path(svhip, crops, pinned):
+    """The reference's ownership contract as a stream (elas.cpp:40-56: host images in, host maps out;
+    readfromfilesthread.cpp:25-112: a producer with decoded frames): a 100-frame sequence from ONE host array
+    (consecutive frames: the groups' copies are strided, one per camera and group), handed over in rings of 25 through
+    svh_elas_stream_push_n while a consumer pops in order.  Pinned (hipHostMalloc) and pageable frames; every map
+    equals the reference's golden map of its crop, and the maps of the device-resident entry for the same frames."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    h, w = crops[0][0].shape
+    n, ring = 100, 25
+
+    def host_array(shape, dtype):
+        if not pinned:
+            return np.zeros(shape, dtype), None
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        assert hip.hipHostMalloc(C.byref(p), C.c_size_t(nbytes), 0) == 0
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape), p
+    I1, p1 = host_array((n, h, w), np.uint8)
+    I2, p2 = host_array((n, h, w), np.uint8)
+    D1, p3 = host_array((n, h, w), np.float32)
+    D2, p4 = host_array((n, h, w), np.float32)
+    try:
+        for i in range(n):
+            I1[i], I2[i] = crops[(i * 7) % 4][:2]
+        D1[:] = -3.0
+        D2[:] = -3.0
+        e = svhip.Elas(H.robotics())
+        s = e.stream(w, h)
+        st = []
+        t = threading.Thread(target=lambda: st.extend(s.pop_n(n)))
+        t.start()
+        for r0 in range(0, n, ring):
+            first = s.push_n(I1[r0:r0 + ring], I2[r0:r0 + ring], D1[r0:r0 + ring], D2[r0:r0 + ring])
+            assert first == r0
+        s.flush()
+        t.join(120)
+        assert not t.is_alive() and st == [0] * n
+        s.close()
+        for i in range(n):
+            c = crops[(i * 7) % 4]
+            assert np.array_equal(D1[i], c[2]) and np.array_equal(D2[i], c[3]), i
+        # the device-resident batch entry on the same frames
+        stb, B1, B2 = e.process_batch(I1[:12].copy(), I2[:12].copy())
+        assert stb == [0] * 12 and np.array_equal(B1, D1[:12]) and np.array_equal(B2, D2[:12])
+    finally:
+        del I1, I2, D1, D2
+        for p in (p1, p2, p3, p4):
+            if p is not None:
+                hip.hipHostFree(p)

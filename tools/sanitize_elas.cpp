@@ -38,6 +38,7 @@ hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "stub"; }
 hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)8 << 30; *t = (size_t)16 << 30; return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned int) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
@@ -119,10 +120,13 @@ void launch_segments_label(const LaunchCtx&, const svh_elas_params&, const Dims&
                            const DevMaps&, const PostScratch&) {}
 }  // namespace svh
 
+extern "C" int32_t svh_test_fail_at(const char* spec);   // test hook of the engines (csrc/svh_internal.h)
 // ---------------------------------------------------------------- driver
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 12;
+    // (the library no longer reads a fault specification from the environment: the driver passes its own on)
     const char* inject = getenv("SVH_TEST_FAIL_AT");
+    if (inject && svh_test_fail_at(inject) != SVH_OK) { fprintf(stderr, "bad SVH_TEST_FAIL_AT\n"); return 2; }
     const int W = 320, H = 120;
     const int32_t dims[3] = {W, H, W};
     svh_elas_params prm;
