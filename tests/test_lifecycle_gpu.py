@@ -82,6 +82,7 @@ def test_trim_releases_the_idle_lanes():
         S.trim()
 
 
+@pytest.mark.gpu
 def test_a_plain_process_gets_the_engines_settings_without_any_environment_variable():
     """svh_init by first use (include/svh.h): a fresh process that loads only libsvhip -- no torch, no environment
     variable -- runs a batch; the library asked the HIP runtime for 20 hardware queues before the runtime started
