@@ -1559,8 +1559,8 @@ struct FastK {
 //  * min3 on (best, key, key): two operations per four candidates.
 template <int kSide>
 __device__ __forceinline__ int ml_fast(const uint4& own, uint32_t rowaddr, uint32_t lrec, uint32_t tail, int t1, int u,
-                                       bool valid, bool excl, bool band_ok, const FastK& K, const int* s_band,
-                                       const MatchParams& P) {
+                                       bool valid, bool excl, bool band_ok, bool edge, uint32_t rowlo, const FastK& K,
+                                       const int* s_band, const MatchParams& P) {
     const int rad = P.plane_radius;
     int best = 0x7FFFFFFF;
     const uint32_t n = tail >> 16;
@@ -1588,10 +1588,33 @@ __device__ __forceinline__ int ml_fast(const uint4& own, uint32_t rowaddr, uint3
         best = min3_op(best, k0, k1);                                                                         \
         best = min3_op(best, k2, k3);                                                                         \
     }
+    // (edge: a wave beside the image border, where some lane's largest candidate warps out of the row -- round 5 sent
+    // such waves to the checked form, 684 operations per pixel, 2.9 % of the kernel for 1.2 % of its pixels: the
+    // exclusion trip with a second range test, the slot's address against the row's columns 2 .. W-3)
+#define ML_TRIP4E(cc, i)                                                                                      \
+    {                                                                                                         \
+        const uint32_t c0 = (cc).x & 0xFFFFu, c1 = (cc).x >> 16, c2 = (cc).y & 0xFFFFu, c3 = (cc).y >> 16;    \
+        const uint32_t a0 = ML_ADDR(c0), a1 = ML_ADDR(c1), a2 = ML_ADDR(c2), a3 = ML_ADDR(c3);                \
+        const uint4 o0 = lds_read16(a0), o1 = lds_read16(a1), o2 = lds_read16(a2), o3 = lds_read16(a3);       \
+        const int k0 = a0 - bandlo <= blen || a0 - rowlo > rowspan ? 0x7FFFFFFF : sad_hi16(own, o0, (i));     \
+        const int k1 = a1 - bandlo <= blen || a1 - rowlo > rowspan ? 0x7FFFFFFF : sad_hi16(own, o1, (i) + 1u); \
+        const int k2 = a2 - bandlo <= blen || a2 - rowlo > rowspan ? 0x7FFFFFFF : sad_hi16(own, o2, (i) + 2u); \
+        const int k3 = a3 - bandlo <= blen || a3 - rowlo > rowspan ? 0x7FFFFFFF : sad_hi16(own, o3, (i) + 3u); \
+        best = min3_op(best, k0, k1);                                                                         \
+        best = min3_op(best, k2, k3);                                                                         \
+    }
 #if SVH_ML_PROBE != 5
     if (n != 0) {
         uint2 ca = lds_read8(lrec), cb;
-        if (!excl) {
+        if (edge) {
+            const uint32_t blen = 32u * (uint32_t)rad, rowspan = 16u * (uint32_t)(P.W - 5);
+#pragma unroll 1
+            for (uint32_t i = 0; __builtin_amdgcn_ballot_w64(i < n) != 0; i += 4) {
+                ML_CNT(12, 1);
+                ML_TRIP4E(ca, i)
+                ca = lds_read8(lrec + 2 * i + 8);
+            }
+        } else if (!excl) {
             for (uint32_t i = 0;; i += 8) {
                 cb = lds_read8(lrec + 2 * i + 8);
                 ML_CNT(7, 1);
@@ -1623,6 +1646,7 @@ __device__ __forceinline__ int ml_fast(const uint4& own, uint32_t rowaddr, uint3
 #endif
 #undef ML_TRIP4
 #undef ML_TRIP4X
+#undef ML_TRIP4E
 #undef ML_ADDR
 #if SVH_ML_PROBE == 4
     if (best == 0x7FFFFFFF) return -1;
@@ -1706,25 +1730,28 @@ __device__ __forceinline__ int ml_pixel(const uint4& own, const float4& pl, int 
     const int d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pl.x, (float)u), __fmul_rn(pl.y, vf)), pl.z);
     const int t1 = d_plane - rad;
     const uint32_t lim = kSide ? (uint32_t)K.cell_c - u16 : u16 - (uint32_t)K.cell_c;
-    const uint64_t m_cell = __builtin_amdgcn_ballot_w64((tail & 0xFFFFu) > lim) |
-                            __builtin_amdgcn_ballot_w64(tail >= ((uint32_t)(ML_FAST + 1) << 16));
+    const uint64_t m_warp = __builtin_amdgcn_ballot_w64((tail & 0xFFFFu) > lim);          // a candidate leaves the row
+    const uint64_t m_many = __builtin_amdgcn_ballot_w64(tail >= ((uint32_t)(ML_FAST + 1) << 16));
     int bl = kSide ? K.band_c - u : u - K.band_c;
     bl = bl < K.band_m ? bl : K.band_m;
     bl = bl > 0 ? bl : 0;
     const bool band_ok = (m_live & __builtin_amdgcn_ballot_w64((uint32_t)t1 >= (uint32_t)bl)) == 0;
-    *is_cold = !((m_live & m_cell) == 0 && (band_ok || rad == 2));
+    const bool edge = (m_live & m_warp) != 0;
+    *is_cold = (m_live & m_many) != 0 || (rad != 2 && (!band_ok || edge));
     if (*is_cold) {
         ML_CNT(6, 1);
         return -10;
     }
-    const bool excl = !neg_prior || (m_live & __builtin_amdgcn_ballot_w64(__float_as_int(pl.w) == 0)) != 0;
-    ML_CNT(3, 1); ML_CNT(4, excl ? 1 : 0); ML_CNT(5, band_ok ? 0 : 1);
+    // (an edge wave takes the exclusion forms throughout: its band keys are masked one by one)
+    const bool excl = edge || !neg_prior || (m_live & __builtin_amdgcn_ballot_w64(__float_as_int(pl.w) == 0)) != 0;
+    ML_CNT(3, 1); ML_CNT(4, excl ? 1 : 0); ML_CNT(5, band_ok ? 0 : 1); ML_CNT(13, edge ? 1 : 0);
     ML_CNT(11, __builtin_popcountll(m_live));
     int res = -10;
 #if SVH_ML_PROBE == 3
     if (live) res = (d_plane ^ (int)tail) + (excl ? 1 : 0) + (band_ok ? 2 : 0) + (int)(rowaddr & 1u);
 #else
-    if (live) res = ml_fast<kSide>(own, rowaddr, lrec, tail, t1, u, __float_as_int(pl.w) != 0, excl, band_ok, K, s_band, P);
+    if (live) res = ml_fast<kSide>(own, rowaddr, lrec, tail, t1, u, __float_as_int(pl.w) != 0, excl, band_ok && !edge, edge,
+                                   oth_base + 32u, K, s_band, P);
 #endif
     return res;
 }

@@ -11,9 +11,9 @@ OUT=$O/match_split.txt
 python -c "import sys; sys.path.insert(0,'$R/stereo-vision_amd'); import svhip; print('#', svhip.lib().svh_version().decode())" > $OUT
 for n in $VARS; do
   lib=$R/stereo-vision_amd/libsvhip.so; [ $n != 0 ] && lib=$R/tools/bin/libsvhip_probe$n.so
-  for try in 1 2 3; do
+  for try in 1 2; do
     rm -rf /tmp/ms_$n
-    if SVH_LIB=$lib timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES -d /tmp/ms_$n -o p -- $ISO > /tmp/ms_$n.log 2>&1; then break; fi
+    if SVH_LIB=$lib timeout 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES -d /tmp/ms_$n -o p -- $ISO > /tmp/ms_$n.log 2>&1; then break; fi
   done
   db=$(find /tmp/ms_$n -name "*.db" | head -1)
   echo "== probe $n" >> $OUT
@@ -33,7 +33,7 @@ L.svh_probe_ml_counters(cnt, 1)
 st, D1, D2 = e.process_batch(np.stack(ls), np.stack(rs))
 L.svh_probe_ml_counters(cnt, 1)
 names = ["wave_pixels", "wp_any_live", "live_lanes", "fast_wp", "fast_excl_wp", "fast_band_clipped_wp", "cold_wp",
-         "trips_plain", "lane_trips_plain", "trips_excl", "lane_trips_excl", "live_lanes_fast"]
+         "trips_plain", "lane_trips_plain", "trips_excl", "lane_trips_excl", "live_lanes_fast", "trips_edge", "edge_wp"]
 print("== event counters, 4 urban pairs (status %s)" % st)
 for n, v in zip(names, cnt): print("   %-24s %12d" % (n, v))
 PY
