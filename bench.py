@@ -201,6 +201,44 @@ def matcher_bench(iters=40):
     out = {"workload": "quad match on libviso2/img I1p/I2p/I1c/I2c 1344x391, default parameters",
            "pushBack_ms": push, "matchFeatures_ms": match, "frame_ms": push + match,
            "frames_per_s": 1e3 / (push + match), "matches": nm}
+    # round 6: the call's timeline from the library's own clocks (svh_matcher_get_timing: host wall-clock steps, and
+    # the device time of the three device phases from HIP events on the object's streams), a second pass with the
+    # collection on; and the leg's roofline: SURVEY 8(d)'s 17 N bytes per stereo frame over the device time
+    try:
+        dev.lib.svh_matcher_set_timing(1)
+        dev.lib.svh_matcher_get_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        names, ms = (C.c_char_p * 10)(), (C.c_double * 10)()
+        dev.lib.svh_matcher_get_timing(C.c_void_p(dev.h), names, ms, 10, 1)
+        tpush, tmatch, _ = run(dev, iters)
+        k = dev.lib.svh_matcher_get_timing(C.c_void_p(dev.h), names, ms, 10, 1)
+        dev.lib.svh_matcher_set_timing(0)
+        tl = {names[i].decode(): round(ms[i], 4) for i in range(k)}
+        host = [ms[i] for i in range(7)]
+        dev_ms = ms[7] + ms[8] + ms[9]
+        frame = tpush + tmatch
+        n_px = im[0].shape[0] * im[0].shape[1]
+        out["timeline"] = {
+            "frame_ms_with_the_clocks_on": round(frame, 4), "steps_ms": tl,
+            "device_ms": round(dev_ms, 4), "device_busy_fraction_of_the_call": round(dev_ms / frame, 3),
+            "host_only_ms": round(host[0] + host[3] + host[4] + host[6], 4),
+            "host_waiting_for_the_device_ms": round(host[1] + host[2] + host[5], 4),
+            "outside_the_library_ms": round(frame - sum(host), 4),
+            "note": "one object, one frame after the other (Matcher::pushBack then matchFeatures(2), as viso_stereo.cpp:41-68 "
+                    "calls them): the dense outlier vote (a Delaunay triangulation of ~2.9 k matches, matcher.cpp:1383-1570) "
+                    "and the prior statistics are host steps of the reference that SURVEY 8(a) leaves on the host; nothing "
+                    "of the NEXT frame exists while they run (the caller hands it over afterwards), so for one object they "
+                    "are idle time of the device.  K objects in lockstep fill it: visual_odometry.lockstep"}
+        out["roofline"] = {
+            "bound": "latency", "unit": "GB/s", "algorithmic_bytes_per_frame": 17 * n_px,
+            "achieved": round(17 * n_px / (dev_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+            "frac": round(17 * n_px / (dev_ms * 1e-3) / 1e9 / 8000.0, 4),
+            "device_ms_per_frame": round(dev_ms, 4),
+            "note": "SURVEY 8(d): 17 N bytes per stereo frame (2 images x (4 N full-resolution Sobel + half image + 18 N/4)) "
+                    "over the summed device time of the call's three device phases (HIP events); a frame is ~25 short "
+                    "launches on one stream -- 8.9 MB cannot fill the machine, the phases are launch- and "
+                    "latency-bound, and the call as a whole is bound by its host steps (timeline)"}
+    except Exception as ex:      # (an older library under SVH_LIB)
+        out["timeline"] = {"error": str(ex)}
     if Hh.have_ref_viso():
         ref = Hh.RefMatcher(prm)
         ref.lib.ref_init(0)

@@ -384,6 +384,14 @@ typedef struct svh_matcher svh_matcher;
 /* Matcher::Matcher(parameters) / ~Matcher() -- matcher.cpp:33-98 */
 svh_matcher* svh_matcher_create(const svh_matcher_params* p);
 void         svh_matcher_destroy(svh_matcher* m);
+/* Per-call timeline of a Matcher (round 6): svh_matcher_set_timing(1) switches the collection on for the process (the
+ * same clocks SVH_MATCHER_TIMING=1 prints at destroy); svh_matcher_get_timing returns averages per call, in ms: seven
+ * host wall-clock steps (pushBack: pack + enqueue, wait; matchFeatures: sparse matching, sparse vote, prior statistics,
+ * dense matching + refinement, dense vote -- the matching steps include their wait for the device) and the device time of
+ * the three device phases from HIP events on the object's streams (first launch to last copy).  Returns the number of
+ * entries written (<= cap); reset != 0 clears the sums. */
+void    svh_matcher_set_timing(int32_t on);
+int32_t svh_matcher_get_timing(svh_matcher* m, const char** names, double* ms, int32_t cap, int32_t reset);
 /* Matcher::setIntrinsics -- matcher.h:78-84 */
 void svh_matcher_set_intrinsics(svh_matcher* m, double f, double cu, double cv, double base);
 /* Matcher::pushBack(I1,I2,dims,replace) -- matcher.cpp:102-205.  I2 may be NULL

@@ -452,15 +452,31 @@ struct svh_matcher {
     double tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double tfine[6] = {0, 0, 0, 0, 0, 0};
     int64_t tcalls[2] = {0, 0};
+    // svh_matcher_set_timing (round 6): device time of the three device phases (pushBack's feature kernels, sparse
+    // matching, dense matching + refinement) from HIP events on the object's streams: first launch -> last copy
+    hipEvent_t tev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double tdev[3] = {0, 0, 0};
 };
 
 static double mnow_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 // SVH_MATCHER_TIMING, evaluated at the first use (never while the library is loaded)
+static std::atomic<int> g_mtiming_api{0};   // svh_matcher_set_timing
 static bool mtiming_on() {
     static const bool on = svh::env("SVH_MATCHER_TIMING") != nullptr;
-    return on;
+    return on || g_mtiming_api.load(std::memory_order_relaxed) != 0;
+}
+// event pair k of an object's device phase (0 pushBack stream 1, 1 pushBack stream 2, 2 sparse, 3 dense): created on
+// first use while timing is on; failures only lose the measurement
+static void tev_record(svh_matcher* m, int idx, hipStream_t s) {
+    if (!m->tev[idx] && hipEventCreate(&m->tev[idx]) != hipSuccess) { m->tev[idx] = nullptr; (void)hipGetLastError(); return; }
+    (void)hipEventRecord(m->tev[idx], s);
+}
+static double tev_ms(svh_matcher* m, int a, int b) {
+    float ms = 0;
+    if (!m->tev[a] || !m->tev[b] || hipEventElapsedTime(&ms, m->tev[a], m->tev[b]) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return ms;
 }
 #define g_mtiming mtiming_on()
 enum { T_PACK = 0, T_PUSH_GPU, T_SPARSE, T_OUT1, T_PRIOR, T_DENSE, T_OUT2 };
@@ -848,10 +864,13 @@ static void match_collect(svh_matcher* m, const MatchPass& mp, std::vector<svh_p
 static int run_matching(svh_matcher* m, int dense, int32_t method, bool use_prior, const double* Tr,
                         std::vector<svh_p_match>& out, bool refine, std::vector<svh_p_match>* raw_tap) {
     MatchPass mp;
+    const bool timed = g_mtiming;
+    if (timed) tev_record(m, dense ? 6 : 4, m->stream);
     int rc = match_enqueue(m, dense, method, use_prior, Tr, mp);
     if (rc) return rc;
     auto download = [&](std::vector<svh_p_match>& dst) -> int {
         download_enqueue(m, mp);
+        if (timed) tev_record(m, dense ? 7 : 5, m->stream);
         HIP_TRY((hipError_t)wait_stream(m->stream));
         HIP_TRY(hipGetLastError());
         match_collect(m, mp, dst);
@@ -864,6 +883,7 @@ static int run_matching(svh_matcher* m, int dense, int32_t method, bool use_prio
     if (refine) refine_enqueue(m, method, mp);
     rc = download(out);
     if (rc) return rc;
+    if (timed) m->tdev[dense ? 2 : 1] += tev_ms(m, dense ? 6 : 4, dense ? 7 : 5);
     if (!refine && raw_tap && m->taps) *raw_tap = out;
     return SVH_OK;
 }
@@ -946,6 +966,32 @@ svh_matcher* svh_matcher_create(const svh_matcher_params* p) {
     return m;
 }
 
+void svh_matcher_set_timing(int32_t on) { g_mtiming_api.store(on ? 1 : 0); }
+
+int32_t svh_matcher_get_timing(svh_matcher* m, const char** names, double* ms, int32_t cap, int32_t reset) {
+    static const char* kNames[10] = {
+        "pushBack: pack + enqueue (host)", "pushBack: wait for the device (host)", "matchFeatures: sparse matching (host wall, waits for the device)",
+        "matchFeatures: sparse outlier vote (host)", "matchFeatures: prior statistics (host)",
+        "matchFeatures: dense matching + refinement (host wall, waits for the device)", "matchFeatures: dense outlier vote (host)",
+        "device: pushBack kernels", "device: sparse matching", "device: dense matching + refinement"};
+    if (!m) return 0;
+    const double a = m->tcalls[0] ? 1.0 / (double)m->tcalls[0] : 0, b = m->tcalls[1] ? 1.0 / (double)m->tcalls[1] : 0;
+    const double v[10] = {m->tacc[T_PACK] * a, m->tacc[T_PUSH_GPU] * a, m->tacc[T_SPARSE] * b, m->tacc[T_OUT1] * b,
+                          m->tacc[T_PRIOR] * b, m->tacc[T_DENSE] * b, m->tacc[T_OUT2] * b,
+                          m->tdev[0] * a, m->tdev[1] * b, m->tdev[2] * b};
+    int32_t n = 0;
+    for (; n < 10 && n < cap; n++) {
+        if (names) names[n] = kNames[n];
+        if (ms) ms[n] = v[n];
+    }
+    if (reset) {
+        for (double& x : m->tacc) x = 0;
+        for (double& x : m->tdev) x = 0;
+        m->tcalls[0] = m->tcalls[1] = 0;
+    }
+    return n;
+}
+
 void svh_matcher_destroy(svh_matcher* m) {
     if (!m) return;
     if (g_mtiming && m->tcalls[0] && m->tcalls[1]) {
@@ -958,6 +1004,8 @@ void svh_matcher_destroy(svh_matcher* m) {
                         "features enqueue %.3f, d2h enqueue %.3f ms\n",
                 m->tfine[0] * a, m->tfine[1] * a, m->tfine[2] * a, m->tfine[3] * a, m->tfine[4] * a);
     }
+    for (auto& e : m->tev)
+        if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (m->next_job.valid()) (void)m->next_job.get();   // a hand-over still running on the prefetch thread
     if (m->stream) {
         (void)hipSetDevice(m->device);
@@ -1080,21 +1128,27 @@ int32_t svh_matcher_push_back(svh_matcher* m, const uint8_t* I1, const uint8_t* 
     int32_t rc = push_prepare(m, I1, I2, dims, replace);
     if (rc) return rc;
     const uint8_t* src[2] = {I1, I2};
-    const double t0 = g_mtiming ? mnow_ms() : 0;
+    const bool timed = g_mtiming;
+    const double t0 = timed ? mnow_ms() : 0;
     for (int k = 0; k < 2; k++) {
         if (!src[k]) continue;
+        if (timed) tev_record(m, 2 * k, k == 1 ? m->stream2 : m->stream);
         rc = compute_features(m, m->cur[k], k, src[k], dims[2]);
         if (rc) return rc;
+        if (timed) tev_record(m, 2 * k + 1, k == 1 ? m->stream2 : m->stream);
     }
-    const double t1 = g_mtiming ? mnow_ms() : 0;
+    const double t1 = timed ? mnow_ms() : 0;
     HIP_TRY((hipError_t)wait_stream(m->stream));
     HIP_TRY((hipError_t)wait_stream(m->stream2));
     HIP_TRY(hipGetLastError());
     push_finish(m, I1, I2);
-    if (g_mtiming) {
+    if (timed) {
         m->tacc[T_PACK] += t1 - t0;
         m->tacc[T_PUSH_GPU] += mnow_ms() - t1;
         m->tcalls[0]++;
+        // (the two cameras run on two streams side by side: the longer one is the phase's device time)
+        const double a = src[0] ? tev_ms(m, 0, 1) : 0, b = src[1] ? tev_ms(m, 2, 3) : 0;
+        m->tdev[0] += a > b ? a : b;
     }
     return SVH_OK;
 }
