@@ -10,7 +10,7 @@ ulimit -c 0
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/evidence
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 mkdir -p $O
 GRAFT_REPO_ROOT=$R timeout 600 bash $R/tools/gpu_pmc_all.sh > $O/pmc_summary.txt 2>&1
 cp $R/gpurun_out/pmc_issue.json $R/gpurun_out/pmc_traffic.json $O/
@@ -21,11 +21,16 @@ GRAFT_REPO_ROOT=$R timeout 600 bash $R/tools/gpu_pmc_all.sh _hd1080 --workload h
 cp $R/gpurun_out/pmc_issue_hd1080.json $R/gpurun_out/pmc_traffic_hd1080.json $O/
 cp $R/gpurun_out/pmc_issue_hd1080.json $R/profiles/${ROUND}_pmc_issue_hd1080.json
 cp $R/gpurun_out/pmc_traffic_hd1080.json $R/profiles/${ROUND}_pmc_traffic_hd1080.json
+# k_match_list's instruction split: the product and the eight probe builds (tools/Makefile `probe`), event counters
+GRAFT_REPO_ROOT=$R timeout 1500 bash $R/tools/gpu_match_split.sh > /dev/null 2>&1
+cp $R/gpurun_out/match_split.txt $O/match_split_raw.txt
 # counters of the overlapped run (device-wide, nothing serialised): tools/devcount.cpp
 make -C $R/tools libdevcount.so > /dev/null 2>&1
 GRAFT_REPO_ROOT=$R timeout 900 bash $R/tools/gpu_devcount.sh > $O/devcount_summary.txt 2>&1
 cp $R/gpurun_out/devcount.json $O/devcount.json
 cp $R/gpurun_out/devcount.json $R/profiles/${ROUND}_devcount.json
+GRAFT_REPO_ROOT=$R timeout 900 bash $R/tools/gpu_devcount.sh _hd1080 --workload hd1080 > $O/devcount_summary_hd1080.txt 2>&1
+cp $R/gpurun_out/devcount_hd1080.json $O/devcount_hd1080.json
 cd $R
 b() { name=$1; shift; timeout 600 python bench.py "$@" > $O/bench_line$name.json 2> $O/bench_line$name.err; }
 b "" --gpus 1 --steps 20 --warmup 5
@@ -46,9 +51,12 @@ b _8ranks_gloo_1gpu_kitti $Q --gpus 8 --dist-backend gloo --steps 4 --warmup 1 -
 b _8ranks_gloo_1gpu_sequence $Q --gpus 8 --dist-backend gloo --steps 4 --warmup 1 --workload sequence --lanes 2
 b _8ranks_gloo_1gpu_hd1080 $Q --gpus 8 --dist-backend gloo --steps 8 --warmup 2 --workload hd1080 --lanes 2 --group 8   # (16 pairs per launch: the 32 lanes of eight ranks spend these few steps allocating)
 # the C++ driver above the C-ABI (apps/svh_shard.cpp): one rank with its RCCL communicator, four ranks sharing the GPU
-timeout 300 stereo-vision_amd/bin/svh_shard --ranks 1 --gather rccl --pairs-per-rank 6144 --steps 20 --warmup 5 2> /dev/null | grep '^{' > $O/shard_driver_1rank_rccl.json
-timeout 300 stereo-vision_amd/bin/svh_shard --ranks 4 --pairs-per-rank 1536 --steps 20 --warmup 5 2> /dev/null | grep '^{' > $O/shard_driver_4ranks_pipes_1gpu.json
-timeout 300 stereo-vision_amd/bin/svh_shard --ranks 8 --total 430 --steps 20 --warmup 5 --lanes 2 2> /dev/null | grep '^{' > $O/shard_driver_8ranks_sequence_strong.json
+env -u GPU_MAX_HW_QUEUES timeout 300 stereo-vision_amd/bin/svh_shard --ranks 1 --gather rccl --pairs-per-rank 6144 --steps 20 --warmup 5 2> /dev/null | grep '^{' > $O/shard_driver_1rank_rccl.json
+env -u GPU_MAX_HW_QUEUES timeout 300 stereo-vision_amd/bin/svh_shard --ranks 4 --pairs-per-rank 1536 --steps 20 --warmup 5 2> /dev/null | grep '^{' > $O/shard_driver_4ranks_pipes_1gpu.json
+env -u GPU_MAX_HW_QUEUES timeout 300 stereo-vision_amd/bin/svh_shard --ranks 8 --total 430 --steps 20 --warmup 5 --lanes 2 2> /dev/null | grep '^{' > $O/shard_driver_8ranks_sequence_strong.json
+# the Matcher's timeline / roofline on its own, and the single Elas::process call (no environment variable anywhere)
+timeout 200 python tools/matcher_probe.py 200 2> /dev/null | tail -1 > $O/matcher_probe.json
+env -u GPU_MAX_HW_QUEUES timeout 200 python tools/gpu_single_latency.py 400 > $O/single_call_latency.txt 2>&1
 SVH_MATCH_LIST=0 timeout 300 python bench.py $Q --steps 10 --warmup 3 > $O/bench_line_keyed_matcher.json 2> /dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 cd /tmp

@@ -74,9 +74,12 @@ def main(before, after):
     for k in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAVE_CYCLES"):
         print("   %-28s %12d %12d" % (k, p0[0].get(k, 0), p1[0].get(k, 0)))
     print()
-    print("events of the launch (probe 7: counters in the kernel), before -> after")
-    for k in sorted(set(e0) | set(e1), key=lambda k: list(e1).index(k) if k in e1 else 99):
-        print("   %-24s %10s -> %10s" % (k, e0.get(k, "-"), e1.get(k, "-")))
+    print("events of the launch (probe 7: counters in the kernel; the same four pairs before and after -- the kernel's control flow")
+    print("is data, not code: wave-pixels, live ones, hot / cold split and trips did not move, except for the edge form)")
+    for k in e1:
+        if k.startswith("lane_trips"):
+            continue
+        print("   %-24s %10s" % (k, e1[k]) + ("   (before: %s)" % e0[k] if k in e0 and e0[k] != e1[k] and not k.startswith("live_lanes") else ""))
     print()
     print("SAD instructions the launch needs: %d (16 per trip of four candidates, 20 per band, 4 per texture test) = %.1f %% of "
           "the kernel after, %.1f %% before" % (sad, 100.0 * sad / f1, 100.0 * sad / f0))
