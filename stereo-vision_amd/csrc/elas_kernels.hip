@@ -584,12 +584,27 @@ __device__ __forceinline__ int support_match_rows(const StripView& own, const St
     uint32_t a0 = oth_addr + (uint32_t)(uw_first - 2 - oth.x0) * 16u;      // (row 0, uw - 2) of j = 0; + 256 per trip
     const uint32_t row1 = (uint32_t)oth.w * 16u;
     int d = d_first;
-    auto trip = [&](uint32_t addr0, uint32_t addr1, int dd) {
-        uint32_t key = (uint32_t)sad_hi16(r0, lds_read16(addr0), (uint32_t)dd);
-        key = (uint32_t)sad_hi16(r1, lds_read16(addr0 + 64u), key);
-        key = (uint32_t)sad_hi16(r2, lds_read16(addr1), key);
-        key = (uint32_t)sad_hi16(r3, lds_read16(addr1 + 64u), key);
+    // Round 6: the four slot reads of a trip are REQUESTED together (hipcc's scheduler, left alone, keeps one
+    // four-register buffer and waits for every read before its four SADs -- four exposed LDS round trips per trip), and in
+    // the unrolled loop the next trip's four are requested before the current trip's SADs start (two register sets,
+    // alternating by name: no copies).  The compiler barrier pins the requests where they are written.
+    struct Slots { uint4 a, b, c, e; };
+    auto fetch = [&](uint32_t addr0, uint32_t addr1) {
+        Slots q;
+        q.a = lds_read16(addr0); q.b = lds_read16(addr0 + 64u); q.c = lds_read16(addr1); q.e = lds_read16(addr1 + 64u);
+        return q;
+    };
+    auto eval = [&](const Slots& q, int dd) {
+        uint32_t key = (uint32_t)sad_hi16(r0, q.a, (uint32_t)dd);
+        key = (uint32_t)sad_hi16(r1, q.b, key);
+        key = (uint32_t)sad_hi16(r2, q.c, key);
+        key = (uint32_t)sad_hi16(r3, q.e, key);
         keep_two(key, best1, best2);
+    };
+    auto trip = [&](uint32_t addr0, uint32_t addr1, int dd) {
+        const Slots q = fetch(addr0, addr1);
+        asm volatile("" ::: "memory");
+        eval(q, dd);
     };
     const int dstep = right ? 16 : -16;
     int j = 0;
@@ -598,12 +613,25 @@ __device__ __forceinline__ int support_match_rows(const StripView& own, const St
             if (j >= jl) trip(a0, a0 + row1, d);
     }
     const int jend = right ? jsplit + 1 : T;
-    for (; j + 4 <= jend; j += 4, a0 += 1024u, d += 4 * dstep) {
-        const uint32_t a1 = a0 + row1;
-        trip(a0, a1, d);
-        trip(a0 + 256u, a1 + 256u, d + dstep);
-        trip(a0 + 512u, a1 + 512u, d + 2 * dstep);
-        trip(a0 + 768u, a1 + 768u, d + 3 * dstep);
+    if (j + 4 <= jend) {
+        Slots qa = fetch(a0, a0 + row1), qb;
+        for (; j + 4 <= jend; j += 4, a0 += 1024u, d += 4 * dstep) {
+            const uint32_t a1 = a0 + row1;
+            qb = fetch(a0 + 256u, a1 + 256u);
+            asm volatile("" ::: "memory");
+            eval(qa, d);
+            qa = fetch(a0 + 512u, a1 + 512u);
+            asm volatile("" ::: "memory");
+            eval(qb, d + dstep);
+            qb = fetch(a0 + 768u, a1 + 768u);
+            asm volatile("" ::: "memory");
+            eval(qa, d + 2 * dstep);
+            // (the next turn's first trip; past the last turn it reads slots of this block's strips or the padding
+            // behind them and is dropped)
+            qa = fetch(a0 + 1024u, a1 + 1024u);
+            asm volatile("" ::: "memory");
+            eval(qb, d + 3 * dstep);
+        }
     }
     for (; j < jend; j++, a0 += 256u, d += dstep) trip(a0, a0 + row1, d);
     if (right) {    // masked tail
