@@ -1587,8 +1587,8 @@ struct FastK {
 //  * min3 on (best, key, key): two operations per four candidates.
 template <int kSide>
 __device__ __forceinline__ int ml_fast(const uint4& own, uint32_t rowaddr, uint32_t lrec, uint32_t tail, int t1, int u,
-                                       bool valid, bool excl, bool band_ok, bool edge, uint32_t rowlo, const FastK& K,
-                                       const int* s_band, const MatchParams& P) {
+                                       bool valid, bool excl, bool band_ok, bool edge, uint32_t rowlo, uint2 ca,
+                                       const FastK& K, const int* s_band, const MatchParams& P) {
     const int rad = P.plane_radius;
     int best = 0x7FFFFFFF;
     const uint32_t n = tail >> 16;
@@ -1633,7 +1633,7 @@ __device__ __forceinline__ int ml_fast(const uint4& own, uint32_t rowaddr, uint3
     }
 #if SVH_ML_PROBE != 5
     if (n != 0) {
-        uint2 ca = lds_read8(lrec), cb;
+        uint2 cb;      // (ca: the record's first four candidates, requested a pixel ahead by the kernel)
         if (edge) {
             const uint32_t blen = 32u * (uint32_t)rad, rowspan = 16u * (uint32_t)(P.W - 5);
 #pragma unroll 1
@@ -1743,17 +1743,10 @@ __device__ __forceinline__ int ml_fast(const uint4& own, uint32_t rowaddr, uint3
 //  * band test: (unsigned)(d_plane - rad) < clamp(u - 2 rad - 1 | W - 2 - 2 rad - u, 0, disp_max - 2 rad + 1).
 template <int kSide>
 __device__ __forceinline__ int ml_pixel(const uint4& own, const float4& pl, int u, float vf, bool live, uint64_t m_live,
-                                        uint32_t rec_addr, uint32_t oth_base, int neg_prior, const FastK& K,
-                                        const int* s_band, const MatchParams& P, bool* is_cold) {
+                                        uint32_t lrec, uint32_t tail, uint2 ca, uint32_t oth_base, int neg_prior,
+                                        const FastK& K, const int* s_band, const MatchParams& P, bool* is_cold) {
     const int rad = P.plane_radius;
     const uint32_t u16 = (uint32_t)u * 16u;
-    uint32_t lrec;
-    {
-        const uint32_t cell = __umulhi((uint32_t)u, P.grid_magic);
-        asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(lrec) : "v"(cell), "s"(rec_addr));   // + cell * 2 ML_CAP
-    }
-    static_assert(ML_CAP * 2 == 64, "record size of the shift above");
-    const uint32_t tail = lds_read4(lrec + 2 * (ML_CAP - 2));   // [30] last candidate, [31] count
     const uint32_t rowaddr = oth_base + u16;
     const int d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pl.x, (float)u), __fmul_rn(pl.y, vf)), pl.z);
     const int t1 = d_plane - rad;
@@ -1779,7 +1772,7 @@ __device__ __forceinline__ int ml_pixel(const uint4& own, const float4& pl, int 
     if (live) res = (d_plane ^ (int)tail) + (excl ? 1 : 0) + (band_ok ? 2 : 0) + (int)(rowaddr & 1u);
 #else
     if (live) res = ml_fast<kSide>(own, rowaddr, lrec, tail, t1, u, __float_as_int(pl.w) != 0, excl, band_ok && !edge, edge,
-                                   oth_base + 32u, K, s_band, P);
+                                   oth_base + 32u, ca, K, s_band, P);
 #endif
     return res;
 }
@@ -1974,17 +1967,37 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
     float* out_row = G.Draw + (size_t)z * P.DW * P.DH + (size_t)y * P.DW;
     int16_t* raw_row = s_raw + side * Q.Wr;
     uint32_t cold = 0;     // pixels (bit k) of this wave that need the checked form
+    // Round 6: what a pixel's scan starts from -- its own descriptor, the address of its cell's record, the record's
+    // last word (count, largest candidate) and first four candidates -- is requested ONE PIXEL AHEAD, like the plane: these
+    // were three dependent LDS round trips at the head of every pixel (descriptor -> texture vote -> record word -> plan
+    // -> first candidates), with nothing of the wave's own to cover them.  (Columns beyond the row read LDS bytes that
+    // the x < DW test then never looks at.)
+    struct Head { uint4 own; uint32_t lrec, tail; uint2 ca; };
+    static_assert(ML_CAP * 2 == 64, "record size of the shift below");
+    auto head_of = [&](int k) {
+        Head h;
+        const uint32_t u = (uint32_t)((x0 + k * half) * mul);
+        h.own = lds_read16(own_base + u * 16u);
+        const uint32_t cell = __umulhi(u, P.grid_magic);
+        asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(h.lrec) : "v"(cell), "s"(rec_addr));   // + cell * 2 ML_CAP
+        h.tail = lds_read4(h.lrec + 2 * (ML_CAP - 2));   // [30] last candidate, [31] count
+        h.ca = lds_read8(h.lrec);
+        return h;
+    };
+    Head hd_next = head_of(0);
 #pragma unroll
     for (int k = 0; k < kIters; k++) {
         const int x = x0 + k * half, u = x * mul;
         const float4 pl = pl_next;
+        const Head hd = hd_next;
         if (k + 1 < kIters) {
             pl_next = plane_of(tk[k + 1] - own1);
-            asm volatile("" ::: "memory");   // the request goes out HERE (hipcc would sink it to its use, a pixel later)
+            hd_next = head_of(k + 1);
+            asm volatile("" ::: "memory");   // the requests go out HERE (hipcc would sink them to their uses, a pixel later)
         }
         if (x < P.DW) {
             int res = -10;
-            const uint4 own = lds_read16(own_base + (uint32_t)u * 16u);
+            const uint4 own = hd.own;
             // (votes: the ballot of ONE comparison is that comparison's mask -- see ml_pixel)
             const bool owned = tk[k] >= own1, textured = (int)texture16(own) >= P.match_texture;
             const bool live = owned && textured;
@@ -1998,8 +2011,8 @@ __global__ __launch_bounds__(kIters <= 5 ? 768 : 512) __attribute__((amdgpu_wave
 #endif
                 ML_CNT(1, 1); ML_CNT(2, __builtin_popcountll(m_live));
                 bool is_cold;
-                res = side ? ml_pixel<1>(own, pl, u, vf, live, m_live, rec_addr, oth_base, neg_prior, K, s_band, P, &is_cold)
-                           : ml_pixel<0>(own, pl, u, vf, live, m_live, rec_addr, oth_base, neg_prior, K, s_band, P, &is_cold);
+                res = side ? ml_pixel<1>(own, pl, u, vf, live, m_live, hd.lrec, hd.tail, hd.ca, oth_base, neg_prior, K, s_band, P, &is_cold)
+                           : ml_pixel<0>(own, pl, u, vf, live, m_live, hd.lrec, hd.tail, hd.ca, oth_base, neg_prior, K, s_band, P, &is_cold);
                 if (is_cold) cold |= 1u << k;
             }
             if (!kLr || write_raw) out_row[x] = (float)res;
