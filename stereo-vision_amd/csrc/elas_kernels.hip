@@ -3199,19 +3199,23 @@ constexpr int QX = 64, QY = 32;
 
 // nearest valid neighbour on each side (<= gap away, inside [0, len)) -> interpolated value
 __device__ __forceinline__ float gap_pick(float val, const float* line, int stride, int pos, int len, int gap) {
+    // Round 6: the eight neighbours are read up front, together (they lie inside the tile's halo whatever the pixel
+    // is); reading one only when the one before it was not decisive made eight dependent LDS round trips of a
+    // handful of comparisons.  The compiler barrier keeps hipcc from sinking the reads back under the conditions.
+    float a[4], b[4];
+#pragma unroll
+    for (int k = 1; k <= 4; k++) {
+        a[k - 1] = line[-k * stride];
+        b[k - 1] = line[k * stride];
+    }
+    asm volatile("" ::: "memory");
     if (val >= 0) return val;
     int l = 0, r = 0;
     float vl = 0.f, vr = 0.f;
 #pragma unroll
     for (int k = 4; k >= 1; k--) {
-        if (k <= gap && pos - k >= 0) {
-            const float a = line[-k * stride];
-            if (a >= 0) { l = k; vl = a; }
-        }
-        if (k <= gap && pos + k < len) {
-            const float b = line[k * stride];
-            if (b >= 0) { r = k; vr = b; }
-        }
+        if (k <= gap && pos - k >= 0 && a[k - 1] >= 0) { l = k; vl = a[k - 1]; }
+        if (k <= gap && pos + k < len && b[k - 1] >= 0) { r = k; vr = b[k - 1]; }
     }
     return (l && r && r <= gap - l + 1) ? gap_value(vl, vr) : val;
 }
@@ -3393,6 +3397,8 @@ __device__ __forceinline__ void mean_col_pass(const float* sB, float* D, const f
         if (gy >= DH) break;
         const float* col = sB + r * kMeanSB + lane;
         float res = orig[j];
+        // (round 6 measured: reading the window's taps together with the centre, before the centre is looked at, costs
+        // more than the saved round trip -- 61 -> 66 us per 32 pairs: invalid centres are many and skip their taps)
         const float centre = col[HL * kMeanSB];
         if (centre >= 0 && xin && gy >= lead - back && gy <= DH - 1 - back)
             am_eval_rot<kTaps, (kQ - HL) & 3>([&](int k) { return col[k * kMeanSB]; }, centre, &res);
