@@ -8,5 +8,5 @@ cp $E/match_split_raw.txt profiles/${R}_match_split_raw_final.txt
 cp $E/single_call_latency.txt profiles/${R}_single_call_latency.txt; cp $E/smoke.txt profiles/${R}_smoke.txt
 cp $E/lockstep_phases.txt profiles/${R}_vo_lockstep_phases.txt; cp $E/lockstep_phases_pipelined.txt profiles/${R}_vo_lockstep_phases_pipelined.txt
 cp $E/lockstep_libc_rand.txt profiles/${R}_vo_lockstep_libc_rand.txt
-python tools/match_split_summary.py profiles/${R}_match_split_raw_baseline.txt profiles/${R}_match_split_raw_final.txt > /tmp/split_table.txt
+python tools/match_split_summary.py profiles/${R}_match_split_raw_baseline.txt profiles/${R}_match_split_raw_final.txt > profiles/${R}_match_split.txt; cat tools/match_split_notes.txt >> profiles/${R}_match_split.txt
 python tools/design_table_update.py $R
