@@ -1375,32 +1375,40 @@ def main():
             srm = e.stream(W, H)
             got = []
 
-            def seq_pass():
+            def seq_pass(passes):
+                # `passes` x the 430-frame sequence as ONE stream: the producer keeps pushing rings while the consumer pops
                 del got[:]
-                cons = _th.Thread(target=lambda: got.extend(srm.pop_n(ns)))
+                cons = _th.Thread(target=lambda: got.extend(srm.pop_n(passes * ns)))
                 cons.start()
-                for r0 in range(0, ns, ring):
-                    k = min(ring, ns - r0)
-                    srm.push_n_raw(k, (C.c_void_p * k)(*a1[r0:r0 + k]), (C.c_void_p * k)(*a2[r0:r0 + k]),
-                                   (C.c_void_p * k)(*d1[r0:r0 + k]), (C.c_void_p * k)(*d2[r0:r0 + k]))
+                for _ in range(passes):
+                    for r0 in range(0, ns, ring):
+                        k = min(ring, ns - r0)
+                        srm.push_n_raw(k, (C.c_void_p * k)(*a1[r0:r0 + k]), (C.c_void_p * k)(*a2[r0:r0 + k]),
+                                       (C.c_void_p * k)(*d1[r0:r0 + k]), (C.c_void_p * k)(*d2[r0:r0 + k]))
                 srm.flush()
                 cons.join()
             hD1.zero_(); hD2.zero_()
-            seq_pass()
+            seq_pass(1)
             t = time.perf_counter()
             for _ in range(3):
-                seq_pass()
+                seq_pass(1)              # one sequence at a time: each pass pays the stream's ramp-up and drain
             dts = time.perf_counter() - t
+            ok1 = got == [0] * ns
+            t = time.perf_counter()
+            seq_pass(6)                  # the same frames as one long stream (2 580 frames): the steady state
+            dtl = time.perf_counter() - t
             srm.close()
-            same_s = bool(got == [0] * ns and all(
+            same_s = bool(ok1 and got == [0] * (6 * ns) and all(
                 torch.equal(hD1[i].to(dev), dD1[i]) and torch.equal(hD2[i].to(dev), dD2[i]) for i in (0, 1, ns // 2, ns - 1)))
             out["throughput_host_buffers_stream"] = {
-                "value": 3 * ns / dts, "unit": "pairs/s", "frames": ns, "passes": 3, "ring": ring,
-                "vs_batch_entry": round(3 * ns / dts / out["throughput_host_buffers"]["value"], 3),
-                "pcie_GBps": 3 * ns * 10 * N_PIX / dts / 1e9, "maps_equal_device_path": same_s,
-                "note": "svh_elas_stream_push_n / pop_n: a %d-frame sequence from pinned host frames, maps back to "
-                        "pinned host memory, submission order preserved; each pass includes the stream's ramp-up and "
-                        "drain (the sequence is shorter than a second); PCIe-inclusive, never `value`" % ns}
+                "value": 6 * ns / dtl, "unit": "pairs/s", "frames": 6 * ns, "ring": ring,
+                "per_sequence_of_430": {"value": 3 * ns / dts, "passes": 3,
+                                        "note": "first push to last pop of ONE 430-frame sequence (37 ms): ramp-up and drain included"},
+                "vs_batch_entry": round(6 * ns / dtl / out["throughput_host_buffers"]["value"], 3),
+                "pcie_GBps": 6 * ns * 10 * N_PIX / dtl / 1e9, "maps_equal_device_path": same_s,
+                "note": "svh_elas_stream_push_n / pop_n: pinned host frames in, maps back to pinned host memory, submission "
+                        "order preserved; a producer pushing rings of %d frames and a consumer popping, the %d-frame "
+                        "sequence six times over as one stream; PCIe-inclusive, never `value`" % (ring, ns)}
             del hI1, hI2, hD1, hD2
         if extras and args.workload == "kitti" and args.data == "urban":
             # the round-1 headline workload for comparison: seeded synthetic pairs, same step

@@ -55,8 +55,8 @@ rows.append(("`--workload hd1080` (configs[3])", "**%d pairs/s** through the str
 rows.append(("`--workload sequence` (configs[2] substitute)", "**%d pairs/s** through the stream, %d through the batch entry"
              % (v(L("bench_line_sequence"), "value", default=0), v(L("bench_line_sequence_batch_api"), "value", default=0))))
 hb, hs = b.get("throughput_host_buffers", {}), b.get("throughput_host_buffers_stream", {})
-rows.append(("host buffers in and out (PCIe-inclusive, never `value`)", "batch entry **%d pairs/s** (%.1f GB/s over PCIe); as a stream (`svh_elas_stream_push_n`, 430-frame sequence, order preserved) **%d pairs/s** = %.2f of it, maps == device path: %s; single `svh_elas_process` %.2f ms"
-             % (hb.get("value", 0), hb.get("pcie_GBps", 0), hs.get("value", 0), hs.get("vs_batch_entry", 0), str(hs.get("maps_equal_device_path")).lower(), b.get("latency_ms_single_pair_host_buffers", 0))))
+rows.append(("host buffers in and out (PCIe-inclusive, never `value`)", "batch entry **%d pairs/s** (%.1f GB/s over PCIe); as a stream (`svh_elas_stream_push_n` / `pop_n`, order preserved) **%d pairs/s** = %.2f of it (%d for one 430-frame sequence on its own, ramp-up and drain included), maps == device path: %s; single `svh_elas_process` %.2f ms"
+             % (hb.get("value", 0), hb.get("pcie_GBps", 0), hs.get("value", 0), hs.get("vs_batch_entry", 0), v(hs, "per_sequence_of_430", "value", default=0), str(hs.get("maps_equal_device_path")).lower(), b.get("latency_ms_single_pair_host_buffers", 0))))
 m, vo = b.get("matcher", {}), b.get("visual_odometry", {})
 tl = m.get("timeline", {})
 runs = {(r["calling_threads"], r["objects_per_call"]): r for r in v(vo, "lockstep", "runs", default=[]) if r.get("pipelined")}
