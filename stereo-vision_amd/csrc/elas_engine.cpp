@@ -350,8 +350,8 @@ struct Lane {
 // Delaunay / lattice-filter work of the other workers needs those cycles (measured on the
 // 16-core-quota MI355X box: same throughput at 10 instead of 16 cores).  They poll a completion
 // event and sleep in between (SVH_WAIT_US, default 40; 0 = spin).
-static int g_wait_us = 40;   // (SVH_WAIT_US / svh_config::wait_us: apply_config below)
-static bool g_hostprof = false;   // SVH_HOST_PROF (apply_config)
+static std::atomic<int> g_wait_us{40};   // (SVH_WAIT_US / svh_config::wait_us: apply_config below)
+static std::atomic<bool> g_hostprof{false};   // SVH_HOST_PROF (apply_config)
 static hipError_t lane_wait(Lane& L) {
     if (!L.poll_wait || g_wait_us <= 0) return hipStreamSynchronize(L.stream);
     if (!L.wait_ev) {
@@ -363,7 +363,7 @@ static hipError_t lane_wait(Lane& L) {
     for (;;) {
         e = hipEventQuery(L.wait_ev);
         if (e != hipErrorNotReady) return e;
-        std::this_thread::sleep_for(std::chrono::microseconds(g_wait_us));
+        std::this_thread::sleep_for(std::chrono::microseconds(g_wait_us.load(std::memory_order_relaxed)));
     }
 }
 
@@ -593,7 +593,7 @@ static hipError_t event_wait(Lane& L, hipEvent_t ev) {
     for (;;) {
         hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
-        std::this_thread::sleep_for(std::chrono::microseconds(g_wait_us));
+        std::this_thread::sleep_for(std::chrono::microseconds(g_wait_us.load(std::memory_order_relaxed)));
     }
 }
 
@@ -972,6 +972,13 @@ static int run_group_body(Lane& L, const svh_elas_params& p, const int32_t* dims
         HP_MARK(HP_ENQ_B);
         t1 = t2 = now_ms();
     } else {
+    // the host stage of a latency call triangulates on helper threads: they wake while the device still works
+    const bool warm = L.parallel_host && g == 1;
+    if (warm) helpers_warm(3, 1500);
+    struct WarmOff {
+        bool on;
+        ~WarmOff() { if (on) helpers_warm(0, 0); }
+    } warm_off{warm};
     HIP_TRY(lane_wait(L));
     HIP_TRY(hipGetLastError());
     L.prof.collect();
@@ -1051,6 +1058,10 @@ static int run_group_body(Lane& L, const svh_elas_params& p, const int32_t* dims
             off += v.size() * sizeof(int32_t);
         }
     if (off > L.prior_cap) return fail(SVH_ERR_BAD_ARG, "prior exceeds staging capacity");
+    if (warm_off.on) {
+        helpers_warm(0, 0);
+        warm_off.on = false;
+    }
     t2 = now_ms();
     HP_MARK(HP_PACK);
 

@@ -443,6 +443,8 @@ struct svh_matcher {
     int32_t* h_n = nullptr;                     // pinned: feature counts [camera][sparse, dense]
     int32_t h_pm_cap = 0;
     bool taps = false;                          // keep every intermediate stage (parity tests)
+    int32_t last_dense = 0;                     // matches of the last dense pass before the vote (predicts the next one)
+    bool warm_on_wait = false;                  // wake the vote's helper threads once the dense pass is enqueued
     // results
     std::vector<svh_p_match> m1, m2;
     std::vector<svh_p_match> m2_kept;   // the match list of the last good matchFeatures while a new one is being built
@@ -681,6 +683,16 @@ static int ensure_bins(svh_matcher* m, DevView* const* views, int nviews, int32_
     return SVH_OK;
 }
 
+// the triangulation of a large vote runs on 2^depth threads when this is the only sequence on the GPU's host side
+// (several callers at once = several sequences: their own threads already fill the cores, the helper pool would only
+// be fought over; inside a batch call the pool of the batch is the parallelism)
+static int vote_par_depth() {
+    static const int par = svh::env("SVH_DELAUNAY_PAR") ? atoi(svh::env("SVH_DELAUNAY_PAR")) : 3;
+    const bool alone = g_active_callers.load(std::memory_order_relaxed) <= 2 && !t_in_batch;
+    return alone ? std::max(0, std::min(par, 3)) : 0;
+}
+static const int32_t kVoteParMin = 1500;
+
 // M9  Matcher::removeOutliers   matcher.cpp:1383-1570 (host: Delaunay + edge votes)
 static int remove_outliers(const svh_matcher_params& p, std::vector<svh_p_match>& pm, int32_t method) {
     if (pm.size() <= 3) return SVH_OK;
@@ -691,34 +703,42 @@ static int remove_outliers(const svh_matcher_params& p, std::vector<svh_p_match>
         pts[2 * i + 1] = pm[i].v1c;
     }
     std::vector<int32_t> tri((size_t)3 * (2 * n + 16));
-    // the Matcher is a single-stream, latency-bound path: large votes triangulate on 4 threads
-    static const int par = svh::env("SVH_DELAUNAY_PAR") ? atoi(svh::env("SVH_DELAUNAY_PAR")) : 2;
-    // (several callers at once = several sequences on this GPU: their host threads already fill the
-    // cores, the helper pool would only be fought over)
-    const bool alone = g_active_callers.load(std::memory_order_relaxed) <= 2 && !t_in_batch;
-    const int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 16, (n >= 1500 && alone) ? par : 0);
+    // the Matcher is a single-stream, latency-bound path: large votes triangulate on helper threads
+    const int par = n >= kVoteParMin ? vote_par_depth() : 0;
+    const int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 16, par);
     if (nt < 0) return mfail(SVH_ERR_UNSUPPORTED, "outlier triangulation failed");
-    std::vector<int32_t> votes(n, 0);
     const float ft = (float)p.outlier_flow_tolerance, dt = (float)p.outlier_disp_tolerance;
-    for (int32_t t = 0; t < nt; t++) {
-        const int32_t* c = &tri[3 * t];
-        static const int e[3][2] = {{0, 1}, {1, 2}, {0, 2}};
-        for (int k = 0; k < 3; k++) {
-            const svh_p_match& a = pm[c[e[k][0]]];
-            const svh_p_match& b = pm[c[e[k][1]]];
-            bool ok = true;
-            if (method == 1) {
-                ok = fabsf((a.u1c - a.u2c) - (b.u1c - b.u2c)) < dt;
-            } else {
-                if (method == 2) ok = fabsf((a.u1p - a.u2p) - (b.u1p - b.u2p)) < dt;
-                const float fu = (a.u1c - a.u1p) - (b.u1c - b.u1p), fv = (a.v1c - a.v1p) - (b.v1c - b.v1p);
-                ok = ok && fabsf(fu) + fabsf(fv) < ft;
-            }
-            if (ok) {
-                votes[c[e[k][0]]]++;
-                votes[c[e[k][1]]]++;
+    // support of a vertex = its triangle edges whose endpoints agree (an edge counts once per triangle it bounds)
+    auto count = [&](int32_t t0, int32_t t1, int32_t* votes) {
+        for (int32_t t = t0; t < t1; t++) {
+            const int32_t* c = &tri[3 * t];
+            static const int e[3][2] = {{0, 1}, {1, 2}, {0, 2}};
+            for (int k = 0; k < 3; k++) {
+                const svh_p_match& a = pm[c[e[k][0]]];
+                const svh_p_match& b = pm[c[e[k][1]]];
+                bool ok = true;
+                if (method == 1) {
+                    ok = fabsf((a.u1c - a.u2c) - (b.u1c - b.u2c)) < dt;
+                } else {
+                    if (method == 2) ok = fabsf((a.u1p - a.u2p) - (b.u1p - b.u2p)) < dt;
+                    const float fu = (a.u1c - a.u1p) - (b.u1c - b.u1p), fv = (a.v1c - a.v1p) - (b.v1c - b.v1p);
+                    ok = ok && fabsf(fu) + fabsf(fv) < ft;
+                }
+                if (ok) {
+                    votes[c[e[k][0]]]++;
+                    votes[c[e[k][1]]]++;
+                }
             }
         }
+    };
+    const int parts = par > 0 ? 4 : 1;
+    std::vector<int32_t> votes((size_t)n * parts, 0);
+    if (parts == 1) {
+        count(0, nt, votes.data());
+    } else {   // (the helpers are still awake from the triangulation)
+        run_many(parts, [&](int i) { count((int32_t)((int64_t)nt * i / parts), (int32_t)((int64_t)nt * (i + 1) / parts), &votes[(size_t)n * i]); });
+        for (int k = 1; k < parts; k++)
+            for (int32_t i = 0; i < n; i++) votes[i] += votes[(size_t)n * k + i];
     }
     size_t w = 0;
     for (int32_t i = 0; i < n; i++)
@@ -871,6 +891,10 @@ static int run_matching(svh_matcher* m, int dense, int32_t method, bool use_prio
     auto download = [&](std::vector<svh_p_match>& dst) -> int {
         download_enqueue(m, mp);
         if (timed) tev_record(m, dense ? 7 : 5, m->stream);
+        if (m->warm_on_wait) {   // (costs this thread a few futex wakes: paid while the device works)
+            m->warm_on_wait = false;
+            helpers_warm(7, 1500);
+        }
         HIP_TRY((hipError_t)wait_stream(m->stream));
         HIP_TRY(hipGetLastError());
         match_collect(m, mp, dst);
@@ -1482,6 +1506,8 @@ int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double*
     double tm[6] = {0, 0, 0, 0, 0, 0};
     auto tick = [&](int i) { if (g_mtiming) tm[i] = mnow_ms(); };
     tick(0);
+    // the dense vote of a frame like the last one will triangulate on helper threads: have them awake by then
+    const bool warm = m->last_dense >= kVoteParMin && vote_par_depth() > 0;
     if (p.multi_stage) {
         rc = run_matching(m, 0, method, false, Tr, m->m1, false, &m->stage[SVH_M_SPARSE_RAW]);
         if (rc) return rc;
@@ -1494,15 +1520,23 @@ int32_t svh_matcher_match_features(svh_matcher* m, int32_t method, const double*
         HIP_TRY(hipMemcpyAsync(m->ranges_dev, m->ranges.data(), m->ranges.size() * sizeof(float),
                                hipMemcpyHostToDevice, m->stream));
         tick(3);
+        m->warm_on_wait = warm;
         rc = run_matching(m, 1, method, true, Tr, m->m2, p.refinement > 0, &m->stage[SVH_M_DENSE_RAW]);
     } else {
         tick(1); tick(2); tick(3);
+        m->warm_on_wait = warm;
         rc = run_matching(m, 1, method, false, Tr, m->m2, p.refinement > 0, &m->stage[SVH_M_DENSE_RAW]);
     }
-    if (rc) return rc;
+    m->warm_on_wait = false;
+    if (rc) {
+        if (warm) helpers_warm(0, 0);
+        return rc;
+    }
     tick(4);
     if (m->taps) m->stage[SVH_M_DENSE_REFINED] = m->m2;
+    m->last_dense = (int32_t)m->m2.size();
     rc = remove_outliers(p, m->m2, method);
+    if (warm) helpers_warm(0, 0);
     if (rc) return rc;
     tick(5);
     if (g_mtiming) {

@@ -26,6 +26,8 @@ namespace svh {
 namespace {
 
 std::atomic<int> g_fixed{0};          // the configuration has been fixed (explicitly or implicitly)
+std::atomic<int> g_ready{0};          // ... and every subscriber has applied it (what ensure_init's fast path waits for)
+thread_local bool t_in_fix = false;   // a subscriber that reaches ensure_init while it is being called
 std::atomic<int> g_read_env{1};
 std::mutex g_mu;
 svh_config g_cfg;                     // effective configuration
@@ -109,7 +111,10 @@ int fix(const svh_config* in, bool explicit_call) {
     g_cfg = c;
     g_fixed.store(1, std::memory_order_release);
     g_explicit = explicit_call ? 1 : 0;
+    t_in_fix = true;
     for (auto fn : hooks()) fn(g_cfg, g_explicit);
+    t_in_fix = false;
+    g_ready.store(1, std::memory_order_release);
     return SVH_OK;
 }
 
@@ -118,7 +123,8 @@ int fix(const svh_config* in, bool explicit_call) {
 const char* env(const char* name) { return g_read_env.load(std::memory_order_relaxed) ? getenv(name) : nullptr; }
 
 void ensure_init() {
-    if (g_fixed.load(std::memory_order_acquire)) return;
+    // (a second first user waits on the mutex inside fix() until the first one's subscribers are through)
+    if (g_ready.load(std::memory_order_acquire) || t_in_fix) return;
     (void)fix(nullptr, false);
 }
 

@@ -88,6 +88,11 @@ void support_from_candidates(const svh_elas_params& p, const Dims& d, int16_t* d
 bool triangulate_support(HostPrior& hp, bool parallel = false);
 // runs a() on the calling thread and b() on a parked helper thread (or both here if none is free)
 void run_pair(const std::function<void()>& a, const std::function<void()>& b);
+// fn(0) on the calling thread, fn(1) .. fn(k-1) on helper threads (or here, one after the other, if none is free); k <= 8
+void run_many(int k, const std::function<void(int)>& fn);
+// `want` helper threads poll for tasks for the next `us` microseconds instead of sleeping (0, 0: back to sleep once
+// idle).  Called a little ahead of a parallel section on a latency path; a polling helper is a busy core.
+void helpers_warm(int want, int us);
 // prior table + plane radius (elas.cpp:984-993)
 void prior_table(const svh_elas_params& p, std::vector<int32_t>& P, int32_t* plane_radius);
 // reference-layout grid (int32 [gh][gw][disp_max+2]) from the device bit sets, for the tap

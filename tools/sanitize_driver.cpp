@@ -58,6 +58,19 @@ int main(int argc, char** argv) {
                 }
             }
             if (na > 0) tris += na;
+            // ---- the helper calls of the Matcher's vote: a warm window, then a four-way split with private outputs
+            if (r % 3 == 0) helpers_warm(3, 200);
+            long part[4] = {0, 0, 0, 0};
+            run_many(4, [&](int i) {
+                for (int32_t t = na * i / 4; t < na * (i + 1) / 4; t++) part[i] += a[3 * t] + a[3 * t + 1] + a[3 * t + 2];
+            });
+            long whole = 0;
+            for (int32_t t = 0; t < 3 * std::max(na, 0); t++) whole += a[t];
+            if (part[0] + part[1] + part[2] + part[3] != whole) {
+                fprintf(stderr, "thread %d round %d: run_many lost work\n", id, r);
+                bad++;
+            }
+            if (r % 3 == 0) helpers_warm(0, 0);
             // ---- both triangulations of a support list on two threads (single-call path)
             HostPrior hp;
             for (int i = 0; i < 400; i++) {
