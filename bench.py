@@ -230,7 +230,9 @@ def matcher_bench(iters=40):
                     "calls them): the dense outlier vote (a Delaunay triangulation of ~2.9 k matches, matcher.cpp:1383-1570) "
                     "and the prior statistics are host steps of the reference that SURVEY 8(a) leaves on the host; nothing "
                     "of the NEXT frame exists while they run (the caller hands it over afterwards), so for one object they "
-                    "are idle time of the device.  K objects in lockstep fill it: visual_odometry.lockstep"}
+                    "are idle time of the device (the triangulation runs on eight threads of the host: helper threads on the "
+                    "caller's L3, awake while the dense matching is on the device).  K objects in lockstep fill it: "
+                    "visual_odometry.lockstep"}
         out["roofline"] = {
             "bound": "latency", "unit": "GB/s", "algorithmic_bytes_per_frame": 17 * n_px,
             "achieved": round(17 * n_px / (dev_ms * 1e-3) / 1e9, 1), "peak": 8000.0,

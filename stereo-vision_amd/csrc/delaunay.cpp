@@ -139,6 +139,7 @@ struct HelperPool {
         std::condition_variable cv;
     };
     Box box[kHelpers];
+    std::atomic<int64_t> n_tasks{0}, n_moves{0}, n_hot{0}, n_woken{0};   // tasks run, of them after a move to another L3; taken by a polling / a sleeping helper
     std::atomic<int64_t> warm_until{0};   // helpers poll instead of sleeping until then
     std::mutex spawn_mu;
 
@@ -150,8 +151,11 @@ struct HelperPool {
             if (st == TASK) {
                 const int g = b->l3;
                 if (g >= 0 && g != mine && CPU_COUNT(&l3map().mask[g]) >= 2 &&
-                    sched_setaffinity(0, sizeof(cpu_set_t), &l3map().mask[g]) == 0)
+                    sched_setaffinity(0, sizeof(cpu_set_t), &l3map().mask[g]) == 0) {
                     mine = g;
+                    n_moves.fetch_add(1, std::memory_order_relaxed);
+                }
+                n_tasks.fetch_add(1, std::memory_order_relaxed);
                 b->fn();
                 b->fn = nullptr;
                 std::atomic<int>* d = b->done;
@@ -189,8 +193,10 @@ struct HelperPool {
                 b->state.store(TASK, std::memory_order_release);
             }
             b->cv.notify_one();
+            n_woken.fetch_add(1, std::memory_order_relaxed);
         } else {
             b->state.store(TASK, std::memory_order_release);
+            n_hot.fetch_add(1, std::memory_order_relaxed);
         }
         return true;
     }
@@ -1032,6 +1038,15 @@ int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap, int par
 }
 
 }  // namespace svh
+
+extern "C" void svh_host_helper_stats(int64_t out[4]) {
+    if (!out) return;
+    svh::HelperPool& p = svh::helper_pool();
+    out[0] = p.n_tasks.load();
+    out[1] = p.n_moves.load();
+    out[2] = p.n_hot.load();
+    out[3] = p.n_woken.load();
+}
 
 extern "C" int32_t svh_delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap) {
     if (!pts || !tri || n < 0) return SVH_ERR_BAD_ARG;

@@ -49,6 +49,28 @@ def test_matches_golden_reference_output(case):
     assert (got == want).all()
 
 
+@pytest.mark.parametrize("case", ["viso_quad_default", "viso_quad_predicted"])
+def test_latency_path_without_taps_matches_golden(case):
+    """the form an application runs: no stage taps, so from the second frame on the dense vote's triangulation
+    starts on the unrefined match list while the device refines it, on warm helper threads (fork depth 3), and the
+    vote itself is split four ways.  Frames alternate so that every call is a fresh quad; the list must be the
+    reference's every time, and equal to the tapped run's"""
+    z = np.load(os.path.join(H.GOLDEN, case + ".npz"))
+    prm = H.MatcherParams.from_buffer_copy(z["params"].tobytes())
+    method = int(z["method"])
+    tr = z["tr"] if z["tr"].size else None
+    im = quad()
+    m = H.ProductMatcher(prm)
+    m.lib.svh_matcher_set_taps(C.c_void_p(m.h), 0)
+    want = z["dense"]
+    for rep in range(4):
+        m.push_back(im["I1p"], im["I2p"])
+        m.push_back(im["I1c"], im["I2c"])
+        assert m.match(method, tr) == 0
+        got = m.matches()
+        assert len(got) == len(want) and (got == want).all(), rep
+
+
 @pytest.mark.parametrize("kw,method", [
     ({}, 2), ({"half_resolution": 0}, 2), ({"multi_stage": 0}, 2), ({"refinement": 0}, 2),
     ({"nms_n": 5, "nms_tau": 30, "match_binsize": 40}, 2), ({"half_resolution": 0}, 0),
