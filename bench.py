@@ -194,13 +194,25 @@ def matcher_bench(iters=40):
             nm = len(m.matches())
         return 1e3 * t_push / n, 1e3 * t_match / n, nm
 
+    def helper_stats():
+        st = (C.c_int64 * 4)()
+        try:
+            dev.lib.svh_host_helper_stats(st)
+        except AttributeError:   # (an older library under SVH_LIB)
+            pass
+        return list(st)
+
     dev = Hh.ProductMatcher(prm)
     dev.lib.svh_matcher_set_taps(C.c_void_p(dev.h), 0)   # timing: no intermediate stage copies
     run(dev, 10)
+    hs0 = helper_stats()
     push, match, nm = run(dev, iters)
+    hs1 = helper_stats()
     out = {"workload": "quad match on libviso2/img I1p/I2p/I1c/I2c 1344x391, default parameters",
            "pushBack_ms": push, "matchFeatures_ms": match, "frame_ms": push + match,
-           "frames_per_s": 1e3 / (push + match), "matches": nm}
+           "frames_per_s": 1e3 / (push + match), "matches": nm,
+           "host_helper_threads": dict(zip(("tasks", "l3_moves", "taken_by_a_polling_helper", "taken_by_a_sleeping_helper"),
+                                           [b - a for a, b in zip(hs0, hs1)]), per_frames=iters)}
     # round 6: the call's timeline from the library's own clocks (svh_matcher_get_timing: host wall-clock steps, and
     # the device time of the three device phases from HIP events on the object's streams), a second pass with the
     # collection on; and the leg's roofline: SURVEY 8(d)'s 17 N bytes per stereo frame over the device time
