@@ -206,11 +206,13 @@ def matcher_bench(iters=40):
     dev.lib.svh_matcher_set_taps(C.c_void_p(dev.h), 0)   # timing: no intermediate stage copies
     run(dev, 10)
     hs0 = helper_stats()
+    cpu0, wall0 = time.process_time(), time.perf_counter()
     push, match, nm = run(dev, iters)
+    host_cores = (time.process_time() - cpu0) / (time.perf_counter() - wall0)   # caller + polling helper threads
     hs1 = helper_stats()
     out = {"workload": "quad match on libviso2/img I1p/I2p/I1c/I2c 1344x391, default parameters",
            "pushBack_ms": push, "matchFeatures_ms": match, "frame_ms": push + match,
-           "frames_per_s": 1e3 / (push + match), "matches": nm,
+           "frames_per_s": 1e3 / (push + match), "matches": nm, "host_cores_used": round(host_cores, 2),
            "host_helper_threads": dict(zip(("tasks", "l3_moves", "taken_by_a_polling_helper", "taken_by_a_sleeping_helper"),
                                            [b - a for a, b in zip(hs0, hs1)]), per_frames=iters)}
     # round 6: the call's timeline from the library's own clocks (svh_matcher_get_timing: host wall-clock steps, and
