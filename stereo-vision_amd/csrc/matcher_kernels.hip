@@ -235,19 +235,29 @@ __device__ __forceinline__ void d_nms(const int16_t* __restrict__ f1,
 // Order-preserving compaction by one workgroup: thread t owns a contiguous
 // chunk of slots, an LDS scan of the per-thread counts gives its output base.
 // ---------------------------------------------------------------------------
+// (round 6: a scan inside each wave by lane shuffles, then the 16 wave totals through LDS -- two barriers instead of
+// the twenty of a 1024-wide Hillis-Steele scan, which were most of the 11-14 us these single-workgroup kernels took)
 __device__ __forceinline__ int block_exclusive_scan_1024(int value, int* total) {
-    __shared__ int s_scan[1024];
-    const int t = threadIdx.x;
-    s_scan[t] = value;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int add = t >= off ? s_scan[t - off] : 0;
-        __syncthreads();
-        s_scan[t] += add;
-        __syncthreads();
+    __shared__ int s_wave[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int incl = value;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
     }
-    *total = s_scan[1023];
-    return s_scan[t] - value;
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const int x = s_wave[w];
+        before += w < wave ? x : 0;
+        all += x;
+    }
+    __syncthreads();   // (s_wave may be written again by the caller's next scan)
+    *total = all;
+    return before + incl - value;
 }
 
 // ordered compaction of the surviving slots: order[k] = slot of the k-th feature
@@ -258,19 +268,42 @@ __device__ __forceinline__ void d_compact_slots(const int32_t* __restrict__ flag
     const int chunk = ((nslots + 1023) / 1024 + 3) & ~3;   // multiple of 4: 16-byte flag loads
     const int lo = min(t * chunk, nslots), hi = min(lo + chunk, nslots);
     int mine = 0;
-    for (int s = lo; s < hi; s += 4) {
-        if (s + 4 <= hi) {
-            const int4 f = *reinterpret_cast<const int4*>(flags + s);
-            mine += f.x + f.y + f.z + f.w;
-        } else {
-            for (int r = s; r < hi; r++) mine += flags[r];
+    // the flags of a chunk of up to 64 slots are kept as a bit mask: the write pass then reads nothing (it used to load
+    // every flag again, one dependent load per slot and turn: 20 of the kernel's 24-35 us on a dense table)
+    const bool masked = chunk <= 64;
+    unsigned long long bits = 0;
+    if (masked) {
+#pragma unroll 4
+        for (int q = 0; q < 16; q++) {
+            const int s = lo + 4 * q;
+            if (s >= hi) break;
+            if (s + 4 <= hi) {
+                const int4 f = *reinterpret_cast<const int4*>(flags + s);
+                const unsigned nib = (f.x ? 1u : 0u) | (f.y ? 2u : 0u) | (f.z ? 4u : 0u) | (f.w ? 8u : 0u);
+                bits |= (unsigned long long)nib << (4 * q);
+            } else {
+                for (int r = s; r < hi; r++) bits |= (unsigned long long)(flags[r] ? 1 : 0) << (r - lo);
+            }
+        }
+        mine = __popcll(bits);
+    } else {
+        for (int s = lo; s < hi; s += 4) {
+            if (s + 4 <= hi) {
+                const int4 f = *reinterpret_cast<const int4*>(flags + s);
+                mine += f.x + f.y + f.z + f.w;
+            } else {
+                for (int r = s; r < hi; r++) mine += flags[r];
+            }
         }
     }
     int total;
     int base = block_exclusive_scan_1024(mine, &total);
-    if (mine)
+    if (masked) {
+        for (; bits; bits &= bits - 1) order[base++] = lo + __builtin_ctzll(bits);
+    } else if (mine) {
         for (int s = lo; s < hi; s++)
             if (flags[s]) order[base++] = s;
+    }
     if (t == 0) *count = total;
 }
 
@@ -607,6 +640,7 @@ __device__ __forceinline__ void d_match_dedupe(const int32_t* __restrict__ n, in
     if (pixel_owner[(size_t)v * width + u] != i) flags[i] = 0;
 }
 
+constexpr int kCompactLds = 8192;   // survivors whose slot numbers fit the LDS list of d_compact_matches
 __device__ __forceinline__ void d_compact_matches(const svh_p_match* __restrict__ in,
                                                           const int32_t* __restrict__ flags,
                                                           const int32_t* __restrict__ nslots_ptr,
@@ -617,11 +651,37 @@ __device__ __forceinline__ void d_compact_matches(const svh_p_match* __restrict_
     const int chunk = (nslots + 1023) / 1024;
     const int lo = min(t * chunk, nslots), hi = min(lo + chunk, nslots);
     int mine = 0;
-    for (int s = lo; s < hi; s++) mine += flags[s];
+    const bool masked = chunk <= 32;   // (as in d_compact_slots: the flags of the chunk as a bit mask)
+    unsigned bits = 0;
+    if (masked) {
+#pragma unroll 8
+        for (int q = 0; q < 32; q++)
+            if (lo + q < hi) bits |= (flags[lo + q] ? 1u : 0u) << q;
+        mine = __popc(bits);
+    } else {
+        for (int s = lo; s < hi; s++) mine += flags[s];
+    }
     int total;
     int base = block_exclusive_scan_1024(mine, &total);
-    for (int s = lo; s < hi; s++)
-        if (flags[s]) out[base++] = in[s];
+    // the survivors' slot numbers go through LDS, then the whole workgroup moves the 48-byte records as 16-byte pieces
+    // side by side (a thread copying its own records one after the other was 6 of the kernel's 10 us)
+    __shared__ int s_src[kCompactLds];
+    static_assert(sizeof(svh_p_match) == 48, "three 16-byte pieces per record");
+    if (masked && total <= kCompactLds) {
+        for (; bits; bits &= bits - 1) s_src[base++] = lo + __builtin_ctz(bits);
+        __syncthreads();
+        const uint4* src = reinterpret_cast<const uint4*>(in);
+        uint4* dst = reinterpret_cast<uint4*>(out);
+        for (int k = t; k < 3 * total; k += 1024) {
+            const int m = k / 3, part = k - 3 * m;
+            dst[k] = src[3 * s_src[m] + part];
+        }
+    } else if (masked) {
+        for (; bits; bits &= bits - 1) out[base++] = in[lo + __builtin_ctz(bits)];
+    } else {
+        for (int s = lo; s < hi; s++)
+            if (flags[s]) out[base++] = in[s];
+    }
     if (t == 0) *count = total;
 }
 

@@ -331,18 +331,23 @@ __device__ __forceinline__ void d_vo_refine(const svh_p_match* __restrict__ pm, 
         const int lo = min(t * chunk, N), hi = min(lo + chunk, N);
         int mine = 0;
         for (int i = lo; i < hi; i++) mine += fl[i];
-        s_scan[t] = mine;
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            const int add = t >= off ? s_scan[t - off] : 0;
-            __syncthreads();
-            s_scan[t] += add;
-            __syncthreads();
+        // (scan inside each wave by shuffles, the four wave totals through LDS: two barriers instead of sixteen)
+        const int lane = t & 63, wave = t >> 6;
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
         }
-        int pos = s_scan[t] - mine;
+        if (lane == 63) s_scan[wave] = incl;
+        __syncthreads();
+        int pos = incl - mine;
+        for (int w = 0; w < 4; w++) {
+            pos += w < wave ? s_scan[w] : 0;
+            nin += s_scan[w];
+        }
         for (int i = lo; i < hi; i++)
             if (fl[i]) out_inliers[pos++] = i;
-        nin = s_scan[255];
         if (t < 6) s_tr[t] = hyp_tr[6 * best + t];
     }
     __syncthreads();

@@ -9,7 +9,10 @@ import bench
 r = bench.matcher_bench(iters=int(sys.argv[1]) if len(sys.argv) > 1 else 40)
 import ctypes as C, svhip
 st = (C.c_int64 * 4)()
-svhip.lib().svh_host_helper_stats(st)
+try:
+    svhip.lib().svh_host_helper_stats(st)
+except AttributeError:   # an older build under SVH_LIB
+    pass
 r["host_helper_stats"] = {"tasks": st[0], "l3_moves": st[1], "to_polling": st[2], "to_sleeping": st[3]}
 print(json.dumps(r))
 import gc; gc.collect()
