@@ -377,11 +377,27 @@ __device__ __forceinline__ void d_bin_index_lds(const int32_t* __restrict__ tabl
         }
     }
     __syncthreads();
+    // the atomics hand out the places of a bin in arrival order; the reference's lists are in index order
+    // (matcher.cpp:1036-1057).  Usual sizes: an entry carries its bin in the high bits, and every ENTRY then counts the
+    // smaller indices of its bin and goes straight to its place in the output -- all entries at once, where one thread
+    // per bin used to insertion-sort its list (10 of the kernel's 20 us on a dense table).
+    const bool ranked = nb < 2048 && n < (1 << 20);
     for (int i = t; i < n; i += 1024) {
         const int b = bin_of(i);
-        s_ids[s_off[b] + atomicAdd(&s_cur[b], 1)] = i;
+        s_ids[s_off[b] + atomicAdd(&s_cur[b], 1)] = ranked ? i | (b << 20) : i;
     }
     __syncthreads();
+    if (ranked) {
+        for (int p = t; p < n; p += 1024) {
+            const int e = s_ids[p], b = e >> 20;
+            const int lo = s_off[b], hi = s_off[b + 1];
+            int rank = 0;
+            for (int q = lo; q < hi; q++) rank += s_ids[q] < e;
+            ids[lo + rank] = e & ((1 << 20) - 1);
+        }
+        for (int b = t; b <= nb; b += 1024) off[b] = s_off[b];
+        return;
+    }
     for (int b = t; b < nb; b += 1024) {   // short lists: insertion sort to ascending index
         const int lo = s_off[b], hi = s_off[b + 1];
         for (int a = lo + 1; a < hi; a++) {
