@@ -46,6 +46,11 @@ b _hd1080_x256 $Q --workload hd1080 --batch 256 --group 16 --lanes 6 --steps 8 -
 b _2ranks_gloo_1gpu $Q --gpus 2 --steps 10 --warmup 2 --dist-backend gloo
 b _1rank_nccl $Q --force-dist --dist-backend nccl --steps 10 --warmup 3
 b _soak60 $Q --steps 8 --warmup 2 --soak 60
+# the Matcher's timeline / roofline on its own, and the single Elas::process call (no environment variable anywhere).
+# Before the eight-rank runs: for some seconds after eight processes have torn down their contexts a single call's
+# second device phase takes 0.39 instead of 0.21 ms (measured: fresh 0.60, right after svh_shard --ranks 8 0.70, later 0.54)
+timeout 200 python tools/matcher_probe.py 200 2> /dev/null | tail -1 > $O/matcher_probe.json
+env -u GPU_MAX_HW_QUEUES timeout 200 python tools/gpu_single_latency.py 400 > $O/single_call_latency.txt 2>&1
 # SCALE readiness: eight ranks sharing the one GPU over gloo, two workers each, small steps (bookkeeping dry runs)
 b _8ranks_gloo_1gpu_kitti $Q --gpus 8 --dist-backend gloo --steps 4 --warmup 1 --batch 128 --lanes 2
 b _8ranks_gloo_1gpu_sequence $Q --gpus 8 --dist-backend gloo --steps 4 --warmup 1 --workload sequence --lanes 2
@@ -54,9 +59,6 @@ b _8ranks_gloo_1gpu_hd1080 $Q --gpus 8 --dist-backend gloo --steps 8 --warmup 2 
 env -u GPU_MAX_HW_QUEUES timeout 300 stereo-vision_amd/bin/svh_shard --ranks 1 --gather rccl --pairs-per-rank 6144 --steps 20 --warmup 5 2> /dev/null | grep '^{' > $O/shard_driver_1rank_rccl.json
 env -u GPU_MAX_HW_QUEUES timeout 300 stereo-vision_amd/bin/svh_shard --ranks 4 --pairs-per-rank 1536 --steps 20 --warmup 5 2> /dev/null | grep '^{' > $O/shard_driver_4ranks_pipes_1gpu.json
 env -u GPU_MAX_HW_QUEUES timeout 300 stereo-vision_amd/bin/svh_shard --ranks 8 --total 430 --steps 20 --warmup 5 --lanes 2 2> /dev/null | grep '^{' > $O/shard_driver_8ranks_sequence_strong.json
-# the Matcher's timeline / roofline on its own, and the single Elas::process call (no environment variable anywhere)
-timeout 200 python tools/matcher_probe.py 200 2> /dev/null | tail -1 > $O/matcher_probe.json
-env -u GPU_MAX_HW_QUEUES timeout 200 python tools/gpu_single_latency.py 400 > $O/single_call_latency.txt 2>&1
 SVH_MATCH_LIST=0 timeout 300 python bench.py $Q --steps 10 --warmup 3 > $O/bench_line_keyed_matcher.json 2> /dev/null
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 cd /tmp
