@@ -422,9 +422,9 @@ struct svh_matcher {
     std::shared_ptr<std::string> next_why;    // ... and its error text, if it failed
     int32_t dims_p[3], dims_c[3];
     // scratch
-    int4* slots[2] = {nullptr, nullptr};      // NMS scratch, one set per camera (the cameras'
-    int32_t* flags[2] = {nullptr, nullptr};   // feature extraction runs on two streams)
-    int32_t* order[2] = {nullptr, nullptr};
+    int4* slots[4] = {nullptr, nullptr, nullptr, nullptr};      // NMS scratch, one set per camera (the cameras' feature
+    int32_t* flags[4] = {nullptr, nullptr, nullptr, nullptr};   // extraction runs on two streams) and, [2 + camera], a second
+    int32_t* order[4] = {nullptr, nullptr, nullptr, nullptr};   // one for the sparse table (both tables by the same launches)
     int32_t slot_cap = 0;
     hipStream_t stream2 = nullptr;            // camera 1 during pushBack
     int32_t* cursor = nullptr;
@@ -552,7 +552,7 @@ static int size_view(svh_matcher* m, DevView& V, int32_t w, int32_t h, int32_t b
 static int ensure_feature_scratch(svh_matcher* m, int32_t slot_need) {
     if (slot_need > m->slot_cap) {
         m->slot_cap = 0;
-        for (int c = 0; c < 2; c++) {
+        for (int c = 0; c < 4; c++) {
             HIP_TRY(drealloc(&m->slots[c], (size_t)slot_need));
             HIP_TRY(drealloc(&m->flags[c], (size_t)slot_need + 4));
             HIP_TRY(drealloc(&m->order[c], (size_t)slot_need));
@@ -610,9 +610,8 @@ static int features_enqueue(svh_matcher* m, DevView& V, int cam, double* tf, boo
     ftick(2);
     const uint8_t* Im = V.I;
     if (p.half_resolution) {
-        mlaunch_half(s, V.I, V.bpl, V.Ih, V.mw, V.mh, V.mbpl);
+        mlaunch_half_filters(s, V.I, V.w, V.h, V.bpl, V.Ih, V.mw, V.mh, V.mbpl, V.du_full, V.dv_full);
         Im = V.Ih;
-        mlaunch_filters(s, V.I, V.w, V.h, V.bpl, V.du_full, V.dv_full, nullptr, nullptr);
     }
     mlaunch_filters(s, Im, V.mw, V.mh, V.mbpl, V.du, V.dv, V.f1, V.f2);
     ftick(3);
@@ -621,17 +620,22 @@ static int features_enqueue(svh_matcher* m, DevView& V, int cam, double* tf, boo
     if (ns > 10) ns = std::max(p.nms_n, 10);
     int rc = ensure_feature_scratch(m, std::max(V.cap[0], V.cap[1]));
     if (rc) return rc;
-    if (p.multi_stage)
-        mlaunch_features(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, ns, p.nms_tau, m->margin, scale,
-                         m->slots[cam], m->flags[cam], m->order[cam], V.tab[0], V.cnt + 0);
-    else
+    if (p.multi_stage) {
+        mlaunch_features2(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, p.nms_tau, m->margin, scale,
+                          ns, m->slots[2 + cam], m->flags[2 + cam], m->order[2 + cam], V.tab[0], V.cnt + 0,
+                          p.nms_n, m->slots[cam], m->flags[cam], m->order[cam], V.tab[1], V.cnt + 1,
+                          (counts ? counts : m->h_n) + 2 * cam);
+    } else {
         mlaunch_fill(s, V.cnt, 0, sizeof(int32_t));
-    mlaunch_features(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, p.nms_n, p.nms_tau, m->margin, scale,
-                     m->slots[cam], m->flags[cam], m->order[cam], V.tab[1], V.cnt + 1);
+        mlaunch_features(s, V.f1, V.f2, V.du, V.dv, V.mw, V.mh, V.mbpl, p.nms_n, p.nms_tau, m->margin, scale,
+                         m->slots[cam], m->flags[cam], m->order[cam], V.tab[1], V.cnt + 1);
+    }
     ftick(4);
     // feature counts come back through pinned memory after BOTH cameras are enqueued
-    // (a copy into pageable memory would block here until this camera's kernels finish)
-    mlaunch_copy(s, (counts ? counts : m->h_n) + 2 * cam, V.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
+    // (a copy into pageable memory would block here until this camera's kernels finish; with both tables the
+    // compaction launch writes them there itself)
+    if (!p.multi_stage)
+        mlaunch_copy(s, (counts ? counts : m->h_n) + 2 * cam, V.cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
     ftick(5);
     V.nbins = 0;   // bin indices are (re)built by matchFeatures for the current bin grid
     V.valid = true;
@@ -818,6 +822,7 @@ static SobelView sobel_of(const DevView& V, bool half) {
 // one matching() pass on the device, in steps a batched call can interleave over its objects:
 // match_enqueue -> [refine_enqueue] -> download_enqueue -> (stream wait) -> match_collect
 struct MatchPass {
+    bool count_on_host = false;   // the compaction wrote the count to h_cnt itself
     int32_t nq = 0;
     const svh_p_match* result = nullptr;
     const int32_t* result_count = nullptr;
@@ -842,15 +847,16 @@ static int match_enqueue(svh_matcher* m, int dense, int32_t method, bool use_pri
     const int32_t nq = q.n[dense];
     int rc = ensure_match_scratch(m, std::max(nq, 1), method < 2 ? (size_t)P.width * P.height : 0);
     if (rc) return rc;
-    mlaunch_match(m->stream, P, view_of(m->prev[0], dense), view_of(m->prev[1], dense), view_of(m->cur[0], dense),
-                  view_of(m->cur[1], dense), nq, m->ranges_dev, use_prior ? 1 : 0, m->pm_slots, m->pm_flags,
-                  m->pixel_owner, m->pm_out, m->pm_count);
     if (nq > m->h_pm_cap || !m->h_cnt) {
         m->h_pm_cap = 0;
         HIP_TRY(hrealloc(&m->h_pm, (size_t)std::max(nq, 1) * sizeof(svh_p_match)));
         if (!m->h_cnt) HIP_TRY(hipHostMalloc((void**)&m->h_cnt, sizeof(int32_t)));
         m->h_pm_cap = std::max(nq, 1);
     }
+    mlaunch_match(m->stream, P, view_of(m->prev[0], dense), view_of(m->prev[1], dense), view_of(m->cur[0], dense),
+                  view_of(m->cur[1], dense), nq, m->ranges_dev, use_prior ? 1 : 0, m->pm_slots, m->pm_flags,
+                  m->pixel_owner, m->pm_out, m->pm_count, m->h_cnt);
+    mp.count_on_host = t_rec == nullptr;   // (a recorded batch compacts through the job table: its count is copied)
     mp.nq = nq;
     mp.result = m->pm_out;
     mp.result_count = m->pm_count;
@@ -867,11 +873,12 @@ static void refine_enqueue(svh_matcher* m, int32_t method, MatchPass& mp) {
     if (parabolic) {
         mp.result = m->pm_slots;
         mp.result_count = m->pm_count + 1;
+        mp.count_on_host = false;
     }
 }
 
 static void download_enqueue(svh_matcher* m, const MatchPass& mp) {
-    mlaunch_copy(m->stream, m->h_cnt, mp.result_count, sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (!mp.count_on_host) mlaunch_copy(m->stream, m->h_cnt, mp.result_count, sizeof(int32_t), hipMemcpyDeviceToHost);
     if (mp.nq > 0)
         mlaunch_copy(m->stream, m->h_pm, mp.result, (size_t)mp.nq * sizeof(svh_p_match), hipMemcpyDeviceToHost);
 }
@@ -1040,7 +1047,7 @@ void svh_matcher_destroy(svh_matcher* m) {
             m->cur[k].release();
             m->next[k].release();
         }
-        for (int c = 0; c < 2; c++) {
+        for (int c = 0; c < 4; c++) {
             (void)hipFree(m->slots[c]); (void)hipFree(m->flags[c]); (void)hipFree(m->order[c]);
         }
         (void)hipFree(m->cursor);

@@ -47,9 +47,15 @@ void mlaunch_half(void* stream, const uint8_t* I, int bpl, uint8_t* out, int hw,
 void mlaunch_filters(void* stream, const uint8_t* I, int w, int h, int bpl, uint8_t* du, uint8_t* dv,
                      int16_t* f1, int16_t* f2);
 int  mnms_blocks(int extent, int n, int margin);
+void mlaunch_half_filters(void* stream, const uint8_t* I, int w, int h, int bpl, uint8_t* Ih, int hw, int hh, int hbpl,
+                          uint8_t* du_full, uint8_t* dv_full);
 void mlaunch_features(void* stream, const int16_t* f1, const int16_t* f2, const uint8_t* du,
                       const uint8_t* dv, int w, int h, int bpl, int n, int tau, int margin, int scale,
                       int4* slots, int32_t* flags, int32_t* order, int32_t* table, int32_t* count);
+void mlaunch_features2(void* stream, const int16_t* f1, const int16_t* f2, const uint8_t* du, const uint8_t* dv, int w,
+                       int h, int bpl, int tau, int margin, int scale, int n_a, int4* slots_a, int32_t* flags_a,
+                       int32_t* order_a, int32_t* table_a, int32_t* count_a, int n_b, int4* slots_b, int32_t* flags_b,
+                       int32_t* order_b, int32_t* table_b, int32_t* count_b, int32_t* host_counts);
 // up to 8 feature tables whose bin indices are built by one launch (one workgroup each)
 struct BinJobs {
     const int32_t* table[8];
@@ -63,7 +69,7 @@ void mlaunch_bin_index(void* stream, const BinJobs& J, int njobs, int n_host_max
 void mlaunch_match(void* stream, const MatchParams& P, const FeatView& m1p, const FeatView& m2p,
                    const FeatView& m1c, const FeatView& m2c, int nquery_cap, const float* ranges,
                    int use_prior, svh_p_match* slots, int32_t* flags, int32_t* pixel_owner,
-                   svh_p_match* out, int32_t* out_count);
+                   svh_p_match* out, int32_t* out_count, int32_t* out_count_host = nullptr);
 // parabolic = 0: relocateMinimum in place; 1: parabolicFitting, survivors compacted into
 // `compacted` / `compacted_count`
 void mlaunch_refine(void* stream, svh_p_match* m, const int32_t* count, int cap, int method, int margin,

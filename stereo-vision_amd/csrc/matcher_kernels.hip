@@ -263,7 +263,8 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int value, int* total) 
 // ordered compaction of the surviving slots: order[k] = slot of the k-th feature
 __device__ __forceinline__ void d_compact_slots(const int32_t* __restrict__ flags, int nslots,
                                                         int32_t* __restrict__ order,
-                                                        int32_t* __restrict__ count, unsigned bx) {
+                                                        int32_t* __restrict__ count, unsigned bx,
+                                                        int32_t* __restrict__ count_host = nullptr) {
     const int t = threadIdx.x;
     const int chunk = ((nslots + 1023) / 1024 + 3) & ~3;   // multiple of 4: 16-byte flag loads
     const int lo = min(t * chunk, nslots), hi = min(lo + chunk, nslots);
@@ -304,7 +305,10 @@ __device__ __forceinline__ void d_compact_slots(const int32_t* __restrict__ flag
         for (int s = lo; s < hi; s++)
             if (flags[s]) order[base++] = s;
     }
-    if (t == 0) *count = total;
+    if (t == 0) {
+        *count = total;
+        if (count_host) *count_host = total;   // (pinned host memory: the count needs no copy launch of its own)
+    }
 }
 
 // M5  descriptor + record packing   matcher.cpp:534-579, 854-877
@@ -736,7 +740,8 @@ __device__ __forceinline__ void d_compact_matches(const svh_p_match* __restrict_
                                                           const int32_t* __restrict__ flags,
                                                           const int32_t* __restrict__ nslots_ptr,
                                                           svh_p_match* __restrict__ out,
-                                                          int32_t* __restrict__ count, unsigned bx) {
+                                                          int32_t* __restrict__ count, unsigned bx,
+                                                          int32_t* __restrict__ count_host = nullptr) {
     const int nslots = *nslots_ptr;
     const int t = threadIdx.x;
     const int chunk = (nslots + 1023) / 1024;
@@ -773,7 +778,10 @@ __device__ __forceinline__ void d_compact_matches(const svh_p_match* __restrict_
         for (int s = lo; s < hi; s++)
             if (flags[s]) out[base++] = in[s];
     }
-    if (t == 0) *count = total;
+    if (t == 0) {
+        *count = total;
+        if (count_host) *count_host = total;   // (pinned host memory: no copy launch for the count)
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1055,6 +1063,18 @@ __global__ __launch_bounds__(256) void k_filters_b(const FiltersJob* J) {
     d_filters<kFeatures>(gptr(a.I), a.w, a.h, a.bpl, gptr(a.du), gptr(a.dv), gptr(a.f1), gptr(a.f2), blockIdx.x, blockIdx.y);
 }
 
+// the half-resolution image and the full-resolution Sobel planes read the same uploaded image and nothing of each
+// other: one launch (single-object path), workgroups [0, gh) halve, the rest filter
+__global__ __launch_bounds__(256) void k_half_filters(HalfJob a, FiltersJob b, int ghx, int gh, int gfx) {
+    const int id = (int)blockIdx.x;
+    if (id < gh) {
+        d_half(a.I, a.bpl, a.out, a.hw, a.hh, a.hbpl, (unsigned)(id % ghx), (unsigned)(id / ghx));
+    } else {
+        const int k = id - gh;
+        d_filters<false>(b.I, b.w, b.h, b.bpl, b.du, b.dv, b.f1, b.f2, (unsigned)(k % gfx), (unsigned)(k / gfx));
+    }
+}
+
 struct NmsJob { const int16_t *f1, *f2; int w, h, bpl, n, tau, margin, ni, nj; int4* slots; int32_t* flags; };
 template <int kG>
 __global__ __launch_bounds__(256) void k_nms(NmsJob a) {
@@ -1066,6 +1086,18 @@ __global__ __launch_bounds__(256) void k_nms_b(const NmsJob* J) {
     d_nms<kG>(gptr(a.f1), gptr(a.f2), a.w, a.h, a.bpl, a.n, a.tau, a.margin, a.ni, a.nj, gptr(a.slots), gptr(a.flags), blockIdx.x);
 }
 
+// the sparse and the dense table of one camera image by the same three launches (single-object path: every launch is
+// on the frame's critical path, and the two tables have nothing to wait for in each other): workgroups [0, ga) belong
+// to job a, the rest to job b
+__global__ __launch_bounds__(256) void k_nms2(NmsJob a, NmsJob b, int ga, int small_a, int small_b) {
+    const bool first = (int)blockIdx.x < ga;
+    const NmsJob& j = first ? a : b;
+    const unsigned bx = first ? blockIdx.x : blockIdx.x - ga;
+    if (first ? small_a : small_b)
+        d_nms<16>(j.f1, j.f2, j.w, j.h, j.bpl, j.n, j.tau, j.margin, j.ni, j.nj, j.slots, j.flags, bx);
+    else
+        d_nms<64>(j.f1, j.f2, j.w, j.h, j.bpl, j.n, j.tau, j.margin, j.ni, j.nj, j.slots, j.flags, bx);
+}
 struct CompactSlotsJob { const int32_t* flags; int nslots; int32_t *order, *count; };
 __global__ __launch_bounds__(1024) void k_compact_slots(CompactSlotsJob a) { d_compact_slots(a.flags, a.nslots, a.order, a.count, 0u); }
 __global__ __launch_bounds__(1024) void k_compact_slots_b(const CompactSlotsJob* J) {
@@ -1073,9 +1105,18 @@ __global__ __launch_bounds__(1024) void k_compact_slots_b(const CompactSlotsJob*
     d_compact_slots(gptr(a.flags), a.nslots, gptr(a.order), gptr(a.count), 0u);
 }
 
+__global__ __launch_bounds__(1024) void k_compact_slots2(CompactSlotsJob a, CompactSlotsJob b, int32_t* host_a, int32_t* host_b) {
+    const CompactSlotsJob& j = blockIdx.x == 0 ? a : b;
+    d_compact_slots(j.flags, j.nslots, j.order, j.count, 0u, blockIdx.x == 0 ? host_a : host_b);
+}
 struct FeatureRecordsJob { const int4* slots; const int32_t *order, *count; const uint8_t *du, *dv; int bpl, scale; int32_t* table; };
 __global__ __launch_bounds__(256) void k_feature_records(FeatureRecordsJob a) {
     d_feature_records(a.slots, a.order, a.count, a.du, a.dv, a.bpl, a.scale, a.table, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_feature_records2(FeatureRecordsJob a, FeatureRecordsJob b, int ga) {
+    const bool first = (int)blockIdx.x < ga;
+    const FeatureRecordsJob& j = first ? a : b;
+    d_feature_records(j.slots, j.order, j.count, j.du, j.dv, j.bpl, j.scale, j.table, first ? blockIdx.x : blockIdx.x - ga);
 }
 __global__ __launch_bounds__(256) void k_feature_records_b(const FeatureRecordsJob* J) {
     const FeatureRecordsJob a = J[blockIdx.z];
@@ -1119,7 +1160,7 @@ __global__ __launch_bounds__(256) void k_match_dedupe_b(const DedupeJob* J) {
 }
 
 struct CompactMatchesJob { const svh_p_match* in; const int32_t *flags, *nslots; svh_p_match* out; int32_t* count; };
-__global__ __launch_bounds__(1024) void k_compact_matches(CompactMatchesJob a) { d_compact_matches(a.in, a.flags, a.nslots, a.out, a.count, 0u); }
+__global__ __launch_bounds__(1024) void k_compact_matches(CompactMatchesJob a, int32_t* count_host) { d_compact_matches(a.in, a.flags, a.nslots, a.out, a.count, 0u, count_host); }
 __global__ __launch_bounds__(1024) void k_compact_matches_b(const CompactMatchesJob* J) {
     const CompactMatchesJob a = J[blockIdx.z];
     d_compact_matches(gptr(a.in), gptr(a.flags), gptr(a.nslots), gptr(a.out), gptr(a.count), 0u);
@@ -1253,6 +1294,22 @@ void mlaunch_filters(void* stream, const uint8_t* I, int w, int h, int bpl, uint
         hipLaunchKernelGGL(k_filters<false>, grid, block, 0, (hipStream_t)stream, a);
 }
 
+// k_half on I -> Ih and the Sobel planes of I (no feature images) by one launch
+void mlaunch_half_filters(void* stream, const uint8_t* I, int w, int h, int bpl, uint8_t* Ih, int hw, int hh, int hbpl,
+                          uint8_t* du_full, uint8_t* dv_full) {
+    if (t_rec || FX != 64) {
+        mlaunch_half(stream, I, bpl, Ih, hw, hh, hbpl);
+        mlaunch_filters(stream, I, w, h, bpl, du_full, dv_full, nullptr, nullptr);
+        return;
+    }
+    const HalfJob a = {I, bpl, Ih, hw, hh, hbpl};
+    const FiltersJob b = {I, w, h, bpl, du_full, dv_full, nullptr, nullptr};
+    const int ghx = (hw + 63) / 64, ghy = (hh + 3) / 4;
+    const int gfx = (bpl / 4 + FX - 1) / FX, gfy = (h + 4 * FR - 1) / (4 * FR);
+    hipLaunchKernelGGL(k_half_filters, dim3(ghx * ghy + gfx * gfy), dim3(64, 4), 0, (hipStream_t)stream, a, b, ghx,
+                       ghx * ghy, gfx);
+}
+
 int mnms_blocks(int extent, int n, int margin) {
     int c = 0;
     for (int i = n + margin; i < extent - n - margin; i += n + 1) c++;
@@ -1285,6 +1342,35 @@ void mlaunch_features(void* stream, const int16_t* f1, const int16_t* f2, const 
     if (nb > 0) hipLaunchKernelGGL(k_feature_records, dim3((nb * 4 * 8 + 255) / 256), dim3(256), 0, s, af);
 }
 
+// both tables of a camera image (n_a: the sparse table's NMS radius, n_b: the dense one's); scratch set per table;
+// the two counts also go to host_counts[0..1] (pinned), written by the compaction itself
+void mlaunch_features2(void* stream, const int16_t* f1, const int16_t* f2, const uint8_t* du, const uint8_t* dv, int w,
+                       int h, int bpl, int tau, int margin, int scale, int n_a, int4* slots_a, int32_t* flags_a,
+                       int32_t* order_a, int32_t* table_a, int32_t* count_a, int n_b, int4* slots_b, int32_t* flags_b,
+                       int32_t* order_b, int32_t* table_b, int32_t* count_b, int32_t* host_counts) {
+    hipStream_t s = (hipStream_t)stream;
+    const int ni_a = mnms_blocks(w, n_a, margin), nj_a = mnms_blocks(h, n_a, margin), nb_a = ni_a * nj_a;
+    const int ni_b = mnms_blocks(w, n_b, margin), nj_b = mnms_blocks(h, n_b, margin), nb_b = ni_b * nj_b;
+    if (t_rec || nb_a <= 0 || nb_b <= 0) {   // (recorded batches and degenerate images: the two plain sequences)
+        mlaunch_features(stream, f1, f2, du, dv, w, h, bpl, n_a, tau, margin, scale, slots_a, flags_a, order_a, table_a, count_a);
+        mlaunch_features(stream, f1, f2, du, dv, w, h, bpl, n_b, tau, margin, scale, slots_b, flags_b, order_b, table_b, count_b);
+        // (count_a and count_b are consecutive words of the view: one copy, as the callers of mlaunch_features do)
+        mlaunch_copy(stream, host_counts, count_a, 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
+        return;
+    }
+    const NmsJob na = {f1, f2, w, h, bpl, n_a, tau, margin, ni_a, nj_a, slots_a, flags_a};
+    const NmsJob nb = {f1, f2, w, h, bpl, n_b, tau, margin, ni_b, nj_b, slots_b, flags_b};
+    const bool small_a = (n_a + 1) * (n_a + 1) <= 16, small_b = (n_b + 1) * (n_b + 1) <= 16;
+    const int ga = small_a ? (nb_a + 15) / 16 : (nb_a + 3) / 4, gb = small_b ? (nb_b + 15) / 16 : (nb_b + 3) / 4;
+    hipLaunchKernelGGL(k_nms2, dim3(ga + gb), dim3(256), 0, s, na, nb, ga, small_a ? 1 : 0, small_b ? 1 : 0);
+    const CompactSlotsJob ca = {flags_a, nb_a * 4, order_a, count_a}, cb = {flags_b, nb_b * 4, order_b, count_b};
+    hipLaunchKernelGGL(k_compact_slots2, dim3(2), dim3(1024), 0, s, ca, cb, host_counts, host_counts + 1);
+    const FeatureRecordsJob fa = {slots_a, order_a, count_a, du, dv, bpl, scale, table_a};
+    const FeatureRecordsJob fb = {slots_b, order_b, count_b, du, dv, bpl, scale, table_b};
+    const int ra = (nb_a * 4 * 8 + 255) / 256, rb = (nb_b * 4 * 8 + 255) / 256;
+    hipLaunchKernelGGL(k_feature_records2, dim3(ra + rb), dim3(256), 0, s, fa, fb, ra);
+}
+
 void mlaunch_bin_index(void* stream, const BinJobs& J, int njobs, int n_host_max, int ub, int vb, int binsize,
                        int32_t* cursor) {
     const int nb = 4 * ub * vb;
@@ -1311,7 +1397,7 @@ void mlaunch_bin_index(void* stream, const BinJobs& J, int njobs, int n_host_max
 void mlaunch_match(void* stream, const MatchParams& P, const FeatView& m1p, const FeatView& m2p,
                    const FeatView& m1c, const FeatView& m2c, int nquery_cap, const float* ranges,
                    int use_prior, svh_p_match* slots, int32_t* flags, int32_t* pixel_owner,
-                   svh_p_match* out, int32_t* out_count) {
+                   svh_p_match* out, int32_t* out_count, int32_t* out_count_host) {
     hipStream_t s = (hipStream_t)stream;
     const FeatView& q = P.method == 2 ? m1p : m1c;
     if (P.method < 2) mlaunch_fill(stream, pixel_owner, 0x7F, (size_t)P.width * P.height * sizeof(int32_t));
@@ -1331,7 +1417,7 @@ void mlaunch_match(void* stream, const MatchParams& P, const FeatView& m1p, cons
         hipLaunchKernelGGL(k_match, dim3((nquery_cap * kQ + 127) / 128), dim3(128), 0, s, am);
         if (P.method < 2) hipLaunchKernelGGL(k_match_dedupe, dim3((nquery_cap + 255) / 256), dim3(256), 0, s, ad);
     }
-    hipLaunchKernelGGL(k_compact_matches, dim3(1), dim3(1024), 0, s, ac);
+    hipLaunchKernelGGL(k_compact_matches, dim3(1), dim3(1024), 0, s, ac, out_count_host);
 }
 
 void mlaunch_refine(void* stream, svh_p_match* m, const int32_t* count, int cap, int method, int margin,
@@ -1355,7 +1441,7 @@ void mlaunch_refine(void* stream, svh_p_match* m, const int32_t* count, int cap,
         return t_rec->add(b_compact_matches, ac, 1);
     }
     if (cap > 0) hipLaunchKernelGGL(k_refine_parabolic, dim3((cap + 127) / 128), dim3(128), 0, s, ar);
-    hipLaunchKernelGGL(k_compact_matches, dim3(1), dim3(1024), 0, s, ac);
+    hipLaunchKernelGGL(k_compact_matches, dim3(1), dim3(1024), 0, s, ac, (int32_t*)nullptr);
 }
 
 }  // namespace svh

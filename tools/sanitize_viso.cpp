@@ -88,6 +88,7 @@ void mlaunch_copy(void*, void* dst, const void* src, size_t bytes, int) { memcpy
 void mlaunch_fill(void*, void* dst, int v, size_t bytes) { memset(dst, v, bytes); }
 void mlaunch_half(void*, const uint8_t*, int, uint8_t*, int, int, int) {}
 void mlaunch_filters(void*, const uint8_t*, int, int, int, uint8_t*, uint8_t*, int16_t*, int16_t*) {}
+void mlaunch_half_filters(void*, const uint8_t*, int, int, int, uint8_t*, int, int, int, uint8_t*, uint8_t*) {}
 int mnms_blocks(int extent, int n, int margin) { const int e = extent - 2 * margin; return e <= 0 ? 0 : (e + n) / (n + 1); }
 void mlaunch_features(void*, const int16_t*, const int16_t*, const uint8_t* du, const uint8_t*, int w, int h, int, int n,
                       int, int margin, int scale, int4*, int32_t*, int32_t*, int32_t* table, int32_t* count) {
@@ -107,10 +108,18 @@ void mlaunch_features(void*, const int16_t*, const int16_t*, const uint8_t* du, 
         }
     *count = k;
 }
+void mlaunch_features2(void* st, const int16_t* f1, const int16_t* f2, const uint8_t* du, const uint8_t* dv, int w, int h,
+                       int bpl, int tau, int margin, int scale, int n_a, int4* sa, int32_t* fa, int32_t* oa, int32_t* ta,
+                       int32_t* ca, int n_b, int4* sb, int32_t* fb, int32_t* ob, int32_t* tb, int32_t* cb, int32_t* host_counts) {
+    mlaunch_features(st, f1, f2, du, dv, w, h, bpl, n_a, tau, margin, scale, sa, fa, oa, ta, ca);
+    mlaunch_features(st, f1, f2, du, dv, w, h, bpl, n_b, tau, margin, scale, sb, fb, ob, tb, cb);
+    host_counts[0] = *ca;
+    host_counts[1] = *cb;
+}
 void mlaunch_bin_index(void*, const BinJobs&, int, int, int, int, int, int32_t*) {}
 void mlaunch_match(void*, const MatchParams& P, const FeatView& m1p, const FeatView&, const FeatView& m1c,
                    const FeatView&, int nquery_cap, const float*, int, svh_p_match*, int32_t*, int32_t*,
-                   svh_p_match* out, int32_t* out_count) {
+                   svh_p_match* out, int32_t* out_count, int32_t* out_count_host) {
     // every third feature of the current left image "matches": consistent small flow and disparity
     const int nc = *m1c.count, np = *m1p.count;
     int k = 0;
@@ -127,6 +136,7 @@ void mlaunch_match(void*, const MatchParams& P, const FeatView& m1p, const FeatV
         out[k++] = m;
     }
     *out_count = k;
+    if (out_count_host) *out_count_host = k;
 }
 void mlaunch_refine(void*, svh_p_match* m, const int32_t* count, int, int, int, const SobelView&, const SobelView&,
                     const SobelView&, const SobelView&, int parabolic, int32_t*, svh_p_match* compacted,
