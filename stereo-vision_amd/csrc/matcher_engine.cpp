@@ -709,7 +709,7 @@ static int remove_outliers(const svh_matcher_params& p, std::vector<svh_p_match>
     std::vector<int32_t> tri((size_t)3 * (2 * n + 16));
     // the Matcher is a single-stream, latency-bound path: large votes triangulate on helper threads
     const int par = n >= kVoteParMin ? vote_par_depth() : 0;
-    const int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 16, par);
+    const int32_t nt = delaunay(pts.data(), n, tri.data(), 2 * n + 16, par, /*expect_dups=*/true);
     if (nt < 0) return mfail(SVH_ERR_UNSUPPORTED, "outlier triangulation failed");
     const float ft = (float)p.outlier_flow_tolerance, dt = (float)p.outlier_disp_tolerance;
     // support of a vertex = its triangle edges whose endpoints agree (an edge counts once per triangle it bounds)

@@ -79,7 +79,7 @@ void mlaunch_refine(void* stream, svh_p_match* m, const int32_t* count, int cap,
 
 // par_depth > 0: the top `par_depth` levels of the divide-and-conquer run their halves on two
 // threads (2^par_depth threads in all); the output is identical to the sequential run
-int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap, int par_depth = 0);
+int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap, int par_depth = 0, bool expect_dups = false);
 // the helper threads of delaunay.cpp (see svh_internal.h): fn(0) here, fn(1 .. k-1) on helpers; poll / sleep
 void run_many(int k, const std::function<void(int)>& fn);
 void helpers_warm(int want, int us);

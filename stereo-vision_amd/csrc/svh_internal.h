@@ -101,7 +101,7 @@ void expand_grid(const svh_elas_params& p, const Dims& d, const uint32_t* mask,
 
 // par_depth > 0: the top `par_depth` levels of the divide-and-conquer run their halves on two
 // threads (2^par_depth threads in all); the output is identical to the sequential run
-int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap, int par_depth = 0);
+int32_t delaunay(const float* pts, int32_t n, int32_t* tri, int32_t cap, int par_depth = 0, bool expect_dups = false);
 
 // ---------------------------------------------------------------- device-side E5-E7
 // The stages between the two matching phases on the GPU (elas_stage_kernels.hip): lattice filters

@@ -50,7 +50,8 @@ int main(int argc, char** argv) {
             std::vector<int32_t> a(3 * (2 * n + 16)), b(a.size());
             const int32_t na = delaunay(pts.data(), n, a.data(), 2 * n + 16, 0);
             for (int depth = 1; depth <= 3; depth++) {
-                const int32_t nb = delaunay(pts.data(), n, b.data(), 2 * n + 16, depth);
+                // (odd depths with the Matcher's hint: the mirrored quicksort without the radix sort ahead of it)
+                const int32_t nb = delaunay(pts.data(), n, b.data(), 2 * n + 16, depth, (depth & 1) != 0);
                 if (na != nb || (na > 0 && memcmp(a.data(), b.data(), sizeof(int32_t) * 3 * na) != 0)) {
                     fprintf(stderr, "thread %d round %d kind %d n %d depth %d: parallel result differs\n", id, r, kind,
                             n, depth);
