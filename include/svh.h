@@ -348,7 +348,7 @@ int32_t svh_delaunay_mt(const float* pts, int32_t n, int32_t* tri, int32_t cap, 
  * of one svh_elas_process call) run on up to seven helper threads of the library.  They exist only on the latency
  * paths -- one sequence per process side; batch and lockstep entries never use them --, sleep between uses, poll for
  * work during a parallel section (at most ~0.3 ms per frame / call) and pin themselves to the cores that share the
- * calling thread's L3 cache.  Counters since the library was loaded: out[0] tasks run, out[1] of them after the helper
+ * calling thread's L3 cache; there are no more of them than the process has CPUs to spare (none below three CPUs).  Counters since the library was loaded: out[0] tasks run, out[1] of them after the helper
  * moved to another L3 domain, out[2] handed to a polling helper, out[3] to a sleeping one (a futex wake, 30-50 us late) */
 void svh_host_helper_stats(int64_t out[4]);
 

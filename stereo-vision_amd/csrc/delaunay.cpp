@@ -139,6 +139,28 @@ struct HelperPool {
         std::condition_variable cv;
     };
     Box box[kHelpers];
+    // A helper that polls is a busy core: no more helpers than the process has CPUs to spare (its affinity mask, and
+    // the CPU quota of its cgroup if it has one) beyond the calling thread's -- none at all below three CPUs, where a
+    // polling helper would run INSTEAD of the caller.  Callers see a pool that is always busy and do the work themselves.
+    const int usable = helper_budget();
+    static int helper_budget() {
+        cpu_set_t allowed;
+        CPU_ZERO(&allowed);
+        int cpus = sched_getaffinity(0, sizeof(allowed), &allowed) == 0 ? CPU_COUNT(&allowed) : 1;
+        for (const char* path : {"/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"}) {
+            FILE* f = fopen(path, "r");
+            if (!f) continue;
+            char buf[64] = {0};
+            long quota = -1, period = 100000;
+            if (fgets(buf, sizeof(buf), f)) {
+                if (sscanf(buf, "%ld %ld", &quota, &period) < 1) quota = -1;   // ("max 100000": no quota)
+            }
+            fclose(f);
+            if (quota > 0 && period > 0) cpus = std::min<long>(cpus, (quota + period - 1) / period);
+            break;
+        }
+        return cpus < 3 ? 0 : std::min(kHelpers, cpus - 1);
+    }
     std::atomic<int64_t> n_tasks{0}, n_moves{0}, n_hot{0}, n_woken{0};   // tasks run, of them after a move to another L3; taken by a polling / a sleeping helper
     std::atomic<int64_t> warm_until{0};   // helpers poll instead of sleeping until then
     std::mutex spawn_mu;
@@ -202,12 +224,14 @@ struct HelperPool {
     }
     // false: no helper free right now -- the caller runs the task itself
     bool submit(const std::function<void()>& fn, std::atomic<int>* done) {
-        for (Box& b : box)
-            if (b.state.load(std::memory_order_relaxed) == HOT && hand(&b, HOT, fn, done)) return true;
-        for (Box& b : box)
-            if (b.state.load(std::memory_order_relaxed) == PARKED && hand(&b, PARKED, fn, done)) return true;
+        for (int i = 0; i < usable; i++)
+            if (box[i].state.load(std::memory_order_relaxed) == HOT && hand(&box[i], HOT, fn, done)) return true;
+        for (int i = 0; i < usable; i++)
+            if (box[i].state.load(std::memory_order_relaxed) == PARKED && hand(&box[i], PARKED, fn, done)) return true;
+        if (usable == 0) return false;
         std::lock_guard<std::mutex> lk(spawn_mu);
-        for (Box& b : box)
+        for (int i = 0; i < usable; i++) {
+            Box& b = box[i];
             if (b.state.load(std::memory_order_relaxed) == ABSENT) {
                 b.fn = fn;
                 b.done = done;
@@ -216,6 +240,7 @@ struct HelperPool {
                 std::thread(&HelperPool::worker, this, &b).detach();
                 return true;
             }
+        }
         return false;
     }
     void warm(int want, int64_t ns) {
@@ -226,7 +251,7 @@ struct HelperPool {
         warm_until.store(mono_ns() + ns, std::memory_order_relaxed);
         int n = 0;
         for (Box& b : box) {
-            if (n++ >= want) break;
+            if (n++ >= std::min(want, usable)) break;
             const int st = b.state.load(std::memory_order_relaxed);
             if (st == ABSENT) {
                 std::lock_guard<std::mutex> lk(spawn_mu);

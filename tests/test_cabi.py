@@ -277,3 +277,39 @@ def test_private_rand_stream_is_glibc_rand():
         libc.srand(C.c_uint(seed))
         want = np.fromiter((libc.rand() for _ in range(n)), np.int32, n)
         assert np.array_equal(got, want), seed
+
+
+def test_helper_threads_respect_the_cpus_of_the_process():
+    """a polling helper is a busy core: with fewer than three CPUs in the affinity mask the parallel triangulation runs
+    on the calling thread alone (no helper task at all), with four it uses at most three helpers -- and the triangle
+    list is the sequential one either way"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, ctypes as C
+        import numpy as np
+        cpus = sorted(os.sched_getaffinity(0))[:int(sys.argv[1])]
+        os.sched_setaffinity(0, set(cpus))
+        sys.path.insert(0, %r)
+        import svhip as S
+        lib = S.lib()
+        rng = np.random.default_rng(5)
+        pts = np.ascontiguousarray(rng.integers(0, 600, (3000, 2)) * 2.0, np.float32)
+        want = S.delaunay(pts)
+        tri = np.zeros((2 * len(pts) + 16) * 3, np.int32)
+        for rep in range(5):
+            nt = lib.svh_delaunay_mt(pts.ctypes.data_as(C.c_void_p), len(pts), tri.ctypes.data_as(C.c_void_p), 2 * len(pts) + 16, 3)
+            assert nt == len(want) and np.array_equal(tri[:3 * nt].reshape(-1, 3), want)
+        st = (C.c_int64 * 4)()
+        lib.svh_host_helper_stats(st)
+        print(len(cpus), st[0])
+    """ % os.path.join(H.ROOT, "stereo-vision_amd"))
+    have = len(os.sched_getaffinity(0))
+    out = subprocess.run([sys.executable, "-c", code, "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    n, tasks = map(int, out.stdout.split())
+    assert tasks == 0, "two CPUs: no helper may run"
+    if have >= 4:
+        out = subprocess.run([sys.executable, "-c", code, "4"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        n, tasks = map(int, out.stdout.split())
+        assert n == 4 and tasks > 0
