@@ -63,12 +63,18 @@ def test_latency_path_without_taps_matches_golden(case):
     m = H.ProductMatcher(prm)
     m.lib.svh_matcher_set_taps(C.c_void_p(m.h), 0)
     want = z["dense"]
+    st0, st1 = (C.c_int64 * 4)(), (C.c_int64 * 4)()
+    m.lib.svh_host_helper_stats(st0)
     for rep in range(4):
         m.push_back(im["I1p"], im["I2p"])
         m.push_back(im["I1c"], im["I2c"])
         assert m.match(method, tr) == 0
         got = m.matches()
         assert len(got) == len(want) and (got == want).all(), rep
+    m.lib.svh_host_helper_stats(st1)
+    if len(os.sched_getaffinity(0)) >= 3:
+        # (from the second call on the vote is expected to be large: its halves and its four parts went to helpers)
+        assert st1[0] > st0[0], "the dense votes ran without a helper thread"
 
 
 @pytest.mark.parametrize("kw,method", [
