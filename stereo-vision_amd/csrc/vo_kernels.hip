@@ -121,22 +121,53 @@ __device__ __forceinline__ bool wave_solve6(double& a, int lane) {
             v = fabs(a);
             pos = r * 6 + cidx;
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const double ov = __shfl_xor(v, m, 64);
-            const int op = __shfl_xor(pos, m, 64);
+        // largest (|a|, position) pair of the wave.  Round 6: four DPP steps inside each row of 16 lanes (pairs, quads,
+        // half-row mirror, row mirror: every lane then holds its row's winner) and the four row winners combined from
+        // scalar reads, instead of six dependent ds_bpermute round trips per pivot -- the solve was a chain of ~55
+        // LDS-crossbar latencies, two thirds of a Gauss-Newton iteration of one hypothesis.  The winner does not
+        // depend on the order in which pairs are compared.
+        auto take = [&](double ov, int op) {
             if (ov > v || (ov == v && op > pos)) {
                 v = ov;
                 pos = op;
             }
+        };
+#define SVH_DPP_STEP(CTRL)                                                                                      \
+        {                                                                                                       \
+            const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);            \
+            const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);            \
+            const int op = __builtin_amdgcn_update_dpp(0, pos, CTRL, 0xF, 0xF, false);                          \
+            take(__hiloint2double(hi, lo), op);                                                                 \
         }
+        SVH_DPP_STEP(0xB1)    // quad_perm [1,0,3,2]
+        SVH_DPP_STEP(0x4E)    // quad_perm [2,3,0,1]
+        SVH_DPP_STEP(0x141)   // row_half_mirror
+        SVH_DPP_STEP(0x140)   // row_mirror
+#undef SVH_DPP_STEP
+        {
+            double rv[4];
+            int rp[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int lo = __builtin_amdgcn_readlane(__double2loint(v), 16 * q);
+                const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 16 * q);
+                rv[q] = __hiloint2double(hi, lo);
+                rp[q] = __builtin_amdgcn_readlane(pos, 16 * q);
+            }
+            v = rv[0];
+            pos = rp[0];
+#pragma unroll
+            for (int q = 1; q < 4; q++) take(rv[q], rp[q]);
+        }
+        pos = __builtin_amdgcn_readfirstlane(pos);   // (the same in every lane: scalar from here on)
         const int irow = pos / 6, icol = pos - 6 * irow;
         used |= 1u << icol;
         if (irow != icol) {   // swap rows irow and icol (uniform branch)
             const int src = r == irow ? icol * 7 + cidx : (r == icol ? irow * 7 + cidx : lane);
             a = __shfl(a, elem ? src : lane, 64);
         }
-        const double pivot = __shfl(a, icol * 7 + icol, 64);
+        const double pivot = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), icol * 7 + icol),
+                                              __builtin_amdgcn_readlane(__double2loint(a), icol * 7 + icol));   // (a uniform lane)
         if (fabs(pivot) < 1e-20) return false;
         const double pivinv = __ddiv_rn(1.0, pivot);
         if (elem && r == icol) a = __dmul_rn(cidx == icol ? 1.0 : a, pivinv);
