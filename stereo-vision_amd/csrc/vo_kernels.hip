@@ -184,15 +184,27 @@ enum { VO_UPDATED = 0, VO_FAILED = 1, VO_CONVERGED = 2 };
 // res [rows] (LDS or global).  Lane e < 42 sums its entry of [JtJ | Jt r] over the rows in
 // ascending order (the reference's loop order; loads are batched, the add chain is not
 // reordered), the wave solves, lanes 0..5 update tr (LDS).  Returns the status uniformly.
+// kCols: J is stored column by column, J[col * stride + row] (stride a multiple of 8, the rows up to the next multiple
+// of 8 exist and are ignored): a lane's eight operands of a turn are consecutive, two per 16-byte LDS read -- half the
+// LDS instructions of the row-major form, which issued 2 000 of them per lane and iteration next to the 1 000 additions
+// that have to be a chain.  The order of the additions is the same.
+template <bool kCols = false>
 __device__ __forceinline__ int wave_gn_step(const double* J, const double* res, int rows, int lane,
-                                            double* s_tr, double eps) {
+                                            double* s_tr, double eps, int stride = 0) {
     const int m = lane / 7, n = lane - 7 * m;
     double acc = 0.0;
     if (lane < 42) {
+        const double* xc = kCols ? J + (size_t)m * stride : J;
+        const double* yc = kCols ? (n < 6 ? J + (size_t)n * stride : res) : J;
         for (int i0 = 0; i0 < rows; i0 += 8) {
             double x[8], y[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
+                if (kCols) {
+                    x[q] = xc[i0 + q];
+                    y[q] = yc[i0 + q];
+                    continue;
+                }
                 const int i = i0 + q < rows ? i0 + q : rows - 1;
                 x[q] = J[i * 6 + m];
                 y[q] = n < 6 ? J[i * 6 + n] : res[i];
@@ -290,9 +302,10 @@ __device__ __forceinline__ void d_vo_ransac(const svh_p_match* __restrict__ pm, 
 
 // Gauss-Newton refinement on the inlier set (viso_stereo.cpp:122-150 on the winning hypothesis):
 // all 256 threads fill the Jacobian / residual rows, wave 0 forms and solves the normal equations.
+template <bool kCols>
 __device__ __forceinline__ int vo_refine_loop(double* J, double* res, const svh_p_match* __restrict__ pm,
                                               const int32_t* __restrict__ inliers, int nin, const VoCalib& c,
-                                              double* s_tr, int* s_status, int t) {
+                                              double* s_tr, int* s_status, int t, int stride) {
     int status = VO_UPDATED, iter = 0;
     while (status == VO_UPDATED) {
         double tr[6];
@@ -308,10 +321,15 @@ __device__ __forceinline__ int vo_refine_loop(double* J, double* res, const svh_
             for (int col = 0; col < 6; col++) {
                 double j0, j1, j2;
                 jacobian_col(R, P, q, w, c, col, &j0, &j1, &j2);
-                J[(size_t)(4 * a + 0) * 6 + col] = j0;
-                J[(size_t)(4 * a + 1) * 6 + col] = j1;
-                J[(size_t)(4 * a + 2) * 6 + col] = j2;
-                J[(size_t)(4 * a + 3) * 6 + col] = j1;
+                if (kCols) {
+                    double* jc = J + (size_t)col * stride + 4 * a;
+                    jc[0] = j0; jc[1] = j1; jc[2] = j2; jc[3] = j1;
+                } else {
+                    J[(size_t)(4 * a + 0) * 6 + col] = j0;
+                    J[(size_t)(4 * a + 1) * 6 + col] = j1;
+                    J[(size_t)(4 * a + 2) * 6 + col] = j2;
+                    J[(size_t)(4 * a + 3) * 6 + col] = j1;
+                }
             }
             res[4 * a + 0] = w * ((double)m.u1c - q.p[0]);
             res[4 * a + 1] = w * ((double)m.v1c - q.p[1]);
@@ -320,7 +338,7 @@ __device__ __forceinline__ int vo_refine_loop(double* J, double* res, const svh_
         }
         __syncthreads();
         if (t < 64) {   // wave 0 forms and solves the normal equations
-            const int st = wave_gn_step(J, res, 4 * nin, t, s_tr, 1e-8);
+            const int st = wave_gn_step<kCols>(J, res, 4 * nin, t, s_tr, 1e-8, stride);
             if (t == 0) *s_status = st;
         }
         __syncthreads();
@@ -339,7 +357,7 @@ __device__ __forceinline__ void d_vo_refine(const svh_p_match* __restrict__ pm, 
                                             double* __restrict__ Jg, double* __restrict__ resg,
                                             int lds_rows, VoResult* __restrict__ out,
                                             int32_t* __restrict__ out_inliers) {
-    extern __shared__ double s_rows[];   // [lds_rows][6] J then [lds_rows] residuals
+    extern __shared__ double s_rows[];   // J [6][lds_rows] (column by column) then [lds_rows] residuals
     __shared__ double s_tr[6];
     __shared__ int s_best, s_status, s_scan[256];
     const int t = threadIdx.x;
@@ -386,10 +404,10 @@ __device__ __forceinline__ void d_vo_refine(const svh_p_match* __restrict__ pm, 
     // otherwise) -- one generic pointer would turn every access into a flat load
     int success = 0;
     if (nin >= 6) {
-        if (4 * nin <= lds_rows)
-            success = vo_refine_loop(s_rows, s_rows + (size_t)6 * lds_rows, pm, out_inliers, nin, c, s_tr, &s_status, t);
+        if (4 * nin <= lds_rows)   // (LDS: column by column, lds_rows is a multiple of 8)
+            success = vo_refine_loop<true>(s_rows, s_rows + (size_t)6 * lds_rows, pm, out_inliers, nin, c, s_tr, &s_status, t, lds_rows);
         else
-            success = vo_refine_loop(Jg, resg, pm, out_inliers, nin, c, s_tr, &s_status, t);
+            success = vo_refine_loop<false>(Jg, resg, pm, out_inliers, nin, c, s_tr, &s_status, t, 0);
     }
     if (t == 0) {
         out->success = success;
@@ -469,7 +487,7 @@ void vlaunch_estimate(void* stream, const svh_p_match* pm, int N, const int32_t*
                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        144 * 1024), true);
     (void)attr_once;
-    int lds_rows = 4 * N;
+    int lds_rows = (4 * N + 7) & ~7;
     if ((size_t)lds_rows * 7 * sizeof(double) > 144 * 1024) lds_rows = 0;
     const VoRansacJob ar = {pm, N, samples, c, hyp_tr, hyp_count, hyp_flags, iters};
     const VoRefineJob af = {pm, N, iters, c, hyp_tr, hyp_count, hyp_flags, Jg, resg, lds_rows, out, out_inliers};
