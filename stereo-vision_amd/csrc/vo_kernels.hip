@@ -196,7 +196,27 @@ __device__ __forceinline__ int wave_gn_step(const double* J, const double* res, 
     if (lane < 42) {
         const double* xc = kCols ? J + (size_t)m * stride : J;
         const double* yc = kCols ? (n < 6 ? J + (size_t)n * stride : res) : J;
-        for (int i0 = 0; i0 < rows; i0 += 8) {
+        int i0 = 0;
+        if (kCols) {
+            // whole turns of 8 rows without the per-row test, the next turn's operands requested before this turn's
+            // chain of additions (the chain is what has to be serial; nothing else should wait for it)
+            const int full = rows & ~7;
+            double x[8], y[8], nx[8], ny[8];
+            if (full > 0) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) { x[q] = xc[q]; y[q] = yc[q]; }
+            }
+            for (; i0 < full; i0 += 8) {
+                // (past the last turn this reads the padding rows: they exist, see the layout, and are dropped)
+#pragma unroll
+                for (int q = 0; q < 8; q++) { nx[q] = xc[i0 + 8 + q]; ny[q] = yc[i0 + 8 + q]; }
+#pragma unroll
+                for (int q = 0; q < 8; q++) acc = __dadd_rn(acc, __dmul_rn(x[q], y[q]));
+#pragma unroll
+                for (int q = 0; q < 8; q++) { x[q] = nx[q]; y[q] = ny[q]; }
+            }
+        }
+        for (; i0 < rows; i0 += 8) {
             double x[8], y[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
@@ -487,7 +507,7 @@ void vlaunch_estimate(void* stream, const svh_p_match* pm, int N, const int32_t*
                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        144 * 1024), true);
     (void)attr_once;
-    int lds_rows = (4 * N + 7) & ~7;
+    int lds_rows = ((4 * N + 7) & ~7) + 8;   // (+ 8: the sums read one turn ahead)
     if ((size_t)lds_rows * 7 * sizeof(double) > 144 * 1024) lds_rows = 0;
     const VoRansacJob ar = {pm, N, samples, c, hyp_tr, hyp_count, hyp_flags, iters};
     const VoRefineJob af = {pm, N, iters, c, hyp_tr, hyp_count, hyp_flags, Jg, resg, lds_rows, out, out_inliers};
