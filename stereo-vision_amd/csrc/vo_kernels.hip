@@ -31,8 +31,12 @@ struct Rot {   // R = Rx*Ry*Rz and its partial derivatives (viso_stereo.cpp:352-
 };
 
 __device__ __forceinline__ Rot make_rot(const double* tr) {
-    const double sx = sin(tr[0]), cx = cos(tr[0]), sy = sin(tr[1]), cy = cos(tr[1]);
-    const double sz = sin(tr[2]), cz = cos(tr[2]);
+    // (sincos: one argument reduction per angle instead of two -- six fp64 sine / cosine evaluations are a large part
+    // of a Gauss-Newton iteration of one hypothesis)
+    double sx, cx, sy, cy, sz, cz;
+    sincos(tr[0], &sx, &cx);
+    sincos(tr[1], &sy, &cy);
+    sincos(tr[2], &sz, &cz);
     Rot R;
     R.r00 = +cy * cz;                R.r01 = -cy * sz;                R.r02 = +sy;
     R.r10 = +sx * sy * cz + cx * sz; R.r11 = -sx * sy * sz + cx * cz; R.r12 = -sx * cy;
