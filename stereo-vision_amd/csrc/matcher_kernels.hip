@@ -541,27 +541,48 @@ __device__ int find_match(const MatchParams& P, const FeatView& t1, int i1, cons
                     hi[j] = t2.off[b + 1];
                 }
             }
+            // a lane's first entry of each of the four bins: the four ids together, then the four records together --
+            // three round trips for a batch whose bins hold at most kQ entries each (nearly all), where the bins used
+            // to take their two trips one after the other.  Evaluated in bin order, so ties fall as before.
+            int q4[4], i4[4];
+            int4 ra4[4], rb4[4], rc4[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                for (int q = lo[j] + lane; q < hi[j]; q += kQ) {
+                q4[j] = lo[j] + lane;
+                i4[j] = q4[j] < hi[j] ? t2.ids[q4[j]] : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (i4[j] >= 0) {
+                    const int4* r4 = reinterpret_cast<const int4*>(t2.rec + (size_t)12 * i4[j]);
+                    ra4[j] = r4[0]; rb4[j] = r4[1]; rc4[j] = r4[2];
+                }
+            }
+            auto consider = [&](int i2, const int4& ra, const int4& rb, const int4& rc, int seq) {
+                const float u2 = (float)ra.x, v2 = (float)ra.y;
+                if (u2 >= u_min && u2 <= u_max && v2 >= v_min && v2 <= v_max) {
+                    const int32_t d2[8] = {rb.x, rb.y, rb.z, rb.w, rc.x, rc.y, rc.z, rc.w};
+                    double cost = (double)sad32(d1, d2);
+                    if (predicted) {
+                        const double du = __dsub_rn((double)ra.x, u_), dv = __dsub_rn((double)ra.y, v_);
+                        const double dist = __dsqrt_rn(__dadd_rn(__dmul_rn(du, du), __dmul_rn(dv, dv)));
+                        cost = __dadd_rn(cost, __dmul_rn(4.0, dist));
+                    }
+                    if (cost < min_cost) {
+                        min_ind = i2;
+                        min_cost = cost;
+                        min_seq = seq;
+                    }
+                }
+            };
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (i4[j] >= 0) consider(i4[j], ra4[j], rb4[j], rc4[j], seq0 + (q4[j] - lo[j]));
+                for (int q = q4[j] + kQ; q < hi[j]; q += kQ) {   // (a bin with more than kQ entries)
                     const int i2 = t2.ids[q];
                     const int4* r4 = reinterpret_cast<const int4*>(t2.rec + (size_t)12 * i2);
                     const int4 ra = r4[0], rb = r4[1], rc = r4[2];
-                    const float u2 = (float)ra.x, v2 = (float)ra.y;
-                    if (u2 >= u_min && u2 <= u_max && v2 >= v_min && v2 <= v_max) {
-                        const int32_t d2[8] = {rb.x, rb.y, rb.z, rb.w, rc.x, rc.y, rc.z, rc.w};
-                        double cost = (double)sad32(d1, d2);
-                        if (predicted) {
-                            const double du = __dsub_rn((double)ra.x, u_), dv = __dsub_rn((double)ra.y, v_);
-                            const double dist = __dsqrt_rn(__dadd_rn(__dmul_rn(du, du), __dmul_rn(dv, dv)));
-                            cost = __dadd_rn(cost, __dmul_rn(4.0, dist));
-                        }
-                        if (cost < min_cost) {
-                            min_ind = i2;
-                            min_cost = cost;
-                            min_seq = seq0 + (q - lo[j]);
-                        }
-                    }
+                    consider(i2, ra, rb, rc, seq0 + (q - lo[j]));
                 }
                 seq0 += hi[j] - lo[j];
             }
